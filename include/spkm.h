@@ -1,0 +1,151 @@
+/*
+ * spkm.h -- C ABI of the MI355X-native sparsified-K-means Lloyd engine (libspkm.so).
+ *
+ * This is the drop-in boundary for the reference's native layer
+ * (stephenbeckr/SparsifiedKMeans v2.1): MATLAB mex files exporting
+ *     void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+ * (private/SparseMatrixMinusCluster.c:44-45, private/SparseMatrixInnerProduct.c:40-41,
+ *  private/SparseMatrixColumnNormSq.c:35-36, private/hadamard.c:115-116,
+ *  private/hadamard_pthreads.c:227-228).  A mex gateway unpacks its mxArrays
+ * (mxGetM/N/Pr/Ir/Jc) and calls the matching spkm_* host-buffer entry point below;
+ * INTEGRATION.md shows those ~30-line gateways.  Part 2 is the device-resident engine the
+ * reference does not have (fused assign / accumulate / finalise on a shard kept in HBM).
+ *
+ * Conventions
+ *  - plain C types only; all matrices column-major (MATLAB layout); sparse matrices are CSC
+ *    with 64-bit jc/ir exactly as mxGetJc/mxGetIr return them under -largeArrayDims.
+ *  - every function returns an int status: 0 = ok, < 0 = argument error (mirrors the
+ *    reference's mexErrMsgTxt conditions; text via spkm_strerror), > 0 = hipError_t.
+ *    Nothing throws or long-jumps across the boundary; outputs are caller-owned.
+ *  - "_host" entry points take host pointers and do their own transfers; "_dev" entry points
+ *    take device pointers (e.g. torch.Tensor.data_ptr()) and enqueue on the context's stream.
+ *  - cluster indices are 0-based int32 on this side of the ABI (MATLAB value minus one).
+ */
+#ifndef SPKM_H
+#define SPKM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPKM_OK 0
+#define SPKM_ERR_NULL_ARG (-1)       /* required pointer is NULL                                          */
+#define SPKM_ERR_CENTER_ROWS (-2)    /* "Center vector must be ... pxk" SparseMatrixMinusCluster.c:104-107 */
+#define SPKM_ERR_BETA_K (-3)         /* beta form needs K == 1          SparseMatrixMinusCluster.c:119-120 */
+#define SPKM_ERR_LEN_LE_1 (-4)       /* "Vector length must be greater than 1."       hadamard.c:100-102   */
+#define SPKM_ERR_NOT_POW2 (-5)       /* "Vector length must be power of 2."           hadamard.c:108-110   */
+#define SPKM_ERR_BAD_CSC (-6)        /* jc not monotone / ir out of range / rows not ascending (not checked
+                                        by the reference; rejected here because the kernels index with them) */
+#define SPKM_ERR_UNSUPPORTED (-7)    /* shape outside what this build supports (see message)               */
+#define SPKM_ERR_NO_DEVICE (-8)      /* no HIP device / gfx950 code object could not be loaded             */
+#define SPKM_ERR_BAD_VALUE (-9)      /* scalar argument out of range                                       */
+
+typedef struct spkm_ctx spkm_ctx;     /* device id + stream + scratch; one per host thread               */
+typedef struct spkm_shard spkm_shard; /* a CSC block of points resident in HBM                            */
+
+const char *spkm_strerror(int status);
+int spkm_version(void); /* 10000*major + 100*minor + patch */
+
+/* stream: a hipStream_t (as void*) to enqueue on, or NULL for the default stream.  The
+ * context never creates threads.  Not thread-safe: use one context per host thread. */
+int spkm_ctx_create(int device, void *stream, spkm_ctx **out);
+void spkm_ctx_destroy(spkm_ctx *ctx);
+int spkm_ctx_sync(spkm_ctx *ctx); /* block until everything enqueued on the context's stream is done */
+/* device facts used by the host driver / bench: [0]=CU count, [1]=LDS bytes per workgroup,
+ * [2]=device memory bytes, [3]=wavefront size */
+int spkm_device_info(spkm_ctx *ctx, int64_t info[4]);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1 -- mex-equivalent operators, HOST buffers (one call == one mexFunction call)
+ * ------------------------------------------------------------------------------------------ */
+
+/* dist = SparseMatrixMinusCluster(X, C)        (private/SparseMatrixMinusCluster.c:1-8,104-182)
+ * dist = SparseMatrixMinusCluster(X, c, beta)  (:9-11,118-129; K must be 1)
+ * X: p x n sparse (jc[n+1], ir[nnz], x[nnz]); C: c_rows x K dense; dist: K x n dense out.
+ * c_rows != p -> SPKM_ERR_CENTER_ROWS.  beta == NULL selects the plain form. */
+int spkm_SparseMatrixMinusCluster_host(spkm_ctx *ctx, uint64_t p, uint64_t n, const uint64_t *jc,
+                                       const uint64_t *ir, const double *x, uint64_t c_rows, uint64_t K,
+                                       const double *C, const double *beta, double *dist);
+
+/* [ip, nx2] = SparseMatrixInnerProduct(X, c)    (private/SparseMatrixInnerProduct.c:1-9,87-100)
+ * c must have at least p entries (the reference's size check at :71-77 compares with n; the
+ * kernel indexes c by row).  ip, nx2: n doubles each (nx2 may be NULL). */
+int spkm_SparseMatrixInnerProduct_host(spkm_ctx *ctx, uint64_t p, uint64_t n, const uint64_t *jc,
+                                       const uint64_t *ir, const double *x, const double *c, double *ip,
+                                       double *nx2);
+
+/* nx2 = SparseMatrixColumnNormSq(X)             (private/SparseMatrixColumnNormSq.c:1-9,71-77) */
+int spkm_SparseMatrixColumnNormSq_host(spkm_ctx *ctx, uint64_t n, const uint64_t *jc, const double *x,
+                                       double *nx2);
+
+/* y = hadamard(x) / y = hadamard_pthreads(x)    (private/hadamard.c:57-152,
+ * private/hadamard_pthreads.c:69-264).  x, y: m x n dense; m must be a power of two > 1.
+ * Both reference functions give bit-identical output; both names map to one kernel. */
+int spkm_hadamard_host(spkm_ctx *ctx, uint64_t m, uint64_t n, const double *x, double *y);
+int spkm_hadamard_pthreads_host(spkm_ctx *ctx, uint64_t m, uint64_t n, const double *x, double *y);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2 -- device-resident Lloyd engine (replaces the MATLAB hot loops of
+ * kmeans_sparsified.m:417-486 and private/findClusterAssignments.m:76-82,168-171)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Upload a CSC block of n points (columns) of dimension p; indices are validated and narrowed
+ * (row ids to 16 bit when p <= 65536).  Rows must ascend within a column (MATLAB invariant). */
+int spkm_shard_create_host(spkm_ctx *ctx, uint64_t p, uint64_t n, const uint64_t *jc, const uint64_t *ir,
+                           const double *x, spkm_shard **out);
+/* Adopt device arrays without copying (caller keeps them alive): d_jc int64[n+1],
+ * d_ir uint32[nnz] (ir_bits=32) or uint16[nnz] (ir_bits=16), d_x double[nnz]. */
+int spkm_shard_create_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t nnz, const int64_t *d_jc,
+                          const void *d_ir, int ir_bits, const double *d_x, spkm_shard **out);
+void spkm_shard_destroy(spkm_shard *s);
+int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
+
+/* Length (in doubles) of the per-iteration reduce buffer for (p, K):
+ *   [ sums p*K | counts p*K | nk K | obj2 1 ]      -- one SUM all-reduce covers all of it. */
+uint64_t spkm_reduce_len(uint64_t p, uint64_t K);
+
+/* [assignments, distances] = findClusterAssignments(X, centers, [], gamma), dense-centre branch
+ * (private/findClusterAssignments.m:76-82,168-171): d_centers is p x K on the device; gamma <= 0
+ * means "gamma empty" (no centers/gamma scaling).  Outputs (device): d_assign int32[n] (0-based),
+ * d_mind double[n].  d_stats double[3] (device, may be NULL): { sum(mind^2), max(mind),
+ * first index of the max } -- the latter two feed EmptyAction='singleton'
+ * (kmeans_sparsified.m:436).  d_nk_u64 (device, K uint64, may be NULL) receives the cluster sizes. */
+int spkm_assign_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers, double gamma,
+                    int32_t *d_assign, double *d_mind, double *d_stats, uint64_t *d_nk_u64);
+
+/* Per-cluster accumulation (kmeans_sparsified.m:430-431,447-448 with the mask of :352-355):
+ * fills d_reduce (device, spkm_reduce_len doubles) = { S = sum X(:,ind), Cnt = sum spones(X)(:,ind),
+ * nk, obj2 } for this shard.  Call after spkm_assign_dev on the same context (obj2/nk are taken
+ * from that call).  The buffer is overwritten, not accumulated. */
+int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const int32_t *d_assign,
+                        double *d_reduce);
+
+/* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
+ * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;
+ * d_out double[2] (device) = { ||old-new||_F^2, obj2 } (kmeans_sparsified.m:470-471 before sqrt). */
+int spkm_finalize_dev(spkm_ctx *ctx, uint64_t p, uint64_t K, const double *d_reduce, double gamma,
+                      double *d_centers, double *d_out);
+
+/* y = hadamard(x) on device buffers (m x n, column-major). */
+int spkm_fwht_dev(spkm_ctx *ctx, uint64_t m, uint64_t n, const double *d_x, double *d_y);
+/* mix(X) = hadamard(D * [X*premul; 0]) / postdiv  (kmeans_sparsified.m:241-248,286-295):
+ * d_x is p x n, d_y is p2 x n, d_sign is p2 doubles of +-1 (NULL = none), premul = 1+2*eps or 1,
+ * postdiv = sqrt(p2) or 0 for none. */
+int spkm_mix_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, const double *d_x, const double *d_sign,
+                 double premul, double postdiv, double *d_y);
+
+/* Timing hooks for bench.py: hipEvents recorded on the context's stream around the dominant
+ * kernel of the last spkm_assign_dev call.  Returns its duration in milliseconds (blocks). */
+int spkm_last_assign_kernel_ms(spkm_ctx *ctx, double *ms);
+/* Per-launch log of the same kernel: enable=1 starts (and clears) the log, every later
+ * spkm_assign_dev records one event pair without any host sync; spkm_timing_read blocks on the
+ * stream and returns up to cap durations (ms) and the number recorded. */
+int spkm_timing_log(spkm_ctx *ctx, int enable);
+int spkm_timing_read(spkm_ctx *ctx, double *ms, int cap, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPKM_H */

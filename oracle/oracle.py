@@ -1,0 +1,192 @@
+"""ctypes front-end to the CPU oracle (oracle/_build/liborc.so).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg -- never by sparsifiedkmeans_amd/.
+PARITY UNPINNED (see oracle/orc_sparse.c header): restatement of the reference
+source, not checked against outputs of the reference itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liborc.so")
+
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_sz = C.c_size_t
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_dist_csc.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, _f64p, _f64p]
+        L.orc_dist_csc_beta.argtypes = [_sz, _u64p, _u64p, _f64p, _f64p, C.c_double, _f64p]
+        L.orc_innerprod_csc.argtypes = [_sz, _u64p, _u64p, _f64p, _f64p, _f64p, _f64p]
+        L.orc_colnormsq_csc.argtypes = [_sz, _u64p, _f64p, _f64p]
+        L.orc_min_cols.argtypes = [_sz, _sz, _f64p, _f64p, _i32p]
+        L.orc_assign.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, _f64p, C.c_double, _f64p, _i32p, _f64p]
+        L.orc_dist_sparse_centers.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, _u64p, _u64p, _f64p,
+                                              C.c_double, _f64p]
+        L.orc_accumulate.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, _i32p, _f64p, _f64p, _i64p]
+        L.orc_finalize_centers.argtypes = [_sz, _sz, _f64p, _f64p, _i64p, C.c_double, _f64p]
+        L.orc_fro_diff.argtypes = [_sz, _f64p, _f64p]
+        L.orc_fro_diff.restype = C.c_double
+        L.orc_obj.argtypes = [_sz, _f64p]
+        L.orc_obj.restype = C.c_double
+        L.orc_lloyd.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_double,
+                                _f64p, _i32p, _f64p, _f64p, _f64p]
+        L.orc_lloyd.restype = C.c_int
+        L.orc_fwht.argtypes = [C.c_uint, _sz, _f64p, _f64p]
+        L.orc_fwht_threads.argtypes = [C.c_uint, _sz, _f64p, _f64p, C.c_uint]
+        L.orc_check_pow2.argtypes = [C.c_uint]
+        L.orc_check_pow2.restype = C.c_int
+        L.orc_mix.argtypes = [C.c_uint, C.c_uint, _sz, _f64p, _f64p, C.c_double, C.c_double, _f64p, _f64p]
+        _lib = L
+    return _lib
+
+
+def _csc(jc, ir, x):
+    return (np.ascontiguousarray(jc, np.uint64), np.ascontiguousarray(ir, np.uint64),
+            np.ascontiguousarray(x, np.float64))
+
+
+def _colmajor(M):
+    """p x K array -> flat column-major buffer (MATLAB layout)."""
+    return np.ascontiguousarray(np.asarray(M, np.float64).T).ravel()
+
+
+def dist_csc(p, n, jc, ir, x, Cmat):
+    """SparseMatrixMinusCluster(X, C): returns K x n array (as numpy [K, n])."""
+    jc, ir, x = _csc(jc, ir, x)
+    Cmat = np.asarray(Cmat, np.float64).reshape(p, -1)
+    K = Cmat.shape[1]
+    out = np.zeros(n * K)
+    lib().orc_dist_csc(p, n, K, jc, ir, x, _colmajor(Cmat), out)
+    return out.reshape(n, K).T.copy()
+
+
+def dist_csc_beta(n, jc, ir, x, c, beta):
+    jc, ir, x = _csc(jc, ir, x)
+    out = np.zeros(n)
+    lib().orc_dist_csc_beta(n, jc, ir, x, np.ascontiguousarray(c, np.float64).ravel(), float(beta), out)
+    return out
+
+
+def innerprod_csc(n, jc, ir, x, c):
+    jc, ir, x = _csc(jc, ir, x)
+    ip, nx2 = np.zeros(n), np.zeros(n)
+    lib().orc_innerprod_csc(n, jc, ir, x, np.ascontiguousarray(c, np.float64).ravel(), ip, nx2)
+    return ip, nx2
+
+
+def colnormsq_csc(n, jc, x):
+    jc = np.ascontiguousarray(jc, np.uint64)
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.zeros(n)
+    lib().orc_colnormsq_csc(n, jc, x, out)
+    return out
+
+
+def min_cols(dist):
+    """MATLAB [d,a]=min(dist,[],1) on a K x n array; a is 0-based."""
+    K, n = dist.shape
+    flat = np.ascontiguousarray(dist.T).ravel()
+    mind, a = np.zeros(n), np.zeros(n, np.int32)
+    lib().orc_min_cols(K, n, flat, mind, a)
+    return mind, a
+
+
+def assign(p, n, jc, ir, x, Cmat, gamma=0.0):
+    """findClusterAssignments dense-centres branch; returns (assign0 int32[n], mind f64[n])."""
+    jc, ir, x = _csc(jc, ir, x)
+    Cmat = np.asarray(Cmat, np.float64).reshape(p, -1)
+    K = Cmat.shape[1]
+    a, mind = np.zeros(n, np.int32), np.zeros(n)
+    lib().orc_assign(p, n, K, jc, ir, x, _colmajor(Cmat), float(gamma or 0.0), np.zeros(p * K), a, mind)
+    return a, mind
+
+
+def dist_sparse_centers(p, n, jc, ir, x, cjc, cir, cx, K, gamma=0.0):
+    jc, ir, x = _csc(jc, ir, x)
+    cjc, cir, cx = _csc(cjc, cir, cx)
+    out = np.zeros(n * K)
+    lib().orc_dist_sparse_centers(p, n, K, jc, ir, x, cjc, cir, cx, float(gamma or 0.0), out)
+    return out.reshape(n, K).T.copy()
+
+
+def accumulate(p, n, K, jc, ir, x, a):
+    jc, ir, x = _csc(jc, ir, x)
+    sums, counts, nk = np.zeros(p * K), np.zeros(p * K), np.zeros(K, np.int64)
+    lib().orc_accumulate(p, n, K, jc, ir, x, np.ascontiguousarray(a, np.int32), sums, counts, nk)
+    return sums.reshape(K, p).T.copy(), counts.reshape(K, p).T.copy(), nk
+
+
+def finalize_centers(sums, counts, nk, gamma, centers):
+    p, K = sums.shape
+    c = _colmajor(centers).copy()
+    lib().orc_finalize_centers(p, K, _colmajor(sums), _colmajor(counts), np.ascontiguousarray(nk, np.int64),
+                               float(gamma), c)
+    return c.reshape(K, p).T.copy()
+
+
+def lloyd(p, n, jc, ir, x, centers, gamma, unbiased=True, maxiter=100, tol=1e-6):
+    """Dense-centre Lloyd loop (kmeans_sparsified.m:417-486).  Returns dict."""
+    jc, ir, x = _csc(jc, ir, x)
+    centers = np.asarray(centers, np.float64).reshape(p, -1)
+    K = centers.shape[1]
+    c = _colmajor(centers).copy()
+    a, mind = np.zeros(n, np.int32), np.zeros(n)
+    dff, obj = np.zeros(maxiter), np.zeros(maxiter)
+    its = lib().orc_lloyd(p, n, K, jc, ir, x, float(gamma), int(bool(unbiased)), int(maxiter), float(tol),
+                          c, a, mind, dff, obj)
+    return dict(iterations=its, centers=c.reshape(K, p).T.copy(), assign=a, mind=mind,
+                dff=dff[:its], obj=obj[:its])
+
+
+def fwht(x, threads: int = 0):
+    """hadamard(x) / hadamard_pthreads(x): x is m x n (numpy [m, n]); columns transformed."""
+    x = np.asarray(x, np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+    m, n = x.shape
+    rc = lib().orc_check_pow2(m)
+    if rc == 1:
+        raise ValueError("Vector length must be greater than 1.")
+    if rc == 2:
+        raise ValueError("Vector length must be power of 2.")
+    xin = np.ascontiguousarray(x.T).ravel()
+    out = np.zeros_like(xin)
+    if threads and threads > 1:
+        lib().orc_fwht_threads(m, n, xin, out, threads)
+    else:
+        lib().orc_fwht(m, n, xin, out)
+    return out.reshape(n, m).T.copy()
+
+
+def mix(x, d, p2):
+    """mix(X) of kmeans_sparsified.m:295 incl. the (1+2eps) pre-scale (:292)."""
+    x = np.asarray(x, np.float64)
+    p, n = x.shape
+    xin = np.ascontiguousarray(x.T).ravel()
+    out = np.zeros(n * p2)
+    lib().orc_mix(p, p2, n, xin, np.ascontiguousarray(d, np.float64), 1.0 + 2 * np.finfo(np.float64).eps,
+                  float(np.sqrt(np.float64(p2))), out, np.zeros(p2))
+    return out.reshape(n, p2).T.copy()

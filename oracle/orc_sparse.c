@@ -1,0 +1,283 @@
+/*
+ * oracle/orc_sparse.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the arithmetic of the reference's sparse hot path
+ * (stephenbeckr/SparsifiedKMeans v2.1).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this; the product path
+ * (sparsifiedkmeans_amd/) never does.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors or known-answer tests
+ * for this path, and its C files cannot be built in this image (they include
+ * MATLAB's "mex.h", which is absent; writing a stand-in header is not allowed),
+ * so this restatement has not been checked against outputs of the reference
+ * itself.  It is pinned only by (a) line-by-line correspondence with the cited
+ * reference source, (b) an independent numpy restatement (oracle/numpy_ref.py)
+ * that must agree bit-for-bit, and (c) the identities the reference documents
+ * (dist(i) == norm(X(ind,i)-c(ind)), SparseMatrixMinusCluster.c:1-8).
+ *
+ * Build flags matter for bit patterns: compile with
+ *   gcc -O -ffp-contract=off        (reference: `mex -largeArrayDims`, i.e.
+ *   -O and no -march => scalar SSE2, no FMA contraction; setup_kmeans.m:19,26,33)
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference root).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint64_t idx_t; /* mwIndex under -largeArrayDims */
+
+/* ------------------------------------------------------------------------- */
+/* private/SparseMatrixMinusCluster.c:117-184 (no-beta branch).
+ * dist is K x n column-major: dist[i*K+k] = sqrt( sum_{j in col i} (x_j - C[k*p+ir_j])^2 ),
+ * the sum running over the stored entries of column i in storage order, one
+ * subtract, one multiply and one add per (entry, k), each rounded to double.
+ * The reference unrolls K=1,2,3 with stack accumulators (:133-168) and uses a
+ * heap array for K>3 (:169-182); the arithmetic per (column, k) is the same
+ * sequence in all four branches, which is what this loop states. */
+void orc_dist_csc(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir,
+                  const double *x, const double *C, double *dist)
+{
+    double *acc = (double *)malloc((K ? K : 1) * sizeof(double));
+    for (size_t i = 0; i < n; i++) {
+        for (size_t k = 0; k < K; k++) acc[k] = 0.;
+        for (idx_t j = jc[i]; j < jc[i + 1]; j++) {
+            const double xv = x[j];
+            const size_t r = (size_t)ir[j];
+            for (size_t k = 0; k < K; k++) {
+                const double d = xv - C[k * p + r];
+                acc[k] += d * d;
+            }
+        }
+        for (size_t k = 0; k < K; k++) dist[i * K + k] = sqrt(acc[k]);
+    }
+    free(acc);
+}
+
+/* private/SparseMatrixMinusCluster.c:118-129 (beta branch, K must be 1).
+ * The reference first does beta *= -2. (:121) and then accumulates
+ *   dist += x*x + beta*x*c + c*c            (:125)
+ * which C parses as  dist += (((x*x) + ((beta*x)*c)) + (c*c)). */
+void orc_dist_csc_beta(size_t n, const idx_t *jc, const idx_t *ir, const double *x,
+                       const double *c, double beta, double *dist)
+{
+    const double b = beta * -2.;
+    for (size_t i = 0; i < n; i++) {
+        double acc = 0.;
+        for (idx_t j = jc[i]; j < jc[i + 1]; j++) {
+            const double xv = x[j], cv = c[ir[j]];
+            acc += xv * xv + b * xv * cv + cv * cv;
+        }
+        dist[i] = sqrt(acc);
+    }
+}
+
+/* private/SparseMatrixInnerProduct.c:87-100 */
+void orc_innerprod_csc(size_t n, const idx_t *jc, const idx_t *ir, const double *x,
+                       const double *c, double *ip, double *nx2)
+{
+    for (size_t i = 0; i < n; i++) {
+        double nrm = 0., inr = 0.;
+        for (idx_t j = jc[i]; j < jc[i + 1]; j++) {
+            inr += x[j] * c[ir[j]];
+            nrm += x[j] * x[j];
+        }
+        nx2[i] = nrm;
+        ip[i] = inr;
+    }
+}
+
+/* private/SparseMatrixColumnNormSq.c:71-77 */
+void orc_colnormsq_csc(size_t n, const idx_t *jc, const double *x, double *nx2)
+{
+    for (size_t i = 0; i < n; i++) {
+        double nrm = 0.;
+        for (idx_t j = jc[i]; j < jc[i + 1]; j++) nrm += x[j] * x[j];
+        nx2[i] = nrm;
+    }
+}
+
+/* private/findClusterAssignments.m:169  [distances,assignments] = min(distances,[],1)
+ * MATLAB min: smallest value per column, first index on ties, NaNs ignored
+ * unless the whole column is NaN (then NaN, index 1).  assign is 0-BASED here
+ * (the MATLAB value minus one). */
+void orc_min_cols(size_t K, size_t n, const double *dist, double *mind, int32_t *assign)
+{
+    for (size_t i = 0; i < n; i++) {
+        const double *d = dist + i * K;
+        size_t best = 0;
+        int have = 0;
+        for (size_t k = 0; k < K; k++) {
+            if (d[k] != d[k]) continue; /* NaN */
+            if (!have || d[k] < d[best]) { best = k; have = 1; }
+        }
+        mind[i] = have ? d[best] : (K ? d[0] : 0.);
+        assign[i] = (int32_t)best;
+    }
+}
+
+/* private/findClusterAssignments.m:76-82 + :169, dense-centres branch:
+ *   distances = SparseMatrixMinusCluster(X, centers/gamma)   (:78, gamma given)
+ *   distances = SparseMatrixMinusCluster(X, centers)         (:80, gamma empty)
+ *   [distances,assignments] = min(distances,[],1)            (:169)
+ * gamma <= 0 means "gamma empty".  centers/gamma is an element-wise IEEE
+ * divide.  The K x n matrix is not materialised (one column at a time): the
+ * arithmetic per column is unchanged.  Cs is caller scratch of p*K doubles. */
+void orc_assign(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir,
+                const double *x, const double *C, double gamma, double *Cs,
+                int32_t *assign, double *mind)
+{
+    const double *Cuse = C;
+    if (gamma > 0.) {
+        for (size_t t = 0; t < p * K; t++) Cs[t] = C[t] / gamma;
+        Cuse = Cs;
+    }
+    double *col = (double *)malloc((K ? K : 1) * sizeof(double));
+    for (size_t i = 0; i < n; i++) {
+        for (size_t k = 0; k < K; k++) col[k] = 0.;
+        for (idx_t j = jc[i]; j < jc[i + 1]; j++) {
+            const double xv = x[j];
+            const size_t r = (size_t)ir[j];
+            for (size_t k = 0; k < K; k++) {
+                const double d = xv - Cuse[k * p + r];
+                col[k] += d * d;
+            }
+        }
+        for (size_t k = 0; k < K; k++) col[k] = sqrt(col[k]);
+        orc_min_cols(K, 1, col, mind + i, assign + i);
+    }
+    free(col);
+}
+
+/* private/findClusterAssignments.m:63-75: sparse-centres branch.
+ * centres are a sparse p x K matrix (CSC: cjc, cir, cx).  For centre k:
+ *   ind = find(centers(:,k)); gamma_c = nnz(centers(:,k))/p            (:66-67)
+ *   distances(k,:) = SparseMatrixMinusCluster(X(ind,:)/gamma_c, full(centers(ind,k))/gamma)  (:68)
+ * or, gamma empty (:73): the same without either scaling.
+ * X(ind,:) keeps only the rows in ind, so the K=1 loop
+ * (SparseMatrixMinusCluster.c:133-141) runs over supp(x_i) ∩ supp(c_k) in
+ * ascending row order.  dist is K x n column-major (pre-zeroed by the caller's
+ * zeros(k,n), findClusterAssignments.m:57). */
+void orc_dist_sparse_centers(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir,
+                             const double *x, const idx_t *cjc, const idx_t *cir,
+                             const double *cx, double gamma, double *dist)
+{
+    double *cfull = (double *)malloc((p ? p : 1) * sizeof(double));
+    unsigned char *mask = (unsigned char *)malloc(p ? p : 1);
+    for (size_t k = 0; k < K; k++) {
+        memset(mask, 0, p);
+        const size_t nnzc = (size_t)(cjc[k + 1] - cjc[k]);
+        const double gamma_c = (double)nnzc / (double)p;
+        for (idx_t t = cjc[k]; t < cjc[k + 1]; t++) {
+            mask[cir[t]] = 1;
+            cfull[cir[t]] = (gamma > 0.) ? cx[t] / gamma : cx[t];
+        }
+        for (size_t i = 0; i < n; i++) {
+            double acc = 0.;
+            for (idx_t j = jc[i]; j < jc[i + 1]; j++) {
+                const size_t r = (size_t)ir[j];
+                if (!mask[r]) continue;
+                const double xv = (gamma > 0.) ? x[j] / gamma_c : x[j];
+                const double d = xv - cfull[r];
+                acc += d * d;
+            }
+            dist[i * K + k] = sqrt(acc);
+        }
+    }
+    free(cfull);
+    free(mask);
+}
+
+/* kmeans_sparsified.m:430-453, MLcorrection branch (:447-448), dense centres:
+ *   ind = find(assignments==ki)
+ *   centers(:,ki) = gamma*full(sum(X(:,ind),2)) ./ (full(sum(N(:,ind),2)) + 1e-16),  N = spones(X) (:354)
+ * MATLAB's sparse row-sum order is not documented; this restatement adds the
+ * columns in ascending point order (parity on centroids is therefore a 1e-6
+ * relative tolerance, not bit-exact -- BASELINE.json north_star).
+ * Clusters with no members are left untouched and reported in empty[k]=1 (the
+ * caller applies EmptyAction, :432-445).  sums/counts are p x K outputs. */
+void orc_accumulate(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir,
+                    const double *x, const int32_t *assign, double *sums, double *counts,
+                    int64_t *nk)
+{
+    memset(sums, 0, p * K * sizeof(double));
+    memset(counts, 0, p * K * sizeof(double));
+    memset(nk, 0, K * sizeof(int64_t));
+    for (size_t i = 0; i < n; i++) {
+        const size_t k = (size_t)assign[i];
+        nk[k]++;
+        for (idx_t j = jc[i]; j < jc[i + 1]; j++) {
+            sums[k * p + ir[j]] += x[j];
+            counts[k * p + ir[j]] += 1.;
+        }
+    }
+}
+
+void orc_finalize_centers(size_t p, size_t K, const double *sums, const double *counts,
+                          const int64_t *nk, double gamma, double *centers)
+{
+    for (size_t k = 0; k < K; k++) {
+        if (nk[k] == 0) continue; /* EmptyAction handled by caller */
+        for (size_t r = 0; r < p; r++)
+            centers[k * p + r] = (gamma * sums[k * p + r]) / (counts[k * p + r] + 1e-16);
+    }
+}
+
+/* kmeans_sparsified.m:470-471:  dff = norm(centersOld-centers,'fro'); obj = sqrt(sum(distances.^2)) */
+double orc_fro_diff(size_t len, const double *a, const double *b)
+{
+    double s = 0.;
+    for (size_t t = 0; t < len; t++) { const double d = a[t] - b[t]; s += d * d; }
+    return sqrt(s);
+}
+double orc_obj(size_t n, const double *mind)
+{
+    double s = 0.;
+    for (size_t i = 0; i < n; i++) s += mind[i] * mind[i];
+    return sqrt(s);
+}
+
+/* kmeans_sparsified.m:417-486, the Lloyd loop with dense centres, MLcorrection,
+ * EmptyAction='singleton' (:436-437: [~,iMax]=max(distances); centers(:,ki)=X(:,iMax)).
+ * Used as the timed CPU baseline (bench.py cpu_baseline, kind "port") and as the
+ * end-to-end checker.  Returns the number of iterations run; outputs the last
+ * assignments / min distances, dff and obj per iteration (arrays of maxiter). */
+int orc_lloyd(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir, const double *x,
+              double gamma, int unbiased, int maxiter, double tol, double *centers /* p*K in/out */,
+              int32_t *assign, double *mind, double *dff_hist, double *obj_hist)
+{
+    double *Cs = (double *)malloc(p * K * sizeof(double));
+    double *old = (double *)malloc(p * K * sizeof(double));
+    double *sums = (double *)malloc(p * K * sizeof(double));
+    double *counts = (double *)malloc(p * K * sizeof(double));
+    int64_t *nk = (int64_t *)malloc(K * sizeof(int64_t));
+    int its = 0;
+    for (its = 1; its <= maxiter; its++) {
+        orc_assign(p, n, K, jc, ir, x, centers, unbiased ? gamma : 0., Cs, assign, mind);
+        memcpy(old, centers, p * K * sizeof(double));
+        orc_accumulate(p, n, K, jc, ir, x, assign, sums, counts, nk);
+        orc_finalize_centers(p, K, sums, counts, nk, gamma, centers);
+        size_t imax = 0;
+        int have_empty = 0;
+        for (size_t k = 0; k < K; k++) if (nk[k] == 0) have_empty = 1;
+        if (have_empty) {
+            for (size_t i = 1; i < n; i++) if (mind[i] > mind[imax]) imax = i;
+            for (size_t k = 0; k < K; k++) {
+                if (nk[k] != 0) continue;
+                for (size_t r = 0; r < p; r++) centers[k * p + r] = 0.;
+                for (idx_t j = jc[imax]; j < jc[imax + 1]; j++) centers[k * p + ir[j]] = x[j];
+            }
+        }
+        const double dff = orc_fro_diff(p * K, old, centers);
+        const double obj = orc_obj(n, mind);
+        if (dff_hist) dff_hist[its - 1] = dff;
+        if (obj_hist) obj_hist[its - 1] = obj;
+        if (dff < tol) break;
+    }
+    if (its > maxiter) its = maxiter;
+    free(Cs); free(old); free(sums); free(counts); free(nk);
+    return its;
+}

@@ -1,0 +1,761 @@
+// libspkm.so -- C ABI implementation (include/spkm.h).  Unity build: the kernels are included
+// below so that hipcc emits one gfx950 code object.  Host side is plain C++17; no torch types.
+#include "assign.hip"
+#include "fwht.hip"
+#include "sparse_ops.hip"
+#include "update.hip"
+
+#include "../../include/spkm.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#define SPKM_VERSION 100
+
+struct devbuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct spkm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    size_t lds_max = 0;
+    size_t mem_bytes = 0;
+    // grow-only device scratch
+    devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
+        bmap, blk_dff, ct, tmp_assign, tmp_mind;
+    // cached launch geometry of the tiled kernel
+    int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    // optional per-launch timing log of the dominant assignment kernel (bench.py)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tlog;
+    size_t tlog_used = 0;
+    bool tlog_on = false;
+    int assign_KT = 0, assign_G = 0; // of the last assign call
+    char errmsg[256] = {0};
+};
+
+struct spkm_shard {
+    spkm_ctx* ctx = nullptr;
+    uint64_t p = 0, n = 0, nnz = 0;
+    int ir_bits = 32;
+    long long* jc = nullptr;
+    void* ir = nullptr;
+    double* x = nullptr;
+    bool owned = false;
+};
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            if (ctx) snprintf(ctx->errmsg, sizeof(ctx->errmsg), "%s: %s", #expr, hipGetErrorString(_e)); \
+            return (int)_e;                                                                             \
+        }                                                                                               \
+    } while (0)
+
+static int ensure(spkm_ctx* ctx, devbuf& b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return SPKM_OK;
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = std::max<size_t>(bytes, 256);
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.cap = want;
+    return SPKM_OK;
+}
+static void release(devbuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" const char* spkm_strerror(int status)
+{
+    switch (status) {
+    case SPKM_OK: return "ok";
+    case SPKM_ERR_NULL_ARG: return "required pointer argument is NULL";
+    case SPKM_ERR_CENTER_ROWS: return "Center vector must be or pxk, but this vector did not have p rows";
+    case SPKM_ERR_BETA_K: return "Have not yet implemented case for using 'beta' with p x k (k!=1) centers";
+    case SPKM_ERR_LEN_LE_1: return "Vector length must be greater than 1.";
+    case SPKM_ERR_NOT_POW2: return "Vector length must be power of 2.";
+    case SPKM_ERR_BAD_CSC: return "sparse matrix is not valid CSC (jc not monotone, row index out of range, or rows not ascending)";
+    case SPKM_ERR_UNSUPPORTED: return "shape not supported by this build";
+    case SPKM_ERR_NO_DEVICE: return "no usable HIP device (gfx950) available";
+    case SPKM_ERR_BAD_VALUE: return "scalar argument out of range";
+    default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown spkm status";
+}
+
+extern "C" int spkm_version(void) { return SPKM_VERSION; }
+
+extern "C" int spkm_ctx_create(int device, void* stream, spkm_ctx** out)
+{
+    if (!out) return SPKM_ERR_NULL_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return SPKM_ERR_NO_DEVICE;
+    spkm_ctx* ctx = new spkm_ctx();
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete ctx; return (int)e; }
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->mem_bytes = prop.totalGlobalMem;
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds <= 0)
+        lds = (int)prop.sharedMemPerBlock;
+    ctx->lds_max = (size_t)lds;
+    e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) { delete ctx; return (int)e; }
+    *out = ctx;
+    return SPKM_OK;
+}
+
+extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
+                     &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
+                     &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind};
+    for (devbuf* b : all) release(*b);
+    for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+extern "C" int spkm_ctx_sync(spkm_ctx* ctx)
+{
+    if (!ctx) return SPKM_ERR_NULL_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SPKM_OK;
+}
+
+extern "C" int spkm_device_info(spkm_ctx* ctx, int64_t info[4])
+{
+    if (!ctx || !info) return SPKM_ERR_NULL_ARG;
+    info[0] = ctx->num_cus;
+    info[1] = (int64_t)ctx->lds_max;
+    info[2] = (int64_t)ctx->mem_bytes;
+    info[3] = SPKM_WAVE;
+    return SPKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// shards
+// ------------------------------------------------------------------------------------------
+static int validate_csc(uint64_t p, uint64_t n, const uint64_t* jc, const uint64_t* ir)
+{
+    if (jc[0] != 0) return SPKM_ERR_BAD_CSC;
+    for (uint64_t i = 0; i < n; i++) {
+        if (jc[i + 1] < jc[i]) return SPKM_ERR_BAD_CSC;
+        for (uint64_t j = jc[i]; j < jc[i + 1]; j++) {
+            if (ir[j] >= p) return SPKM_ERR_BAD_CSC;
+            if (j > jc[i] && ir[j] <= ir[j - 1]) return SPKM_ERR_BAD_CSC;
+        }
+    }
+    return SPKM_OK;
+}
+
+extern "C" int spkm_shard_create_host(spkm_ctx* ctx, uint64_t p, uint64_t n, const uint64_t* jc,
+                                      const uint64_t* ir, const double* x, spkm_shard** out)
+{
+    if (!ctx || !out || !jc || (!ir && jc[n]) || (!x && jc[n])) return SPKM_ERR_NULL_ARG;
+    *out = nullptr;
+    if (p == 0 || p > 0x7fffffffull || n > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
+    int rc = validate_csc(p, n, jc, ir);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t nnz = jc[n];
+    spkm_shard* s = new spkm_shard();
+    s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->owned = true;
+    s->ir_bits = (p <= 65536) ? 16 : 32;
+    const size_t irb = (size_t)s->ir_bits / 8;
+    // +16 entries of slack so that clamped batch loads never leave the allocation
+    hipError_t e = hipMalloc((void**)&s->jc, (n + 1) * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(&s->ir, (nnz + 16) * irb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->x, (nnz + 16) * sizeof(double));
+    if (e != hipSuccess) { spkm_shard_destroy(s); return (int)e; }
+    std::vector<long long> jcn(n + 1);
+    for (uint64_t i = 0; i <= n; i++) jcn[i] = (long long)jc[i];
+    e = hipMemcpyAsync(s->jc, jcn.data(), (n + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    std::vector<unsigned short> ir16;
+    std::vector<unsigned int> ir32;
+    if (e == hipSuccess && nnz) {
+        if (s->ir_bits == 16) {
+            ir16.resize(nnz);
+            for (uint64_t j = 0; j < nnz; j++) ir16[j] = (unsigned short)ir[j];
+            e = hipMemcpyAsync(s->ir, ir16.data(), nnz * 2, hipMemcpyHostToDevice, ctx->stream);
+        } else {
+            ir32.resize(nnz);
+            for (uint64_t j = 0; j < nnz; j++) ir32[j] = (unsigned int)ir[j];
+            e = hipMemcpyAsync(s->ir, ir32.data(), nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(s->x, x, nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // staging vectors die here
+    if (e != hipSuccess) { spkm_shard_destroy(s); return (int)e; }
+    *out = s;
+    return SPKM_OK;
+}
+
+extern "C" int spkm_shard_create_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint64_t nnz, const int64_t* d_jc,
+                                     const void* d_ir, int ir_bits, const double* d_x, spkm_shard** out)
+{
+    if (!ctx || !out || !d_jc || (nnz && (!d_ir || !d_x))) return SPKM_ERR_NULL_ARG;
+    *out = nullptr;
+    if (p == 0 || p > 0x7fffffffull || n > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
+    if (ir_bits != 16 && ir_bits != 32) return SPKM_ERR_BAD_VALUE;
+    if (ir_bits == 16 && p > 65536) return SPKM_ERR_BAD_VALUE;
+    spkm_shard* s = new spkm_shard();
+    s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->ir_bits = ir_bits;
+    s->jc = (long long*)d_jc; s->ir = (void*)d_ir; s->x = (double*)d_x; s->owned = false;
+    *out = s;
+    return SPKM_OK;
+}
+
+extern "C" void spkm_shard_destroy(spkm_shard* s)
+{
+    if (!s) return;
+    if (s->owned) {
+        if (s->ctx) (void)hipSetDevice(s->ctx->device);
+        if (s->jc) (void)hipFree(s->jc);
+        if (s->ir) (void)hipFree(s->ir);
+        if (s->x) (void)hipFree(s->x);
+    }
+    delete s;
+}
+
+extern "C" int spkm_shard_info(const spkm_shard* s, uint64_t* p, uint64_t* n, uint64_t* nnz, int* ir_bits)
+{
+    if (!s) return SPKM_ERR_NULL_ARG;
+    if (p) *p = s->p;
+    if (n) *n = s->n;
+    if (nnz) *nnz = s->nnz;
+    if (ir_bits) *ir_bits = s->ir_bits;
+    return SPKM_OK;
+}
+
+extern "C" uint64_t spkm_reduce_len(uint64_t p, uint64_t K) { return 2 * p * K + K + 1; }
+
+// ------------------------------------------------------------------------------------------
+// assignment
+// ------------------------------------------------------------------------------------------
+static int pick_kt(const spkm_ctx* ctx, uint64_t p, uint64_t K)
+{
+    int best = 0;
+    uint64_t best_slots = ~0ull;
+    for (int kt : {16, 32, 64}) {
+        if ((p + 1) * (uint64_t)kt * 8 > ctx->lds_max) continue;
+        const uint64_t slots = ((K + kt - 1) / kt) * kt;
+        if (slots < best_slots || (slots == best_slots && kt > best)) { best = kt; best_slots = slots; }
+    }
+    return best; // 0: no tile fits -> generic kernel
+}
+
+// Workgroup -> (tile, chunk stream).  Workgroup b is observed to run on XCD b % 8, so the G
+// workgroups that stream the same chunks (one per tile) are given ids that share an XCD and
+// its L2: the chunk is fetched from HBM once and re-read from L2 by the other tiles.  This is
+// a speed heuristic only -- any placement gives the same results.
+static int build_blockmap(spkm_ctx* ctx, int G)
+{
+    const int NB = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    if (ctx->bmap_G == G && ctx->bmap_blocks == NB) return SPKM_OK;
+    std::vector<spkm_blockmap> bm(NB, spkm_blockmap{-1, 0, 1, 0});
+    const int NX = (NB % 8 == 0) ? 8 : 1;
+    const int per_xcd = NB / NX;
+    const int local_streams = per_xcd / G;
+    int nstreams = 0;
+    std::vector<int> spare;
+    for (int b = 0; b < NB; b++) {
+        const int xcd = b % NX, i = b / NX;
+        if (i < local_streams * G) {
+            bm[b].tile = i % G;
+            bm[b].stream = xcd * local_streams + i / G;
+        } else spare.push_back(b);
+    }
+    nstreams = NX * local_streams;
+    const int extra = (int)spare.size() / G; // floating streams built from the left-over workgroups
+    for (int t = 0; t < extra * G; t++) {
+        bm[spare[t]].tile = t % G;
+        bm[spare[t]].stream = nstreams + t / G;
+    }
+    nstreams += extra;
+    if (nstreams == 0) return SPKM_ERR_UNSUPPORTED; // more tiles than workgroups
+    for (auto& e : bm) e.nstreams = nstreams;
+    int rc = ensure(ctx, ctx->bmap, NB * sizeof(spkm_blockmap));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->bmap.p, bm.data(), NB * sizeof(spkm_blockmap), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->bmap_G = G; ctx->bmap_blocks = NB; ctx->bmap_streams = nstreams;
+    return SPKM_OK;
+}
+
+// Events bracket the dominant kernel on the context's own stream.  With the log enabled each
+// launch gets its own pair, so bench.py can read all durations after its timed region without
+// adding a host sync inside it.
+static hipError_t timing_begin(spkm_ctx* ctx)
+{
+    if (ctx->tlog_on) {
+        if (ctx->tlog_used == ctx->tlog.size()) {
+            hipEvent_t a, b;
+            hipError_t e = hipEventCreate(&a);
+            if (e != hipSuccess) return e;
+            e = hipEventCreate(&b);
+            if (e != hipSuccess) return e;
+            ctx->tlog.emplace_back(a, b);
+        }
+        return hipEventRecord(ctx->tlog[ctx->tlog_used].first, ctx->stream);
+    }
+    return hipEventRecord(ctx->ev0, ctx->stream);
+}
+static hipError_t timing_end(spkm_ctx* ctx)
+{
+    if (ctx->tlog_on) return hipEventRecord(ctx->tlog[ctx->tlog_used++].second, ctx->stream);
+    ctx->ev_valid = true;
+    return hipEventRecord(ctx->ev1, ctx->stream);
+}
+
+template <int KT, typename IR>
+static int launch_tile(spkm_ctx* ctx, const spkm_shard* s, int K, int G, int chunk)
+{
+    const size_t lds = (size_t)(s->p + 1) * KT * 8;
+    auto kern = k_assign_tile<KT, IR>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(timing_begin(ctx));
+    hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const long long*)s->jc,
+                       (const IR*)s->ir, (const double*)s->x, (const double*)ctx->tiles.p, (int)s->p,
+                       (long long)s->n, (long long)s->nnz, K, (const spkm_blockmap*)ctx->bmap.p, chunk,
+                       (double*)ctx->part_acc.p, (int*)ctx->part_k.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(timing_end(ctx));
+    return SPKM_OK;
+}
+
+static constexpr int COMBINE_BLOCKS = 1024;
+
+extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const double* d_centers,
+                               double gamma, int32_t* d_assign, double* d_mind, double* d_stats,
+                               uint64_t* d_nk_u64)
+{
+    if (!ctx || !s || !d_centers || !d_assign || !d_mind) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int K = (int)K64, p = (int)s->p;
+    const long long n = (long long)s->n;
+    int rc;
+    if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, 4 * 8, ctx->stream));
+        if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
+        if (d_nk_u64) HIP_TRY(hipMemsetAsync(d_nk_u64, 0, (size_t)K * 8, ctx->stream));
+        return SPKM_OK;
+    }
+    const int KT = (s->nnz > 0) ? pick_kt(ctx, s->p, K64) : 0;
+    int G = 1;
+    ctx->ev_valid = false;
+    bool tiled = KT > 0;
+    if (tiled) {
+        G = (K + KT - 1) / KT;
+        rc = build_blockmap(ctx, G);
+        if (rc == SPKM_ERR_UNSUPPORTED) tiled = false; // more tiles than workgroups
+        else if (rc) return rc;
+    }
+    if (tiled) {
+        const size_t tile_doubles = (size_t)G * (p + 1) * KT;
+        if ((rc = ensure(ctx, ctx->tiles, tile_doubles * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->part_acc, (size_t)G * n * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->part_k, (size_t)G * n * 4))) return rc;
+        hipLaunchKernelGGL(k_prep_tiles, dim3(std::min<size_t>((tile_doubles + 255) / 256, 2048)), dim3(256), 0,
+                           ctx->stream, d_centers, p, K, KT, G, gamma, (double*)ctx->tiles.p);
+        // chunk: multiple of the points one workgroup covers per sweep; small enough that every
+        // stream gets several chunks, large enough to amortise the loop overhead
+        const int ppw = 64 / KT, sweep = 16 * ppw;
+        long long chunk = n / ((long long)ctx->bmap_streams * 8);
+        chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
+        chunk = (chunk / sweep) * sweep;
+        if (s->ir_bits == 16) {
+            if (KT == 16) rc = launch_tile<16, unsigned short>(ctx, s, K, G, (int)chunk);
+            else if (KT == 32) rc = launch_tile<32, unsigned short>(ctx, s, K, G, (int)chunk);
+            else rc = launch_tile<64, unsigned short>(ctx, s, K, G, (int)chunk);
+        } else {
+            if (KT == 16) rc = launch_tile<16, unsigned int>(ctx, s, K, G, (int)chunk);
+            else if (KT == 32) rc = launch_tile<32, unsigned int>(ctx, s, K, G, (int)chunk);
+            else rc = launch_tile<64, unsigned int>(ctx, s, K, G, (int)chunk);
+        }
+        if (rc) return rc;
+    } else {
+        // generic path: row-major scaled centroids in global memory, one wave per point
+        G = 1;
+        if ((rc = ensure(ctx, ctx->ct, (size_t)p * K * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->part_acc, (size_t)n * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->part_k, (size_t)n * 4))) return rc;
+        hipLaunchKernelGGL(k_prep_rowmajor, dim3(std::min<size_t>(((size_t)p * K + 255) / 256, 2048)), dim3(256), 0,
+                           ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
+        HIP_TRY(timing_begin(ctx));
+        const int blocks = std::max(1, ctx->num_cus) * 8;
+        if (s->ir_bits == 16)
+            hipLaunchKernelGGL((k_assign_generic<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
+                               (const double*)ctx->ct.p, K, n, (double*)ctx->part_acc.p, (int*)ctx->part_k.p);
+        else
+            hipLaunchKernelGGL((k_assign_generic<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
+                               (const double*)ctx->ct.p, K, n, (double*)ctx->part_acc.p, (int*)ctx->part_k.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(timing_end(ctx));
+    }
+    ctx->assign_KT = KT;
+    ctx->assign_G = G;
+    const int cb = (int)std::min<long long>(COMBINE_BLOCKS, (n + 255) / 256);
+    if ((rc = ensure(ctx, ctx->blk_obj, (size_t)cb * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_max, (size_t)cb * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_imax, (size_t)cb * 8))) return rc;
+    hipLaunchKernelGGL(k_combine, dim3(cb), dim3(256), (size_t)K * 4, ctx->stream, (const double*)ctx->part_acc.p,
+                       (const int*)ctx->part_k.p, n, G, K, (int*)d_assign, d_mind, (double*)ctx->blk_obj.p,
+                       (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p, (unsigned long long*)ctx->nk.p);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
+                       (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, cb, (double*)ctx->stats.p);
+    HIP_TRY(hipGetLastError());
+    if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPKM_OK;
+}
+
+extern "C" int spkm_last_assign_kernel_ms(spkm_ctx* ctx, double* ms)
+{
+    if (!ctx || !ms) return SPKM_ERR_NULL_ARG;
+    if (!ctx->ev_valid) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = (double)f;
+    return SPKM_OK;
+}
+
+extern "C" int spkm_timing_log(spkm_ctx* ctx, int enable)
+{
+    if (!ctx) return SPKM_ERR_NULL_ARG;
+    ctx->tlog_on = enable != 0;
+    ctx->tlog_used = 0;
+    return SPKM_OK;
+}
+
+extern "C" int spkm_timing_read(spkm_ctx* ctx, double* ms, int cap, int* count)
+{
+    if (!ctx || !count || (cap > 0 && !ms)) return SPKM_ERR_NULL_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int nrec = (int)ctx->tlog_used;
+    for (int i = 0; i < nrec && i < cap; i++) {
+        float f = 0.f;
+        HIP_TRY(hipEventElapsedTime(&f, ctx->tlog[i].first, ctx->tlog[i].second));
+        ms[i] = (double)f;
+    }
+    *count = nrec;
+    return SPKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// accumulation + finalise
+// ------------------------------------------------------------------------------------------
+static constexpr int SEG_POINTS = 2048;
+
+extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const int32_t* d_assign,
+                                   double* d_reduce)
+{
+    if (!ctx || !s || !d_assign || !d_reduce) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int K = (int)K64, p = (int)s->p;
+    const long long n = (long long)s->n;
+    const size_t pk = (size_t)p * K;
+    double* sums = d_reduce;
+    double* counts = d_reduce + pk;
+    double* nk_f = d_reduce + 2 * pk;
+    double* obj2 = nk_f + K;
+    HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
+    if (!ctx->nk.p || !ctx->stats.p) return SPKM_ERR_BAD_VALUE; // spkm_assign_dev must come first
+    int rc;
+    const size_t slab = (size_t)p * 12;
+    if (n > 0 && s->nnz > 0) {
+        if (slab <= ctx->lds_max && slab <= 64 * 1024) {
+            const int max_items = (int)(n / SEG_POINTS) + K + 1;
+            if ((rc = ensure(ctx, ctx->perm, (size_t)n * 4))) return rc;
+            if ((rc = ensure(ctx, ctx->offs, (size_t)(K + 1) * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
+            if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
+            hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(64), 0, ctx->stream,
+                               (const unsigned long long*)ctx->nk.p, K, SEG_POINTS, (long long*)ctx->offs.p,
+                               (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p, (int*)ctx->nitems.p);
+            const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
+            const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+            hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n,
+                               K, (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
+            const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
+            if (s->ir_bits == 16)
+                hipLaunchKernelGGL((k_accumulate_sorted<unsigned short>), dim3(ab), dim3(256), slab, ctx->stream,
+                                   (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
+                                   (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
+                                   (const int*)ctx->nitems.p, p, sums, counts);
+            else
+                hipLaunchKernelGGL((k_accumulate_sorted<unsigned int>), dim3(ab), dim3(256), slab, ctx->stream,
+                                   (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
+                                   (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
+                                   (const int*)ctx->nitems.p, p, sums, counts);
+        } else {
+            const int blocks = std::max(1, ctx->num_cus) * 8;
+            if (s->ir_bits == 16)
+                hipLaunchKernelGGL((k_accumulate_atomic<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                                   (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
+                                   (const int*)d_assign, p, n, sums, counts);
+            else
+                hipLaunchKernelGGL((k_accumulate_atomic<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                                   (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
+                                   (const int*)d_assign, p, n, sums, counts);
+        }
+    }
+    hipLaunchKernelGGL(k_nk_to_f64, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ctx->nk.p, K, nk_f);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(obj2, ctx->stats.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPKM_OK;
+}
+
+static constexpr int FIN_BLOCKS = 256;
+
+extern "C" int spkm_finalize_dev(spkm_ctx* ctx, uint64_t p, uint64_t K, const double* d_reduce, double gamma,
+                                 double* d_centers, double* d_out)
+{
+    if (!ctx || !d_reduce || !d_centers || !d_out) return SPKM_ERR_NULL_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t pk = (size_t)p * K;
+    int rc;
+    if ((rc = ensure(ctx, ctx->blk_dff, FIN_BLOCKS * 8))) return rc;
+    const int fb = (int)std::min<size_t>(FIN_BLOCKS, (pk + 255) / 256);
+    hipLaunchKernelGGL(k_finalize_centers, dim3(fb), dim3(256), 0, ctx->stream, d_reduce, d_reduce + pk,
+                       d_reduce + 2 * pk, (int)p, (int)K, gamma, d_centers, (double*)ctx->blk_dff.p);
+    hipLaunchKernelGGL(k_reduce_dff, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_dff.p, fb, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(d_out + 1, d_reduce + 2 * pk + K, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// FWHT / mix
+// ------------------------------------------------------------------------------------------
+static int check_pow2(uint64_t m)
+{
+    if (m <= 1) return SPKM_ERR_LEN_LE_1; // hadamard.c:100-102
+    if (m & (m - 1)) return SPKM_ERR_NOT_POW2; // hadamard.c:104-110
+    return SPKM_OK;
+}
+
+static int fwht_launch(spkm_ctx* ctx, uint64_t p_in, uint64_t m, uint64_t n, const double* d_x,
+                       const double* d_sign, double premul, double postdiv, double* d_y)
+{
+    int rc = check_pow2(m);
+    if (rc) return rc;
+    if (p_in > m) return SPKM_ERR_BAD_VALUE;
+    if (n == 0) return SPKM_OK;
+    int logm = 0;
+    while ((1ull << logm) < m) logm++;
+    const int blocks_cap = std::max(1, ctx->num_cus) * 16;
+    if (m < 16) {
+        hipLaunchKernelGGL(k_fwht_small, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 30)), dim3(256), 0,
+                           ctx->stream, d_x, d_y, (int)m, (long long)n, (int)p_in, d_sign, premul, postdiv);
+    } else if (m <= 16384 && (m + m / 8) * 8 <= ctx->lds_max) {
+        const int T = (int)(m / 16);
+        const int threads = std::max(T, 256);
+        const int cpb = threads / T;
+        const size_t lds = (size_t)cpb * (m + m / 8) * 8;
+        HIP_TRY(hipFuncSetAttribute((const void*)k_fwht_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint64_t want = (n + cpb - 1) / cpb;
+        hipLaunchKernelGGL(k_fwht_lds, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)blocks_cap)), dim3(threads),
+                           lds, ctx->stream, d_x, d_y, (int)m, logm, (long long)n, (int)p_in, d_sign, premul,
+                           postdiv, cpb);
+    } else {
+        hipLaunchKernelGGL(k_fwht_load, dim3(blocks_cap), dim3(256), 0, ctx->stream, d_x, d_y, (long long)m,
+                           (long long)n, (long long)p_in, d_sign, premul);
+        for (uint64_t bit = 1; bit < m; bit <<= 1)
+            hipLaunchKernelGGL(k_fwht_stage, dim3(blocks_cap), dim3(256), 0, ctx->stream, d_y, (long long)m,
+                               (long long)n, (long long)bit, (bit << 1 == m) ? postdiv : 0.0);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPKM_OK;
+}
+
+extern "C" int spkm_fwht_dev(spkm_ctx* ctx, uint64_t m, uint64_t n, const double* d_x, double* d_y)
+{
+    if (!ctx || (n && (!d_x || !d_y))) return SPKM_ERR_NULL_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return fwht_launch(ctx, m, m, n, d_x, nullptr, 1.0, 0.0, d_y);
+}
+
+extern "C" int spkm_mix_dev(spkm_ctx* ctx, uint64_t p, uint64_t p2, uint64_t n, const double* d_x,
+                            const double* d_sign, double premul, double postdiv, double* d_y)
+{
+    if (!ctx || (n && (!d_x || !d_y))) return SPKM_ERR_NULL_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return fwht_launch(ctx, p, p2, n, d_x, d_sign, premul, postdiv, d_y);
+}
+
+// ------------------------------------------------------------------------------------------
+// Part 1: mex-equivalent host-buffer operators
+// ------------------------------------------------------------------------------------------
+struct tmpdev {
+    void* p = nullptr;
+    ~tmpdev() { if (p) (void)hipFree(p); }
+};
+
+extern "C" int spkm_hadamard_host(spkm_ctx* ctx, uint64_t m, uint64_t n, const double* x, double* y)
+{
+    if (!ctx || (n && (!x || !y))) return SPKM_ERR_NULL_ARG;
+    int rc = check_pow2(m);
+    if (rc) return rc;
+    if (n == 0) return SPKM_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // bounded device slabs so that arbitrarily large host matrices stream through
+    const uint64_t slab_cols = std::max<uint64_t>(1, (256ull << 20) / (m * 8));
+    tmpdev dx, dy;
+    HIP_TRY(hipMalloc(&dx.p, std::min(n, slab_cols) * m * 8));
+    HIP_TRY(hipMalloc(&dy.p, std::min(n, slab_cols) * m * 8));
+    for (uint64_t c0 = 0; c0 < n; c0 += slab_cols) {
+        const uint64_t nc = std::min(slab_cols, n - c0);
+        HIP_TRY(hipMemcpyAsync(dx.p, x + c0 * m, nc * m * 8, hipMemcpyHostToDevice, ctx->stream));
+        rc = fwht_launch(ctx, m, m, nc, (const double*)dx.p, nullptr, 1.0, 0.0, (double*)dy.p);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(y + c0 * m, dy.p, nc * m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return SPKM_OK;
+}
+
+extern "C" int spkm_hadamard_pthreads_host(spkm_ctx* ctx, uint64_t m, uint64_t n, const double* x, double* y)
+{
+    return spkm_hadamard_host(ctx, m, n, x, y);
+}
+
+extern "C" int spkm_SparseMatrixMinusCluster_host(spkm_ctx* ctx, uint64_t p, uint64_t n, const uint64_t* jc,
+                                                  const uint64_t* ir, const double* x, uint64_t c_rows, uint64_t K,
+                                                  const double* C, const double* beta, double* dist)
+{
+    if (!ctx || !jc || !C || (n && K && !dist)) return SPKM_ERR_NULL_ARG;
+    if (c_rows != p) return SPKM_ERR_CENTER_ROWS;    // SparseMatrixMinusCluster.c:104-107
+    if (beta && K != 1) return SPKM_ERR_BETA_K;      // :119-120
+    if (n == 0 || K == 0) return SPKM_OK;
+    spkm_shard* s = nullptr;
+    int rc = spkm_shard_create_host(ctx, p, n, jc, ir, x, &s);
+    if (rc) return rc;
+    tmpdev dC, dCt, dD;
+    hipError_t e = hipMalloc(&dC.p, p * K * 8);
+    if (e == hipSuccess) e = hipMalloc(&dCt.p, p * K * 8);
+    if (e == hipSuccess) e = hipMalloc(&dD.p, n * K * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(dC.p, C, p * K * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { spkm_shard_destroy(s); return (int)e; }
+    const int blocks = std::max(1, ctx->num_cus) * 8;
+    if (beta) {
+        if (s->ir_bits == 16)
+            hipLaunchKernelGGL((k_dist_beta<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
+                               (const double*)dC.p, *beta, (long long)n, (double*)dD.p);
+        else
+            hipLaunchKernelGGL((k_dist_beta<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
+                               (const double*)dC.p, *beta, (long long)n, (double*)dD.p);
+    } else {
+        hipLaunchKernelGGL(k_transpose_centers, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)dC.p, (int)p,
+                           (int)K, (double*)dCt.p);
+        if (s->ir_bits == 16)
+            hipLaunchKernelGGL((k_dist_full<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
+                               (const double*)dCt.p, (int)K, (long long)n, (double*)dD.p);
+        else
+            hipLaunchKernelGGL((k_dist_full<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
+                               (const double*)dCt.p, (int)K, (long long)n, (double*)dD.p);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(dist, dD.p, n * K * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    spkm_shard_destroy(s);
+    return (int)e;
+}
+
+extern "C" int spkm_SparseMatrixInnerProduct_host(spkm_ctx* ctx, uint64_t p, uint64_t n, const uint64_t* jc,
+                                                  const uint64_t* ir, const double* x, const double* c, double* ip,
+                                                  double* nx2)
+{
+    if (!ctx || !jc || !c || (n && !ip)) return SPKM_ERR_NULL_ARG;
+    if (n == 0) return SPKM_OK;
+    spkm_shard* s = nullptr;
+    int rc = spkm_shard_create_host(ctx, p, n, jc, ir, x, &s);
+    if (rc) return rc;
+    tmpdev dc, dip, dn;
+    hipError_t e = hipMalloc(&dc.p, p * 8);
+    if (e == hipSuccess) e = hipMalloc(&dip.p, n * 8);
+    if (e == hipSuccess) e = hipMalloc(&dn.p, n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(dc.p, c, p * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { spkm_shard_destroy(s); return (int)e; }
+    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, (uint64_t)std::max(1, ctx->num_cus) * 16);
+    if (s->ir_bits == 16)
+        hipLaunchKernelGGL((k_innerprod<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
+                           (const double*)dc.p, (long long)n, (double*)dip.p, (double*)dn.p);
+    else
+        hipLaunchKernelGGL((k_innerprod<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
+                           (const double*)dc.p, (long long)n, (double*)dip.p, (double*)dn.p);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ip, dip.p, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && nx2) e = hipMemcpyAsync(nx2, dn.p, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    spkm_shard_destroy(s);
+    return (int)e;
+}
+
+extern "C" int spkm_SparseMatrixColumnNormSq_host(spkm_ctx* ctx, uint64_t n, const uint64_t* jc, const double* x,
+                                                  double* nx2)
+{
+    if (!ctx || !jc || (n && !nx2)) return SPKM_ERR_NULL_ARG;
+    if (n == 0) return SPKM_OK;
+    for (uint64_t i = 0; i < n; i++) if (jc[i + 1] < jc[i]) return SPKM_ERR_BAD_CSC;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t nnz = jc[n];
+    if (nnz && !x) return SPKM_ERR_NULL_ARG;
+    tmpdev djc, dx, dn;
+    HIP_TRY(hipMalloc(&djc.p, (n + 1) * 8));
+    HIP_TRY(hipMalloc(&dx.p, std::max<uint64_t>(nnz, 1) * 8));
+    HIP_TRY(hipMalloc(&dn.p, n * 8));
+    HIP_TRY(hipMemcpyAsync(djc.p, jc, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)); // u64 == i64 bits here
+    if (nnz) HIP_TRY(hipMemcpyAsync(dx.p, x, nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, (uint64_t)std::max(1, ctx->num_cus) * 16);
+    hipLaunchKernelGGL(k_colnormsq, dim3(blocks), dim3(256), 0, ctx->stream, (const long long*)djc.p,
+                       (const double*)dx.p, (long long)n, (double*)dn.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(nx2, dn.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SPKM_OK;
+}

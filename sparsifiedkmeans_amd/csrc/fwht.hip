@@ -1,0 +1,151 @@
+// Fast Walsh-Hadamard transform of the columns of a dense m x n f64 matrix (gfx950).
+//
+// Replaces hadamard_apply_vector / hadamard_apply_matrix(_threads)
+// (private/hadamard.c:57-92, private/hadamard_pthreads.c:69-107,121-204): unnormalised,
+// Sylvester ("hadamard") ordering, stages applied in the reference's order bit = 1, 2, 4, ..., m/2.
+// Every stage is the same set of disjoint (y[j], y[j|bit]) <- (y[j]+y[j|bit], y[j]-y[j|bit])
+// updates as the reference, so the result is bit-identical (add/sub only, no reassociation).
+//
+// Optional fusions for the preconditioner  mix(X) = hadamard(D*[X*(1+2eps); 0]) / sqrt(p2)
+// (kmeans_sparsified.m:241-248,286-295): rows >= p_in read as zero, sign vector d, premultiplier,
+// post-divide.  HBM-bound: 16 B moved per element, m*log2(m) add/sub per column.
+//
+// Kernel shape: T = m/16 threads own one column; stages are taken 4 at a time in registers
+// (16 elements per thread), with an LDS exchange between rounds.  LDS index padding
+// P(e) = e + 2*(e>>4) keeps the 16-B-aligned per-thread runs conflict-free.
+#include "common.h"
+
+__device__ __forceinline__ int padidx(int e) { return e + ((e >> 4) << 1); }
+
+__global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x, double* __restrict__ y, int m,
+                                                   int logm, long long n, int p_in,
+                                                   const double* __restrict__ dsign, double premul,
+                                                   double postdiv, int cols_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int T = m >> 4;                    // threads per column
+    const int csub = threadIdx.x / T;        // which column of this block
+    const int tau = threadIdx.x % T;
+    const int colstride = m + (m >> 3);      // padded doubles per column
+    double* col = lds + (size_t)csub * colstride;
+    const int nthreads = blockDim.x;
+
+    for (long long cbase = (long long)blockIdx.x * cols_per_block; cbase < n;
+         cbase += (long long)gridDim.x * cols_per_block) {
+        // ---- coalesced load of cols_per_block columns into LDS (with the fused input ops) ----
+        const long long ncols = (n - cbase < cols_per_block) ? (n - cbase) : cols_per_block;
+        const int total = (int)ncols * m;
+        for (int t = threadIdx.x; t < total; t += nthreads) {
+            const int c = t / m, r = t - c * m;
+            double v = 0.0;
+            if (r < p_in) {
+                v = x[(size_t)(cbase + c) * p_in + r];
+                if (premul != 1.0) v = v * premul;
+            }
+            if (dsign) v = dsign[r] * v;
+            lds[(size_t)c * colstride + padidx(r)] = v;
+        }
+        __syncthreads();
+
+        if (cbase + csub < n) {
+            for (int b = 0; b < logm; b += 4) {
+                const int nb = (logm - b < 4) ? (logm - b) : 4;
+                double a[16];
+                int e[16];
+                if (nb == 4) {
+                    const int L = tau & ((1 << b) - 1), H = tau >> b;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) e[q] = (H << (b + 4)) | (q << b) | L;
+                } else {
+                    const int xb = 4 - nb;
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        e[q] = ((q & ((1 << nb) - 1)) << b) | ((q >> nb) << (b - xb)) | tau;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) a[q] = col[padidx(e[q])];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if (s < nb) {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            if ((q & (1 << s)) == 0) {
+                                const double u = a[q], w = a[q | (1 << s)];
+                                a[q] = u + w;
+                                a[q | (1 << s)] = u - w;
+                            }
+                        }
+                    }
+                }
+                if (b + nb >= logm && postdiv > 0.0) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) a[q] = a[q] / postdiv;
+                }
+                // rounds touch disjoint element sets per thread within a round, but the next
+                // round reads other threads' elements: block-wide barrier on both sides.
+#pragma unroll
+                for (int q = 0; q < 16; q++) col[padidx(e[q])] = a[q];
+                __syncthreads();
+            }
+        } else {
+            for (int b = 0; b < logm; b += 4) __syncthreads();
+        }
+
+        // ---- coalesced store ----
+        for (int t = threadIdx.x; t < total; t += nthreads) {
+            const int c = t / m, r = t - c * m;
+            y[(size_t)(cbase + c) * m + r] = lds[(size_t)c * colstride + padidx(r)];
+        }
+        __syncthreads();
+    }
+}
+
+// m in {2,4,8}: one thread per column, registers only.
+__global__ void k_fwht_small(const double* __restrict__ x, double* __restrict__ y, int m, long long n, int p_in,
+                             const double* __restrict__ dsign, double premul, double postdiv)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    double a[8];
+    for (int r = 0; r < m; r++) {
+        double v = 0.0;
+        if (r < p_in) { v = x[(size_t)c * p_in + r]; if (premul != 1.0) v = v * premul; }
+        if (dsign) v = dsign[r] * v;
+        a[r] = v;
+    }
+    for (int bit = 1; bit < m; bit <<= 1)
+        for (int j = 0; j < m; j++)
+            if ((j & bit) == 0) { const double u = a[j], w = a[j | bit]; a[j] = u + w; a[j | bit] = u - w; }
+    for (int r = 0; r < m; r++) y[(size_t)c * m + r] = (postdiv > 0.0) ? a[r] / postdiv : a[r];
+}
+
+// m > 16384: stage-by-stage in global memory (one launch per stage; rare).
+__global__ void k_fwht_load(const double* __restrict__ x, double* __restrict__ y, long long m, long long n,
+                            long long p_in, const double* __restrict__ dsign, double premul)
+{
+    const long long total = m * n;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long c = t / m, r = t - c * m;
+        double v = 0.0;
+        if (r < p_in) { v = x[c * p_in + r]; if (premul != 1.0) v = v * premul; }
+        if (dsign) v = dsign[r] * v;
+        y[t] = v;
+    }
+}
+__global__ void k_fwht_stage(double* __restrict__ y, long long m, long long n, long long bit, double postdiv)
+{
+    const long long half = (m >> 1) * n;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < half;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long c = t / (m >> 1), h = t - c * (m >> 1);
+        const long long j = ((h & ~(bit - 1)) << 1) | (h & (bit - 1));
+        double* col = y + c * m;
+        const double u = col[j], w = col[j | bit];
+        double s = u + w, d = u - w;
+        if (postdiv > 0.0) { s = s / postdiv; d = d / postdiv; }
+        col[j] = s;
+        col[j | bit] = d;
+    }
+}

@@ -1,0 +1,289 @@
+// Lloyd-iteration support kernels around the tiled assignment kernel (gfx950).
+//
+//   k_prep_tiles        centers/gamma (findClusterAssignments.m:78), negated + transposed into LDS tiles
+//   k_combine           [d,a]=min(...) across tiles (findClusterAssignments.m:169) + per-shard statistics
+//   k_reduce_stats      fixed-order reduction of the per-block statistics
+//   k_accumulate_*      per-cluster sums / counts            (kmeans_sparsified.m:430-431,447-448)
+//   k_finalize_centers  gamma*S./(Cnt+1e-16), dff            (kmeans_sparsified.m:448,470)
+#include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+// negCt[g][r][kk] = -(C[(g*KT+kk)*p + r] / gamma)   r < p, g*KT+kk < K;  0 elsewhere (row p is the zero row).
+// gamma <= 0 means "no scaling" (findClusterAssignments.m:80).  The divide is a true IEEE divide.
+__global__ void k_prep_tiles(const double* __restrict__ C, int p, int K, int KT, int G, double gamma,
+                             double* __restrict__ negCt)
+{
+    const size_t total = (size_t)G * (p + 1) * KT;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(t % KT);
+        const size_t rest = t / KT;
+        const int r = (int)(rest % (p + 1));
+        const int g = (int)(rest / (p + 1));
+        const int k = g * KT + kk;
+        double v = 0.0;
+        if (r < p && k < K) {
+            v = C[(size_t)k * p + r];
+            if (gamma > 0.0) v = v / gamma;
+            v = -v;
+        }
+        negCt[t] = v;
+    }
+}
+
+// Per point: winner over the G tile partials under the reference's order
+// "smallest sqrt(acc), first index on ties".  Tiles are ordered by k, so a strict
+// '<' keeps the lowest k.  Writes assign (0-based) and mind = sqrt(acc_win), and
+// per-block partial statistics (deterministic for a fixed launch geometry):
+//   blk_obj2[b] = sum mind^2,  blk_max[b], blk_imax[b] = max mind and its first index,
+// plus the cluster histogram nk[K] (integer atomics: order-independent, exact).
+__global__ __launch_bounds__(256) void k_combine(const double* __restrict__ part_acc,
+                                                 const int* __restrict__ part_k, long long n, int G, int K,
+                                                 int* __restrict__ assign, double* __restrict__ mind,
+                                                 double* __restrict__ blk_obj2, double* __restrict__ blk_max,
+                                                 long long* __restrict__ blk_imax,
+                                                 unsigned long long* __restrict__ nk)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem); // K entries
+    __shared__ double s_obj[4], s_max[4];
+    __shared__ long long s_imax[4];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < K; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+
+    double obj2 = 0.0, dmax = -1.0;
+    long long imax = 0x7fffffffffffffffLL;
+    // contiguous slab per block so that per-block partials are independent of gridDim ordering games
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = (lo + per < n) ? lo + per : n;
+    for (long long i = lo + tid; i < hi; i += blockDim.x) {
+        double best = sqrt(part_acc[i]);
+        int bk = part_k[i];
+        for (int g = 1; g < G; g++) {
+            const double d = sqrt(part_acc[(size_t)g * n + i]);
+            if (d < best) { best = d; bk = part_k[(size_t)g * n + i]; }
+        }
+        assign[i] = bk;
+        mind[i] = best;
+        obj2 += best * best;
+        if (best > dmax) { dmax = best; imax = i; } // i ascending per thread: first index kept
+        atomicAdd(&hist[bk], 1u);
+    }
+    // wave reduce (sum is order-fixed by the shuffle tree)
+    for (int off = 32; off > 0; off >>= 1) {
+        obj2 += __shfl_down(obj2, off);
+        const double om = __shfl_down(dmax, off);
+        const long long oi = __shfl_down(imax, off);
+        if (om > dmax || (om == dmax && oi < imax)) { dmax = om; imax = oi; }
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, m = -1.0;
+        long long im = 0x7fffffffffffffffLL;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+            o += s_obj[w];
+            if (s_max[w] > m || (s_max[w] == m && s_imax[w] < im)) { m = s_max[w]; im = s_imax[w]; }
+        }
+        blk_obj2[blockIdx.x] = o;
+        blk_max[blockIdx.x] = m;
+        blk_imax[blockIdx.x] = im;
+    }
+    for (int k = tid; k < K; k += blockDim.x)
+        if (hist[k]) atomicAdd(&nk[k], (unsigned long long)hist[k]);
+}
+
+// stats[0] = sum_b blk_obj2[b] (fixed order), stats[1] = max mind, stats[2] = its first index (as double).
+__global__ void k_reduce_stats(const double* __restrict__ blk_obj2, const double* __restrict__ blk_max,
+                               const long long* __restrict__ blk_imax, int nblk, double* __restrict__ stats)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double o = 0.0, m = -1.0;
+    long long im = 0x7fffffffffffffffLL;
+    for (int b = 0; b < nblk; b++) {
+        o += blk_obj2[b];
+        if (blk_max[b] > m || (blk_max[b] == m && blk_imax[b] < im)) { m = blk_max[b]; im = blk_imax[b]; }
+    }
+    stats[0] = o;
+    stats[1] = m;
+    stats[2] = (double)im;
+}
+
+// Fallback accumulation straight into the global p x K tables with f64 hardware atomics
+// (used when the per-cluster LDS slab of the sorted path does not fit).  One wave per point.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_accumulate_atomic(const long long* __restrict__ jc,
+                                                           const IR* __restrict__ ir,
+                                                           const double* __restrict__ x,
+                                                           const int* __restrict__ assign, int p, long long n,
+                                                           double* __restrict__ sums, double* __restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long i = wave; i < n; i += nwaves) {
+        const int k = assign[i];
+        const long long j0 = jc[i], j1 = jc[i + 1];
+        for (long long j = j0 + lane; j < j1; j += 64) {
+            const size_t at = (size_t)k * p + (size_t)ir[j];
+            unsafeAtomicAdd(&sums[at], x[j]);
+            unsafeAtomicAdd(&counts[at], 1.0);
+        }
+    }
+}
+
+// ---------------- sorted accumulation: counting sort by cluster + LDS slabs ----------------
+// offs[k] = exclusive prefix of nk; cursor[k] = offs[k]; builds the work-item list: one item per
+// (cluster, segment of <= seg points).  items[t] = {k, start, len}.  Single small block.
+__global__ void k_plan_segments(const unsigned long long* __restrict__ nk, int K, int seg,
+                                long long* __restrict__ offs, unsigned long long* __restrict__ cursor,
+                                int4* __restrict__ items, int* __restrict__ nitems)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long run = 0;
+    int t = 0;
+    for (int k = 0; k < K; k++) {
+        offs[k] = run;
+        cursor[k] = (unsigned long long)run;
+        const long long cnt = (long long)nk[k];
+        for (long long s = 0; s < cnt; s += seg) {
+            const long long len = (cnt - s < seg) ? cnt - s : seg;
+            // start is relative to the cluster (fits 32 bits with 2^31 points per shard)
+            items[t++] = make_int4(k, (int)s, (int)len, 0);
+        }
+        run += cnt;
+    }
+    offs[K] = run;
+    *nitems = t;
+}
+
+// perm[cursor[assign[i]]++] = i, with one global atomic per (block, cluster) via an LDS histogram.
+__global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restrict__ assign, long long n, int K,
+                                                            unsigned long long* __restrict__ cursor,
+                                                            int* __restrict__ perm)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(smem);             // K
+    unsigned long long* base = reinterpret_cast<unsigned long long*>(cnt + ((K + 1) & ~1)); // K
+    const int tid = threadIdx.x;
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = (lo + per < n) ? lo + per : n;
+    for (int k = tid; k < K; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    for (long long i = lo + tid; i < hi; i += blockDim.x) atomicAdd(&cnt[assign[i]], 1u);
+    __syncthreads();
+    for (int k = tid; k < K; k += blockDim.x) {
+        base[k] = cnt[k] ? atomicAdd(&cursor[k], (unsigned long long)cnt[k]) : 0ull;
+        cnt[k] = 0;
+    }
+    __syncthreads();
+    for (long long i = lo + tid; i < hi; i += blockDim.x) {
+        const int k = assign[i];
+        const unsigned int r = atomicAdd(&cnt[k], 1u);
+        perm[base[k] + r] = (int)i;
+    }
+}
+
+// One workgroup per item: accumulate the item's points into an LDS slab
+// (sums f64[p] + counts u32[p]) with LDS atomics, then add the slab's touched rows into the
+// global p x K tables with one hardware f64 atomic per touched row.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_accumulate_sorted(const long long* __restrict__ jc,
+                                                           const IR* __restrict__ ir,
+                                                           const double* __restrict__ x,
+                                                           const int* __restrict__ perm,
+                                                           const long long* __restrict__ offs,
+                                                           const int4* __restrict__ items,
+                                                           const int* __restrict__ nitems, int p,
+                                                           double* __restrict__ sums, double* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ssum = reinterpret_cast<double*>(smem);
+    unsigned int* scnt = reinterpret_cast<unsigned int*>(ssum + p);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    for (int item = blockIdx.x; item < *nitems; item += gridDim.x) {
+        const int4 it = items[item];
+        const int k = it.x;
+        const long long start = offs[k] + it.y;
+        const int len = it.z;
+        for (int r = tid; r < p; r += blockDim.x) { ssum[r] = 0.0; scnt[r] = 0u; }
+        __syncthreads();
+        for (int q = wave; q < len; q += nwaves) {
+            const long long i = perm[start + q];
+            const long long j0 = jc[i], j1 = jc[i + 1];
+            for (long long j = j0 + lane; j < j1; j += 64) {
+                const int r = (int)ir[j];
+                unsafeAtomicAdd(&ssum[r], x[j]);
+                atomicAdd(&scnt[r], 1u);
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < p; r += blockDim.x) {
+            const unsigned int c = scnt[r];
+            if (c) {
+                unsafeAtomicAdd(&sums[(size_t)k * p + r], ssum[r]);
+                unsafeAtomicAdd(&counts[(size_t)k * p + r], (double)c);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// centers(:,k) = (gamma*S(:,k)) ./ (Cnt(:,k) + 1e-16) for non-empty clusters (kmeans_sparsified.m:448);
+// empty clusters keep their old column (the host applies EmptyAction, :432-445).
+// blk_dff2[b] = partial sum of (old - new)^2, reduced in fixed order by k_reduce_dff.
+__global__ __launch_bounds__(256) void k_finalize_centers(const double* __restrict__ sums,
+                                                          const double* __restrict__ counts,
+                                                          const double* __restrict__ nk_f64, int p, int K,
+                                                          double gamma, double* __restrict__ centers,
+                                                          double* __restrict__ blk_dff2)
+{
+    __shared__ double s_part[4];
+    const size_t total = (size_t)p * K;
+    double acc = 0.0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(t / p);
+        const double oldv = centers[t];
+        double newv = oldv;
+        if (nk_f64[k] > 0.0) newv = (gamma * sums[t]) / (counts[t] + 1e-16);
+        centers[t] = newv;
+        const double d = oldv - newv;
+        acc += d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double o = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) o += s_part[w];
+        blk_dff2[blockIdx.x] = o;
+    }
+}
+
+__global__ void k_reduce_dff(const double* __restrict__ blk_dff2, int nblk, double* __restrict__ out_dff2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double o = 0.0;
+    for (int b = 0; b < nblk; b++) o += blk_dff2[b];
+    *out_dff2 = o;
+}
+
+// nk (u64 counters) -> f64 slots of the reduce buffer, so that one SUM all-reduce covers everything.
+__global__ void k_nk_to_f64(const unsigned long long* __restrict__ nk, int K, double* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = (double)nk[k];
+}
+
+template __global__ void k_accumulate_atomic<unsigned short>(const long long*, const unsigned short*, const double*,
+    const int*, int, long long, double*, double*);
+template __global__ void k_accumulate_atomic<unsigned int>(const long long*, const unsigned int*, const double*,
+    const int*, int, long long, double*, double*);
+template __global__ void k_accumulate_sorted<unsigned short>(const long long*, const unsigned short*, const double*,
+    const int*, const long long*, const int4*, const int*, int, double*, double*);
+template __global__ void k_accumulate_sorted<unsigned int>(const long long*, const unsigned int*, const double*,
+    const int*, const long long*, const int4*, const int*, int, double*, double*);

@@ -1,0 +1,160 @@
+"""Device-resident Lloyd engine: thin Python plumbing over Part 2 of include/spkm.h.
+
+PyTorch is used for what it is good at here -- device allocations, the current HIP stream and
+``torch.distributed`` (RCCL) -- and nothing else: every kernel is ours (libspkm.so).
+
+One iteration (kmeans_sparsified.m:417-486 with dense centres):
+    assign      findClusterAssignments(X, centers, [], gamma)         :420
+    accumulate  per-cluster sums / counts of the local shard           :430-431,447-448
+    all-reduce  ONE RCCL SUM over [sums | counts | nk | obj2]          (new: data-parallel over points)
+    finalize    centers = gamma*S./(Cnt+1e-16); dff; obj               :448,470-471
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import Context
+
+
+def _p(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+class Shard:
+    """A block of points (columns of a p x n CSC matrix) resident in HBM."""
+
+    def __init__(self, ctx: Context, handle, keep=()):
+        self.ctx = ctx
+        self.handle = handle
+        self._keep = keep  # tensors backing an adopted shard
+        p, n, nnz, bits = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        _lib.check(_lib.lib().spkm_shard_info(handle, C.byref(p), C.byref(n), C.byref(nnz), C.byref(bits)))
+        self.p, self.n, self.nnz, self.ir_bits = p.value, n.value, nnz.value, bits.value
+
+    @classmethod
+    def from_scipy(cls, ctx: Context, X) -> "Shard":
+        from .ops import _csc_parts, _ptr
+
+        p, n, jc, ir, x = _csc_parts(X)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().spkm_shard_create_host(ctx.handle, p, n, _ptr(jc), _ptr(ir), _ptr(x), C.byref(h)),
+                   "spkm_shard_create_host")
+        return cls(ctx, h)
+
+    @classmethod
+    def from_device(cls, ctx: Context, p: int, jc: torch.Tensor, ir: torch.Tensor, x: torch.Tensor) -> "Shard":
+        """Adopt device tensors: jc int64[n+1], ir int16/uint16 or int32[nnz], x float64[nnz]."""
+        assert jc.dtype == torch.int64 and x.dtype == torch.float64 and jc.is_cuda and x.is_cuda and ir.is_cuda
+        bits = ir.element_size() * 8
+        n = jc.numel() - 1
+        nnz = x.numel()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().spkm_shard_create_dev(ctx.handle, p, n, nnz, _p(jc), _p(ir), bits, _p(x), C.byref(h)),
+                   "spkm_shard_create_dev")
+        return cls(ctx, h, keep=(jc, ir, x))
+
+    def close(self):
+        if self.handle:
+            _lib.lib().spkm_shard_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def torch_context(device: int | None = None) -> Context:
+    """A Context bound to torch's current HIP stream on ``device``."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("sparsifiedkmeans_amd: no HIP device visible to PyTorch; there is no CPU fallback")
+    device = torch.cuda.current_device() if device is None else device
+    torch.cuda.set_device(device)
+    return Context(device, torch.cuda.current_stream(device).cuda_stream)
+
+
+class LloydEngine:
+    """State of one Lloyd run over one local shard (one process per GPU).
+
+    centers: torch float64 [K, p] (row k = centre k, i.e. MATLAB's p x K in column-major bytes).
+    ``group`` is a torch.distributed process group (or None = use the default group when
+    torch.distributed is initialised, single-GPU otherwise).
+    """
+
+    def __init__(self, shard: Shard, K: int, gamma: float, unbiased: bool = True, group=None):
+        self.shard, self.ctx, self.K, self.p = shard, shard.ctx, int(K), int(shard.p)
+        self.gamma = float(gamma)
+        self.unbiased = bool(unbiased)
+        dev = torch.device("cuda", self.ctx.device)
+        n = shard.n
+        self.assign = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+        self.mind = torch.empty(max(n, 1), dtype=torch.float64, device=dev)[:n]
+        self.stats = torch.zeros(3, dtype=torch.float64, device=dev)
+        self.nk = torch.zeros(self.K, dtype=torch.int64, device=dev)
+        self.reduce = torch.zeros(int(_lib.lib().spkm_reduce_len(self.p, self.K)), dtype=torch.float64, device=dev)
+        self.out = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.group = group
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    # -- steps ---------------------------------------------------------------------------
+    def assign_step(self, centers: torch.Tensor):
+        assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)
+        g = self.gamma if self.unbiased else 0.0
+        _lib.check(_lib.lib().spkm_assign_dev(self.ctx.handle, self.shard.handle, self.K, _p(centers), g,
+                                              _p(self.assign), _p(self.mind), _p(self.stats), _p(self.nk)),
+                   "spkm_assign_dev")
+
+    def accumulate_step(self):
+        _lib.check(_lib.lib().spkm_accumulate_dev(self.ctx.handle, self.shard.handle, self.K, _p(self.assign),
+                                                  _p(self.reduce)), "spkm_accumulate_dev")
+
+    def allreduce_step(self):
+        if self.distributed:
+            torch.distributed.all_reduce(self.reduce, op=torch.distributed.ReduceOp.SUM, group=self.group)
+
+    def finalize_step(self, centers: torch.Tensor):
+        _lib.check(_lib.lib().spkm_finalize_dev(self.ctx.handle, self.p, self.K, _p(self.reduce), self.gamma,
+                                                _p(centers), _p(self.out)), "spkm_finalize_dev")
+
+    def iterate(self, centers: torch.Tensor):
+        """One full Lloyd iteration in place on ``centers``; returns the device tensor
+        [dff^2, obj^2] (no host sync)."""
+        self.assign_step(centers)
+        self.accumulate_step()
+        self.allreduce_step()
+        self.finalize_step(centers)
+        return self.out
+
+    # -- helpers -------------------------------------------------------------------------
+    def global_nk(self) -> torch.Tensor:
+        pk = self.p * self.K
+        return self.reduce[2 * pk: 2 * pk + self.K]
+
+    def last_assign_kernel_ms(self) -> float:
+        ms = C.c_double()
+        _lib.check(_lib.lib().spkm_last_assign_kernel_ms(self.ctx.handle, C.byref(ms)))
+        return ms.value
+
+
+def fwht_device(ctx: Context, x: torch.Tensor) -> torch.Tensor:
+    """hadamard() on a device tensor laid out [n, m] (each row = one column of the m x n matrix)."""
+    assert x.dtype == torch.float64 and x.is_contiguous() and x.dim() == 2
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().spkm_fwht_dev(ctx.handle, x.shape[1], x.shape[0], _p(x), _p(y)), "spkm_fwht_dev")
+    return y
+
+
+def mix_device(ctx: Context, x: torch.Tensor, p2: int, sign: torch.Tensor | None, premul: float,
+               postdiv: float) -> torch.Tensor:
+    """mix(X) (kmeans_sparsified.m:295) on a device tensor [n, p] -> [n, p2]."""
+    assert x.dtype == torch.float64 and x.is_contiguous() and x.dim() == 2
+    n, p = x.shape
+    y = torch.empty((n, p2), dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib().spkm_mix_dev(ctx.handle, p, p2, n, _p(x), _p(sign) if sign is not None else None,
+                                       float(premul), float(postdiv), _p(y)), "spkm_mix_dev")
+    return y

@@ -1,0 +1,129 @@
+"""Synthetic Gaussian-mixture workloads in the reference's own input format.
+
+Follows example_sparseKMeans.m:12-22 (centres ~ N(0,I_p), contiguous equal cluster blocks,
+noise 0.1*N(0,I_p)) and then the reference's preprocessing pipeline
+(kmeans_sparsified.m:286-334): X*(1+2eps) -> sign flip -> zero-pad to p2 -> FWHT/sqrt(p2)
+-> keep s = max(1, round(gamma*p2)) uniformly random rows per column, ascending, scaled by
+p2/s (private/randsample_fixedNumberEntries.m:30-31,62).
+
+The RNG is numpy's / torch's, not MATLAB's: RNG-dependent products (sign vector, sampled
+rows, initial centres) are *inputs* to the parity tests, never compared with MATLAB's.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+EPS = np.finfo(np.float64).eps
+
+
+def small_p_of(gamma: float, p2: int) -> int:
+    """kmeans_sparsified.m:324-326: small_p = max(1, round(SparsityLevel*p2)) (MATLAB round: half away from 0)."""
+    return max(1, int(np.floor(gamma * p2 + 0.5)))
+
+
+def gmm_dense(p: int, n: int, K: int, seed: int = 234, noise: float = 0.1):
+    """Dense p x n mixture as in example_sparseKMeans.m:17-22; returns (X, true_centres, labels)."""
+    rng = np.random.default_rng(seed)
+    centres = rng.standard_normal((p, K))
+    labels = (np.arange(n) * K) // n
+    X = centres[:, labels] + noise * rng.standard_normal((p, n))
+    return X, centres, labels
+
+
+def sample_rows(rng: np.random.Generator, p2: int, s: int, n: int) -> np.ndarray:
+    """s distinct uniformly random rows per column, ascending: [n, s] int array
+    (private/randsample_block.m:44-92 -- any exact without-replacement sampler is equivalent)."""
+    keys = rng.random((n, p2))
+    idx = np.argpartition(keys, s - 1, axis=1)[:, :s]
+    idx.sort(axis=1)
+    return idx
+
+
+def sparsify_dense(Xmixed: np.ndarray, s: int, rng: np.random.Generator) -> sp.csc_matrix:
+    """randsample_fixedNumberEntries(X, s): p2 x n CSC with exactly s entries per column
+    (fewer where a sampled value is exactly 0: MATLAB's sparse() drops zeros, :62), values
+    X(ind)/(s/p2) -- a true division by SparsityLevel = s/p2 (:30-31,62)."""
+    p2, n = Xmixed.shape
+    rows = sample_rows(rng, p2, s, n)
+    level = np.float64(s) / np.float64(p2)
+    vals = Xmixed[rows, np.arange(n)[:, None]] / level
+    indptr = np.arange(0, (n + 1) * s, s, dtype=np.int64)
+    Y = sp.csc_matrix((vals.ravel(), rows.ravel().astype(np.int64), indptr), shape=(p2, n))
+    Y.eliminate_zeros()
+    Y.sort_indices()
+    return Y
+
+
+def sparsified_gmm_host(p: int, n: int, K: int, gamma: float, seed: int = 234, fwht=None):
+    """Small-case pipeline on the host (numpy): returns dict with the CSC matrix and everything
+    a Lloyd run needs.  ``fwht`` is the transform to use (callable m x n -> m x n); tests pass the
+    oracle's or the HIP one."""
+    X, centres, labels = gmm_dense(p, n, K, seed)
+    rng = np.random.default_rng(seed + 1)
+    p2 = 1 << int(np.ceil(np.log2(p))) if p > 1 else 2
+    d = np.sign(rng.standard_normal(p2))
+    d[d == 0] = 1.0
+    Xs = X * (1.0 + 2.0 * EPS)
+    Xp = np.zeros((p2, n))
+    Xp[:p] = Xs
+    Xp *= d[:, None]
+    Xm = fwht(Xp) / np.sqrt(np.float64(p2))
+    s = small_p_of(gamma, p2)
+    Y = sparsify_dense(Xm, s, rng)
+    gamma_used = s / p  # kmeans_sparsified.m:329 (divides by p, not p2)
+    return dict(Y=Y, X=X, Xmixed=Xm, d=d, p=p, p2=p2, s=s, gamma=gamma_used, labels=labels, centres=centres)
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side generator for bench-scale workloads (torch only for RNG / sort; the transform is ours)
+# ---------------------------------------------------------------------------------------------
+def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K: int, gamma: float,
+                          seed: int = 234, chunk: int = 65536, noise: float = 0.1):
+    """Generates points [first, first+n_local) of the n_total-point mixture directly into device
+    CSC arrays (jc int64, ir int16/int32, x float64), chunk by chunk, never holding more than
+    ``chunk`` dense columns.  Every rank generates the same global dataset: cluster means and the
+    sign vector come from ``seed``; chunk c uses generator seed ^ (c+1) regardless of which rank
+    owns it (chunks are aligned to global multiples of ``chunk``)."""
+    import torch
+
+    from .engine import mix_device
+
+    dev = torch.device("cuda", ctx.device)
+    p2 = 1 << int(np.ceil(np.log2(p))) if p > 1 else 2
+    s = small_p_of(gamma, p2)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(seed)
+    means = torch.randn((K, p), generator=g0, device=dev, dtype=torch.float64)
+    sign = torch.sign(torch.randn(p2, generator=g0, device=dev, dtype=torch.float64))
+    sign[sign == 0] = 1.0
+    ir_dtype = torch.int16 if p2 <= 32768 else torch.int32  # int16 holds row ids < 32768 (reinterpreted as u16)
+    x = torch.empty(n_local * s, dtype=torch.float64, device=dev)
+    ir = torch.empty(n_local * s, dtype=ir_dtype, device=dev)
+    level = float(np.float64(s) / np.float64(p2))
+    premul = float(1.0 + 2.0 * EPS)
+    postdiv = float(np.sqrt(np.float64(p2)))
+    last = first + n_local
+    c = first // chunk
+    while c * chunk < last:
+        lo, hi = max(first, c * chunk), min(last, (c + 1) * chunk)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed((seed * 1000003) ^ (c + 1))
+        # generate the whole aligned chunk so the stream is rank-independent, then slice
+        m = min((c + 1) * chunk, n_total) - c * chunk
+        ids = torch.arange(c * chunk, c * chunk + m, device=dev)
+        lab = (ids * K) // n_total
+        dense = means[lab] + noise * torch.randn((m, p), generator=gen, device=dev, dtype=torch.float32).double()
+        keys = torch.rand((m, p2), generator=gen, device=dev, dtype=torch.float32)
+        a, b = lo - c * chunk, hi - c * chunk
+        dense, keys = dense[a:b].contiguous(), keys[a:b]
+        mixed = mix_device(ctx, dense, p2, sign, premul, postdiv)          # [m', p2]
+        rows = torch.topk(keys, s, dim=1, largest=False, sorted=False).indices
+        rows, _ = torch.sort(rows, dim=1)
+        vals = torch.gather(mixed, 1, rows) / level
+        o = (lo - first) * s
+        x[o:o + (hi - lo) * s] = vals.reshape(-1)
+        ir[o:o + (hi - lo) * s] = rows.reshape(-1).to(ir_dtype)
+        c += 1
+    jc = torch.arange(0, (n_local + 1) * s, s, dtype=torch.int64, device=dev)
+    return dict(jc=jc, ir=ir, x=x, p2=p2, s=s, gamma=s / p, sign=sign, means=means)
