@@ -48,8 +48,12 @@ __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x,
         }
         __syncthreads();
 
-        if (cbase + csub < n) {
+        // barriers must be reached by every lane of every wave the same number of times: the
+        // rounds are predicated per column instead of branching around them
+        const bool active = cbase + csub < n;
+        {
             for (int b = 0; b < logm; b += 4) {
+              if (active) {
                 const int nb = (logm - b < 4) ? (logm - b) : 4;
                 double a[16];
                 int e[16];
@@ -86,10 +90,9 @@ __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x,
                 // round reads other threads' elements: block-wide barrier on both sides.
 #pragma unroll
                 for (int q = 0; q < 16; q++) col[padidx(e[q])] = a[q];
+              }
                 __syncthreads();
             }
-        } else {
-            for (int b = 0; b < logm; b += 4) __syncthreads();
         }
 
         // ---- coalesced store ----
