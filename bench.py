@@ -68,7 +68,7 @@ def main():
     data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
                                        chunk=args.gen_chunk)
     p2, s, gamma = data["p2"], data["s"], data["gamma"]
-    shard = Shard.from_device(ctx, p2, data["jc"], data["ir"], data["x"])
+    shard = Shard.from_device(ctx, p2, data["jc"], data["ir"], data["x"], nnz=data["nnz"])
     # initial centres: K mixture points in the ORIGINAL space passed through mix(), as the
     # 'Start'-matrix path does (kmeans_sparsified.m:401-406); identical on every rank
     g = torch.Generator(device="cuda")

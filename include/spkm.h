@@ -96,9 +96,13 @@ int spkm_hadamard_pthreads_host(spkm_ctx *ctx, uint64_t m, uint64_t n, const dou
 int spkm_shard_create_host(spkm_ctx *ctx, uint64_t p, uint64_t n, const uint64_t *jc, const uint64_t *ir,
                            const double *x, spkm_shard **out);
 /* Adopt device arrays without copying (caller keeps them alive): d_jc int64[n+1],
- * d_ir uint32[nnz] (ir_bits=32) or uint16[nnz] (ir_bits=16), d_x double[nnz]. */
+ * d_ir uint32 (ir_bits=32) or uint16 (ir_bits=16), d_x double; both hold nnz entries inside
+ * allocations of `capacity` >= nnz entries.  With capacity >= nnz + 16 and a fixed number of
+ * entries per column the fastest kernel variant is used (it reads, and ignores, up to 15
+ * entries past a column's end).  Rows must ascend within a column; not re-validated here. */
 int spkm_shard_create_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t nnz, const int64_t *d_jc,
-                          const void *d_ir, int ir_bits, const double *d_x, spkm_shard **out);
+                          const void *d_ir, int ir_bits, const double *d_x, uint64_t capacity,
+                          spkm_shard **out);
 void spkm_shard_destroy(spkm_shard *s);
 int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
 

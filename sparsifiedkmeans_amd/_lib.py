@@ -88,7 +88,7 @@ def lib():
     L.spkm_hadamard_host.argtypes = [_vp, _u64, _u64, _vp, _vp]
     L.spkm_hadamard_pthreads_host.argtypes = [_vp, _u64, _u64, _vp, _vp]
     L.spkm_shard_create_host.argtypes = [_vp, _u64, _u64, _vp, _vp, _vp, C.POINTER(_vp)]
-    L.spkm_shard_create_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
+    L.spkm_shard_create_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, C.c_int, _vp, _u64, C.POINTER(_vp)]
     L.spkm_shard_destroy.argtypes = [_vp]
     L.spkm_shard_destroy.restype = None
     L.spkm_shard_info.argtypes = [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(C.c_int)]

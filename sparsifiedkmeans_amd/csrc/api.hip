@@ -50,6 +50,8 @@ struct spkm_shard {
     void* ir = nullptr;
     double* x = nullptr;
     bool owned = false;
+    int fixed_s = 0;   // > 0: every column has exactly this many entries
+    uint64_t slack = 0; // entries readable past nnz in ir / x
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -189,6 +191,13 @@ extern "C" int spkm_shard_create_host(spkm_ctx* ctx, uint64_t p, uint64_t n, con
     spkm_shard* s = new spkm_shard();
     s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->owned = true;
     s->ir_bits = (p <= 65536) ? 16 : 32;
+    s->slack = 16;
+    if (n > 0 && nnz > 0 && nnz % n == 0) {
+        const uint64_t st = nnz / n;
+        bool fixed = st <= 0x7fffffffull;
+        for (uint64_t i = 0; fixed && i <= n; i++) fixed = (jc[i] == i * st);
+        if (fixed) s->fixed_s = (int)st;
+    }
     const size_t irb = (size_t)s->ir_bits / 8;
     // +16 entries of slack so that clamped batch loads never leave the allocation
     hipError_t e = hipMalloc((void**)&s->jc, (n + 1) * sizeof(long long));
@@ -218,17 +227,43 @@ extern "C" int spkm_shard_create_host(spkm_ctx* ctx, uint64_t p, uint64_t n, con
     return SPKM_OK;
 }
 
+// flag stays 1 iff jc[i] == i*st for every i in [0, n]
+__global__ void k_check_fixed(const long long* __restrict__ jc, long long n, long long st, int* __restrict__ flag)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x)
+        if (jc[i] != i * st) *flag = 0;
+}
+
 extern "C" int spkm_shard_create_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint64_t nnz, const int64_t* d_jc,
-                                     const void* d_ir, int ir_bits, const double* d_x, spkm_shard** out)
+                                     const void* d_ir, int ir_bits, const double* d_x, uint64_t capacity,
+                                     spkm_shard** out)
 {
     if (!ctx || !out || !d_jc || (nnz && (!d_ir || !d_x))) return SPKM_ERR_NULL_ARG;
     *out = nullptr;
     if (p == 0 || p > 0x7fffffffull || n > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
     if (ir_bits != 16 && ir_bits != 32) return SPKM_ERR_BAD_VALUE;
     if (ir_bits == 16 && p > 65536) return SPKM_ERR_BAD_VALUE;
+    if (capacity < nnz) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipSetDevice(ctx->device));
     spkm_shard* s = new spkm_shard();
     s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->ir_bits = ir_bits;
     s->jc = (long long*)d_jc; s->ir = (void*)d_ir; s->x = (double*)d_x; s->owned = false;
+    s->slack = capacity - nnz;
+    if (n > 0 && nnz > 0 && nnz % n == 0 && nnz / n <= 0x7fffffffull) {
+        int rc = ensure(ctx, ctx->nitems, 64);
+        if (rc) { delete s; return rc; }
+        int one = 1, flag = 0;
+        hipError_t e = hipMemcpyAsync(ctx->nitems.p, &one, 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_check_fixed, dim3((unsigned)std::min<uint64_t>((n + 256) / 256, 4096)), dim3(256), 0,
+                               ctx->stream, (const long long*)d_jc, (long long)n, (long long)(nnz / n),
+                               (int*)ctx->nitems.p);
+            e = hipMemcpyAsync(&flag, ctx->nitems.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { delete s; return (int)e; }
+        if (flag) s->fixed_s = (int)(nnz / n);
+    }
     *out = s;
     return SPKM_OK;
 }
@@ -335,20 +370,28 @@ static hipError_t timing_end(spkm_ctx* ctx)
     return hipEventRecord(ctx->ev1, ctx->stream);
 }
 
-template <int KT, typename IR>
-static int launch_tile(spkm_ctx* ctx, const spkm_shard* s, int K, int G, int chunk)
+template <int KT, typename IR, bool FIXED>
+static int launch_tile2(spkm_ctx* ctx, const spkm_shard* s, int K, int G, int chunk)
 {
     const size_t lds = (size_t)(s->p + 1) * KT * 8;
-    auto kern = k_assign_tile<KT, IR>;
+    auto kern = k_assign_tile<KT, IR, FIXED>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(timing_begin(ctx));
     hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const long long*)s->jc,
-                       (const IR*)s->ir, (const double*)s->x, (const double*)ctx->tiles.p, (int)s->p,
-                       (long long)s->n, (long long)s->nnz, K, (const spkm_blockmap*)ctx->bmap.p, chunk,
+                       (const IR*)s->ir, (const double*)s->x, (const double*)ctx->tiles.p, (int)s->p, (int)s->n,
+                       (long long)s->nnz, s->fixed_s, K, (const spkm_blockmap*)ctx->bmap.p, chunk,
                        (double*)ctx->part_acc.p, (int*)ctx->part_k.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(timing_end(ctx));
     return SPKM_OK;
+}
+
+template <int KT, typename IR>
+static int launch_tile(spkm_ctx* ctx, const spkm_shard* s, int K, int G, int chunk)
+{
+    // the fixed-stride kernel reads up to 15 entries past a column's end: needs slack after nnz
+    if (s->fixed_s > 0 && s->slack >= 16) return launch_tile2<KT, IR, true>(ctx, s, K, G, chunk);
+    return launch_tile2<KT, IR, false>(ctx, s, K, G, chunk);
 }
 
 static constexpr int COMBINE_BLOCKS = 1024;
@@ -391,7 +434,7 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
                            ctx->stream, d_centers, p, K, KT, G, gamma, (double*)ctx->tiles.p);
         // chunk: multiple of the points one workgroup covers per sweep; small enough that every
         // stream gets several chunks, large enough to amortise the loop overhead
-        const int ppw = 64 / KT, sweep = 16 * ppw;
+        const int ppw = 64 / KT, sweep = 16 * 2 * ppw;
         long long chunk = n / ((long long)ctx->bmap_streams * 8);
         chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
         chunk = (chunk / sweep) * sweep;

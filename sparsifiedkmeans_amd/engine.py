@@ -46,15 +46,18 @@ class Shard:
         return cls(ctx, h)
 
     @classmethod
-    def from_device(cls, ctx: Context, p: int, jc: torch.Tensor, ir: torch.Tensor, x: torch.Tensor) -> "Shard":
-        """Adopt device tensors: jc int64[n+1], ir int16/uint16 or int32[nnz], x float64[nnz]."""
+    def from_device(cls, ctx: Context, p: int, jc: torch.Tensor, ir: torch.Tensor, x: torch.Tensor,
+                    nnz: int | None = None) -> "Shard":
+        """Adopt device tensors: jc int64[n+1], ir int16/uint16 or int32, x float64.  ``nnz`` is the
+        number of stored entries; ir / x may be longer (>= nnz + 16 unlocks the fixed-stride kernel)."""
         assert jc.dtype == torch.int64 and x.dtype == torch.float64 and jc.is_cuda and x.is_cuda and ir.is_cuda
         bits = ir.element_size() * 8
         n = jc.numel() - 1
-        nnz = x.numel()
+        nnz = x.numel() if nnz is None else int(nnz)
+        cap = min(x.numel(), ir.numel())
         h = C.c_void_p()
-        _lib.check(_lib.lib().spkm_shard_create_dev(ctx.handle, p, n, nnz, _p(jc), _p(ir), bits, _p(x), C.byref(h)),
-                   "spkm_shard_create_dev")
+        _lib.check(_lib.lib().spkm_shard_create_dev(ctx.handle, p, n, nnz, _p(jc), _p(ir), bits, _p(x), cap,
+                                                    C.byref(h)), "spkm_shard_create_dev")
         return cls(ctx, h, keep=(jc, ir, x))
 
     def close(self):

@@ -98,8 +98,9 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
     sign = torch.sign(torch.randn(p2, generator=g0, device=dev, dtype=torch.float64))
     sign[sign == 0] = 1.0
     ir_dtype = torch.int16 if p2 <= 32768 else torch.int32  # int16 holds row ids < 32768 (reinterpreted as u16)
-    x = torch.empty(n_local * s, dtype=torch.float64, device=dev)
-    ir = torch.empty(n_local * s, dtype=ir_dtype, device=dev)
+    # 16 entries of slack: the fixed-stride kernel reads (and ignores) up to 15 entries past a column
+    x = torch.zeros(n_local * s + 16, dtype=torch.float64, device=dev)
+    ir = torch.zeros(n_local * s + 16, dtype=ir_dtype, device=dev)
     level = float(np.float64(s) / np.float64(p2))
     premul = float(1.0 + 2.0 * EPS)
     postdiv = float(np.sqrt(np.float64(p2)))
@@ -126,4 +127,4 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
         ir[o:o + (hi - lo) * s] = rows.reshape(-1).to(ir_dtype)
         c += 1
     jc = torch.arange(0, (n_local + 1) * s, s, dtype=torch.int64, device=dev)
-    return dict(jc=jc, ir=ir, x=x, p2=p2, s=s, gamma=s / p, sign=sign, means=means)
+    return dict(jc=jc, ir=ir, x=x, nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means)

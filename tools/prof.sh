@@ -1,0 +1,22 @@
+#!/bin/bash
+# Usage (on the GPU box): tools/prof.sh <tag> [bench args...]
+# 1) kernel trace + stats, 2) PMC passes (separate runs; counters never mixed with trace domains).
+# Raw rocprofv3 output stays in /tmp; only the small summaries land in gpurun_out/prof_<tag>/.
+tag=$1; shift
+export TMPDIR=/tmp
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/prof_$tag
+raw=/tmp/prof_raw_$tag
+rm -rf $raw; mkdir -p $out $raw
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/trace -o trace -- python $root/bench.py "$@" > $out/bench_trace.log 2>&1
+find $raw/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_RD" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $raw/pmc$i -o pmc -- python $root/bench.py "$@" > $out/bench_pmc$i.log 2>&1
+done
+python $root/tools/prof_summary.py $raw $out
+ls -la $out

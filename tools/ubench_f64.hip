@@ -1,0 +1,93 @@
+// Micro-benchmarks for the f64 VALU / LDS rates the assignment kernel depends on (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_f64.hip -o ubench_f64 ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP 64
+template <int MODE>
+__global__ __launch_bounds__(1024) void k(double* out, int iters, double seed)
+{
+    extern __shared__ double lds[];
+    for (int i = threadIdx.x; i < 16 * 1025; i += blockDim.x) lds[i] = seed * i;
+    __syncthreads();
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double one = seed;
+    int addr = (threadIdx.x & 15) * 8 + ((threadIdx.x >> 4) & 3) * 128 * 7;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; r++) {
+            if (MODE == 0) { // independent v_fma_f64
+                asm volatile("v_fma_f64 %0, %0, %8, %8\n v_fma_f64 %1, %1, %8, %8\n v_fma_f64 %2, %2, %8, %8\n v_fma_f64 %3, %3, %8, %8\n"
+                             "v_fma_f64 %4, %4, %8, %8\n v_fma_f64 %5, %5, %8, %8\n v_fma_f64 %6, %6, %8, %8\n v_fma_f64 %7, %7, %8, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
+            } else if (MODE == 1) { // v_mul_f64 / v_add_f64 alternating, independent
+                asm volatile("v_mul_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                             "v_mul_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_add_f64 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
+            } else if (MODE == 2) { // v_fmac_f64_dpp row_newbcast
+                asm volatile("v_fmac_f64_dpp %0, %8, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %8, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                             "v_fmac_f64_dpp %2, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %8, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                             "v_fmac_f64_dpp %4, %8, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %5, %8, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                             "v_fmac_f64_dpp %6, %8, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %7, %8, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
+            } else if (MODE == 3) { // dependent chain v_fmac_dpp -> v_mul -> v_add (one accumulator), the kernel's critical path
+                asm volatile("v_fmac_f64_dpp %0, %8, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mul_f64 %0, %0, %0\n v_add_f64 %1, %1, %0\n"
+                             "v_fmac_f64_dpp %2, %8, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mul_f64 %2, %2, %2\n v_add_f64 %1, %1, %2\n"
+                             "v_fmac_f64_dpp %3, %8, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mul_f64 %3, %3, %3"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
+            } else if (MODE == 4) { // ds_read_b64 x8, conflict-free-ish pattern (4 rows per wave)
+                double t0, t1, t2, t3, t4, t5, t6, t7;
+                asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:128\n ds_read_b64 %2, %8 offset:256\n ds_read_b64 %3, %8 offset:384\n"
+                             "ds_read_b64 %4, %8 offset:512\n ds_read_b64 %5, %8 offset:640\n ds_read_b64 %6, %8 offset:768\n ds_read_b64 %7, %8 offset:896\n s_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(addr));
+                a0 += t0; a1 += t1; a2 += t2; a3 += t3; a4 += t4; a5 += t5; a6 += t6; a7 += t7;
+            } else if (MODE == 5) { // v_add_u32_dpp x8
+                int b0, b1, b2, b3;
+                asm volatile("v_add_u32_dpp %0, %4, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %4, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                             "v_add_u32_dpp %2, %4, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %4, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                             "v_add_u32_dpp %0, %4, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %4, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                             "v_add_u32_dpp %2, %4, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %4, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf"
+                             : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(addr));
+                addr ^= (b0 ^ b1 ^ b2 ^ b3) & 0;
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+template <int MODE>
+void run(const char* name, int threads, int blocks_per_cu)
+{
+    int dev = 0; hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
+    const int cus = prop.multiProcessorCount;
+    const int blocks = cus * blocks_per_cu, iters = 2000;
+    double* out; hipMalloc(&out, (size_t)blocks * threads * 8);
+    hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1025 * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<blocks, threads, 16 * 1025 * 8>>>(out, 10, 1.0);
+    hipEventRecord(e0);
+    k<MODE><<<blocks, threads, 16 * 1025 * 8>>>(out, iters, 1.0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double waves_per_simd = (double)threads / 64 * blocks_per_cu / 4;
+    const double insts_per_wave = (double)iters * REP;
+    // wave-instructions issued per SIMD / time -> cycles per wave-instruction per SIMD at 2.4 GHz
+    const double cyc = ms * 1e-3 * 2.4e9 / (insts_per_wave * waves_per_simd);
+    printf("%-34s threads=%4d waves/SIMD=%.0f  %.3f ms  -> %.2f cycles per wave-instr per SIMD (@2.4GHz nominal)\n", name,
+           threads, waves_per_simd, ms, cyc);
+    hipFree(out);
+}
+
+int main()
+{
+    for (int t : {256, 1024}) {
+        run<0>("v_fma_f64 independent", t, 1);
+        run<1>("v_mul_f64/v_add_f64 independent", t, 1);
+        run<2>("v_fmac_f64_dpp independent", t, 1);
+        run<3>("fmac_dpp->mul->add dependent", t, 1);
+        run<4>("ds_read_b64 (8 in flight)", t, 1);
+        run<5>("v_add_u32_dpp", t, 1);
+    }
+    return 0;
+}
