@@ -50,6 +50,37 @@ __global__ __launch_bounds__(1024) void k(double* out, int iters, double seed)
                              "v_add_u32_dpp %2, %4, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %4, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf"
                              : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(addr));
                 addr ^= (b0 ^ b1 ^ b2 ^ b3) & 0;
+            } else if (MODE == 6) { // plain v_add_u32 x8
+                int b0, b1, b2, b3;
+                asm volatile("v_add_u32 %0, %4, %4\n v_add_u32 %1, %4, %4\n v_add_u32 %2, %4, %4\n v_add_u32 %3, %4, %4\n"
+                             "v_add_u32 %0, %4, %4\n v_add_u32 %1, %4, %4\n v_add_u32 %2, %4, %4\n v_add_u32 %3, %4, %4"
+                             : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(addr));
+                addr ^= (b0 ^ b1 ^ b2 ^ b3) & 0;
+            } else if (MODE == 7) { // the kernel's step mix: add_dpp + fmac_dpp + mul + add  (x2), independent regs
+                int b0, b1;
+                asm volatile("v_add_u32_dpp %8, %10, %10 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %0, %11, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mul_f64 %1, %1, %11\n v_add_f64 %2, %2, %11\n"
+                             "v_add_u32_dpp %9, %10, %10 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %11, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_mul_f64 %4, %4, %11\n v_add_f64 %5, %5, %11"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(b0), "=&v"(b1) : "v"(addr), "v"(one));
+                addr ^= (b0 ^ b1) & 0;
+            } else if (MODE == 8) { // step mix with plain add instead of DPP add
+                int b0, b1;
+                asm volatile("v_add_u32 %8, %10, %10\n v_fmac_f64_dpp %0, %11, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mul_f64 %1, %1, %11\n v_add_f64 %2, %2, %11\n"
+                             "v_add_u32 %9, %10, %10\n v_fmac_f64_dpp %3, %11, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_mul_f64 %4, %4, %11\n v_add_f64 %5, %5, %11"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(b0), "=&v"(b1) : "v"(addr), "v"(one));
+                addr ^= (b0 ^ b1) & 0;
+            } else if (MODE == 9) { // v_mov_b32_dpp x8
+                int b0, b1, b2, b3;
+                asm volatile("v_mov_b32_dpp %0, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %2, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %2, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                             : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(addr));
+                addr ^= (b0 ^ b1 ^ b2 ^ b3) & 0;
+            } else if (MODE == 10) { // v_fma_f32 x8 independent
+                float f = (float)seed;
+                asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n"
+                             "v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1"
+                             : "+v"(addr) : "v"(f));
             }
         }
     }
@@ -79,8 +110,25 @@ void run(const char* name, int threads, int blocks_per_cu)
     hipFree(out);
 }
 
+__global__ void k_clock(long long* out, int iters)
+{
+    long long t0 = __builtin_amdgcn_s_memtime();
+    long long w0 = wall_clock64();
+    double a = threadIdx.x;
+    for (int i = 0; i < iters; i++) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(a));
+    long long t1 = __builtin_amdgcn_s_memtime();
+    long long w1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = w1 - w0; out[2] = (long long)a; }
+}
+
 int main()
 {
+    {
+        long long* d; hipMalloc(&d, 64); long long h[3];
+        k_clock<<<1024, 1024>>>(d, 200000);
+        hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        printf("s_memtime ticks=%lld  wall_clock64 ticks (100MHz)=%lld -> s_memtime runs at %.1f MHz under f64 load\n", h[0], h[1], h[0] / (h[1] / 100.0));
+    }
     for (int t : {256, 1024}) {
         run<0>("v_fma_f64 independent", t, 1);
         run<1>("v_mul_f64/v_add_f64 independent", t, 1);
@@ -88,6 +136,11 @@ int main()
         run<3>("fmac_dpp->mul->add dependent", t, 1);
         run<4>("ds_read_b64 (8 in flight)", t, 1);
         run<5>("v_add_u32_dpp", t, 1);
+        run<6>("v_add_u32 plain", t, 1);
+        run<7>("step mix (dpp add)", t, 1);
+        run<8>("step mix (plain add)", t, 1);
+        run<9>("v_mov_b32_dpp", t, 1);
+        run<10>("v_fma_f32 dependent chain", t, 1);
     }
     return 0;
 }
