@@ -147,6 +147,9 @@ int spkm_last_assign_kernel_ms(spkm_ctx *ctx, double *ms);
  * spkm_assign_dev records one event pair without any host sync; spkm_timing_read blocks on the
  * stream and returns up to cap durations (ms) and the number recorded. */
 int spkm_timing_log(spkm_ctx *ctx, int enable);
+/* Developer aid: per-workgroup (start, end) wall-clock stamps (100 MHz) of the tiled assignment
+ * kernel.  enable=1 arms it; enable=0 copies up to cap pairs into out and reports the grid size. */
+int spkm_debug_block_times(spkm_ctx *ctx, int enable, int64_t *out, int cap, int *nblocks);
 int spkm_timing_read(spkm_ctx *ctx, double *ms, int cap, int *count);
 
 #ifdef __cplusplus

@@ -102,6 +102,7 @@ def lib():
     L.spkm_last_assign_kernel_ms.argtypes = [_vp, C.POINTER(_dbl)]
     L.spkm_timing_log.argtypes = [_vp, C.c_int]
     L.spkm_timing_read.argtypes = [_vp, C.POINTER(_dbl), C.c_int, C.POINTER(C.c_int)]
+    L.spkm_debug_block_times.argtypes = [_vp, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
     _lib = L
     return L
 

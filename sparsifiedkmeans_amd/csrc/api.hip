@@ -29,7 +29,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -136,7 +136,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
-                     &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind};
+                     &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -300,7 +300,7 @@ static int pick_kt(const spkm_ctx* ctx, uint64_t p, uint64_t K)
     int best = 0;
     uint64_t best_slots = ~0ull;
     for (int kt : {16, 32, 64}) {
-        if ((p + 1) * (uint64_t)kt * 8 > ctx->lds_max) continue;
+        if ((p + 1) * (uint64_t)kt * 8 + 16 > ctx->lds_max) continue;
         const uint64_t slots = ((K + kt - 1) / kt) * kt;
         if (slots < best_slots || (slots == best_slots && kt > best)) { best = kt; best_slots = slots; }
     }
@@ -373,14 +373,14 @@ static hipError_t timing_end(spkm_ctx* ctx)
 template <int KT, typename IR, bool FIXED>
 static int launch_tile2(spkm_ctx* ctx, const spkm_shard* s, int K, int G, int chunk)
 {
-    const size_t lds = (size_t)(s->p + 1) * KT * 8;
+    const size_t lds = (size_t)(s->p + 1) * KT * 8 + 16; // tile + work-ticket counter
     auto kern = k_assign_tile<KT, IR, FIXED>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(timing_begin(ctx));
     hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const long long*)s->jc,
                        (const IR*)s->ir, (const double*)s->x, (const double*)ctx->tiles.p, (int)s->p, (int)s->n,
                        (long long)s->nnz, s->fixed_s, K, (const spkm_blockmap*)ctx->bmap.p, chunk,
-                       (double*)ctx->part_acc.p, (int*)ctx->part_k.p);
+                       (double*)ctx->part_acc.p, (int*)ctx->part_k.p, (long long*)ctx->dbg.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(timing_end(ctx));
     return SPKM_OK;
@@ -494,6 +494,27 @@ extern "C" int spkm_last_assign_kernel_ms(spkm_ctx* ctx, double* ms)
     float f = 0.f;
     HIP_TRY(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
     *ms = (double)f;
+    return SPKM_OK;
+}
+
+// Developer aid: per-workgroup wall-clock stamps of the tiled kernel (start, end; 100 MHz ticks).
+// enable allocates the buffer (filled by every later spkm_assign_dev); read copies it out.
+extern "C" int spkm_debug_block_times(spkm_ctx* ctx, int enable, int64_t* out, int cap, int* nblocks)
+{
+    if (!ctx) return SPKM_ERR_NULL_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (enable) {
+        const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        int rc = ensure(ctx, ctx->dbg, (size_t)nb * 16);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->dbg.p, 0, (size_t)nb * 16, ctx->stream));
+        return SPKM_OK;
+    }
+    if (!ctx->dbg.p || !out || !nblocks) return SPKM_ERR_BAD_VALUE;
+    const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, ctx->dbg.p, (size_t)std::min(nb, cap) * 16, hipMemcpyDeviceToHost));
+    *nblocks = nb;
     return SPKM_OK;
 }
 
