@@ -119,6 +119,15 @@ uint64_t spkm_reduce_len(uint64_t p, uint64_t K);
 int spkm_assign_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers, double gamma,
                     int32_t *d_assign, double *d_mind, double *d_stats, uint64_t *d_nk_u64);
 
+/* The same with SPARSE centres (private/findClusterAssignments.m:63-75; Lloyd iteration 1 under the
+ * default denseCenters=false, and k-means++ style starts): d_centers is p x K dense with zeros where a
+ * centre has no entry, d_mask (p x K bytes) marks each centre's support.  For centre k the distance
+ * runs over supp(x_i) ∩ supp(c_k) with x divided by gamma_c(k) = nnz(c_k)/p and c by gamma
+ * (gamma <= 0: no scaling at all, :73).  Outputs as spkm_assign_dev. */
+int spkm_assign_sparse_centers_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers,
+                                   const uint8_t *d_mask, double gamma, int32_t *d_assign, double *d_mind,
+                                   double *d_stats, uint64_t *d_nk_u64);
+
 /* Per-cluster accumulation (kmeans_sparsified.m:430-431,447-448 with the mask of :352-355):
  * fills d_reduce (device, spkm_reduce_len doubles) = { S = sum X(:,ind), Cnt = sum spones(X)(:,ind),
  * nk, obj2 } for this shard.  Call after spkm_assign_dev on the same context (obj2/nk are taken

@@ -95,6 +95,7 @@ def lib():
     L.spkm_reduce_len.argtypes = [_u64, _u64]
     L.spkm_reduce_len.restype = _u64
     L.spkm_assign_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp, _vp, _vp]
+    L.spkm_assign_sparse_centers_dev.argtypes = [_vp, _vp, _u64, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]
     L.spkm_accumulate_dev.argtypes = [_vp, _vp, _u64, _vp, _vp]
     L.spkm_finalize_dev.argtypes = [_vp, _u64, _u64, _vp, _dbl, _vp, _vp]
     L.spkm_fwht_dev.argtypes = [_vp, _u64, _u64, _vp, _vp]

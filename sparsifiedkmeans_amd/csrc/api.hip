@@ -396,6 +396,25 @@ static int launch_tile(spkm_ctx* ctx, const spkm_shard* s, int K, int G, int chu
 
 static constexpr int COMBINE_BLOCKS = 1024;
 
+static int combine_partials(spkm_ctx* ctx, long long n, int G, int K, int32_t* d_assign, double* d_mind,
+                            double* d_stats, uint64_t* d_nk_u64)
+{
+    int rc;
+    const int cb = (int)std::min<long long>(COMBINE_BLOCKS, (n + 255) / 256);
+    if ((rc = ensure(ctx, ctx->blk_obj, (size_t)cb * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_max, (size_t)cb * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_imax, (size_t)cb * 8))) return rc;
+    hipLaunchKernelGGL(k_combine, dim3(cb), dim3(256), (size_t)K * 4, ctx->stream, (const double*)ctx->part_acc.p,
+                       (const int*)ctx->part_k.p, n, G, K, (int*)d_assign, d_mind, (double*)ctx->blk_obj.p,
+                       (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p, (unsigned long long*)ctx->nk.p);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
+                       (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, cb, (double*)ctx->stats.p);
+    HIP_TRY(hipGetLastError());
+    if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPKM_OK;
+}
+
 extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const double* d_centers,
                                double gamma, int32_t* d_assign, double* d_mind, double* d_stats,
                                uint64_t* d_nk_u64)
@@ -471,19 +490,53 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
     }
     ctx->assign_KT = KT;
     ctx->assign_G = G;
-    const int cb = (int)std::min<long long>(COMBINE_BLOCKS, (n + 255) / 256);
-    if ((rc = ensure(ctx, ctx->blk_obj, (size_t)cb * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->blk_max, (size_t)cb * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->blk_imax, (size_t)cb * 8))) return rc;
-    hipLaunchKernelGGL(k_combine, dim3(cb), dim3(256), (size_t)K * 4, ctx->stream, (const double*)ctx->part_acc.p,
-                       (const int*)ctx->part_k.p, n, G, K, (int*)d_assign, d_mind, (double*)ctx->blk_obj.p,
-                       (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p, (unsigned long long*)ctx->nk.p);
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
-                       (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, cb, (double*)ctx->stats.p);
+    return combine_partials(ctx, n, G, K, d_assign, d_mind, d_stats, d_nk_u64);
+}
+
+extern "C" int spkm_assign_sparse_centers_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
+                                              const double* d_centers, const uint8_t* d_mask, double gamma,
+                                              int32_t* d_assign, double* d_mind, double* d_stats,
+                                              uint64_t* d_nk_u64)
+{
+    if (!ctx || !s || !d_centers || !d_mask || !d_assign || !d_mind) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int K = (int)K64, p = (int)s->p;
+    const long long n = (long long)s->n;
+    int rc;
+    if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
+    ctx->ev_valid = false;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, 4 * 8, ctx->stream));
+        if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
+        if (d_nk_u64) HIP_TRY(hipMemsetAsync(d_nk_u64, 0, (size_t)K * 8, ctx->stream));
+        return SPKM_OK;
+    }
+    if ((rc = ensure(ctx, ctx->ct, (size_t)p * K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->tmp_mind, (size_t)p * K))) return rc;     // row-major mask
+    if ((rc = ensure(ctx, ctx->tmp_assign, (size_t)K * 8))) return rc;   // gamma_c per centre
+    if ((rc = ensure(ctx, ctx->part_acc, (size_t)n * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->part_k, (size_t)n * 4))) return rc;
+    hipLaunchKernelGGL(k_prep_sparse_centers, dim3(K), dim3(256), 0, ctx->stream, d_centers, d_mask, p, K, gamma,
+                       (double*)ctx->ct.p, (unsigned char*)ctx->tmp_mind.p, (double*)ctx->tmp_assign.p);
+    const int blocks = std::max(1, ctx->num_cus) * 8;
+    const int scale = gamma > 0.0 ? 1 : 0;
+    if (s->ir_bits == 16)
+        hipLaunchKernelGGL((k_assign_sparse_centers<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
+                           (const double*)ctx->ct.p, (const unsigned char*)ctx->tmp_mind.p,
+                           (const double*)ctx->tmp_assign.p, scale, K, n, (double*)ctx->part_acc.p,
+                           (int*)ctx->part_k.p);
+    else
+        hipLaunchKernelGGL((k_assign_sparse_centers<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
+                           (const double*)ctx->ct.p, (const unsigned char*)ctx->tmp_mind.p,
+                           (const double*)ctx->tmp_assign.p, scale, K, n, (double*)ctx->part_acc.p,
+                           (int*)ctx->part_k.p);
     HIP_TRY(hipGetLastError());
-    if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    return SPKM_OK;
+    return combine_partials(ctx, n, 1, K, d_assign, d_mind, d_stats, d_nk_u64);
 }
 
 extern "C" int spkm_last_assign_kernel_ms(spkm_ctx* ctx, double* ms)

@@ -112,6 +112,17 @@ class LloydEngine:
                                               _p(self.assign), _p(self.mind), _p(self.stats), _p(self.nk)),
                    "spkm_assign_dev")
 
+    def assign_sparse_step(self, centers: torch.Tensor, mask: torch.Tensor):
+        """Sparse-centres branch (findClusterAssignments.m:63-75): ``centers`` [K, p] dense values,
+        ``mask`` [K, p] uint8 support of each centre."""
+        assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and tuple(mask.shape) == (self.K, self.p)
+        g = self.gamma if self.unbiased else 0.0
+        _lib.check(_lib.lib().spkm_assign_sparse_centers_dev(self.ctx.handle, self.shard.handle, self.K, _p(centers),
+                                                             _p(mask), g, _p(self.assign), _p(self.mind),
+                                                             _p(self.stats), _p(self.nk)),
+                   "spkm_assign_sparse_centers_dev")
+
     def accumulate_step(self):
         _lib.check(_lib.lib().spkm_accumulate_dev(self.ctx.handle, self.shard.handle, self.K, _p(self.assign),
                                                   _p(self.reduce)), "spkm_accumulate_dev")

@@ -1,0 +1,334 @@
+"""Host driver: the reference's entry point ``kmeans_sparsified`` and its helper
+``findClusterAssignments`` (same names, options and error behaviour), with the hot loops on
+the MI355X through libspkm.so.
+
+Scope: the sparsified path -- 'Sparsify',true with the Hadamard sketch or no
+sketch.  What the reference does with MATLAB toolboxes outside that path (dense k-means via
+pdist2, DCT sketch, matfile streaming, two-pass outputs) raises NotImplementedError naming the
+option, rather than silently doing something else.
+
+MATLAB's RNG cannot be reproduced here; every random product (sign vector, sampled rows, initial
+centres) comes from ``rng`` (a numpy Generator or seed), so runs are reproducible per seed but
+not bit-comparable with a MATLAB run.  Given the same random products the Lloyd iteration itself
+is: assignments bit-exact, centroids within 1e-6 relative (tests/).
+
+Indices follow the reference: IDX is 1-based (values 1..K).
+"""
+from __future__ import annotations
+
+import time
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import synth
+from .engine import LloydEngine, Shard, mix_device, torch_context
+
+EPS = np.finfo(np.float64).eps
+
+# kmeans_sparsified.m:130-155 (name, default)
+_DEFAULTS = dict(
+    Replicates=1, Start="Arthur", MaxIter=100, Display=False, PrintEvery=10, Tol=1e-6, Sparsify=False,
+    SparsityLevel=0.01, SketchType="auto", EmptyAction="singleton", ColumnSamples=False, MLcorrection=True,
+    DataFile=None, MB_limit=500, DataFileVerbose=False, SparsityIgnoreUpsampling=False, FORCE_BUG=False,
+    tryBuiltinMex=True, unbiasedDistance=True, unbiasedInitialization=True, denseCenters=False)
+_EXTRA = dict(rng=None, device=None, nargout=5)  # Python-side additions (not reference options)
+
+
+def _parse(opts: dict) -> dict:
+    canon = {k.lower(): k for k in list(_DEFAULTS) + list(_EXTRA)}
+    out = dict(_DEFAULTS)
+    out.update(_EXTRA)
+    for k, v in opts.items():
+        ck = canon.get(k.lower())
+        if ck is None:
+            raise TypeError(f"'{k}' is not a recognized parameter")  # inputParser behaviour
+        out[ck] = v
+    if isinstance(out["Display"], str) and out["Display"].lower() not in ("off", "iter", "final"):
+        raise ValueError("Display must be 'off', 'iter' or 'final'")  # kmeans_sparsified.m:136-137
+    if not (0 < out["SparsityLevel"] <= 1):
+        raise ValueError("SparsityLevel must satisfy 0 < x <= 1")     # :141
+    if str(out["EmptyAction"]).lower() not in ("singleton", "error", "drop"):
+        raise ValueError("invalid EmptyAction choice")                # :143-144
+    return out
+
+
+def _nextpow2(p: int) -> int:
+    return 1 << max(0, int(np.ceil(np.log2(p)))) if p > 1 else 1
+
+
+class _Sketch:
+    """mix / unmix of kmeans_sparsified.m:238-296 on device tensors laid out [n, p]."""
+
+    def __init__(self, ctx, kind: str, p: int, sign: np.ndarray | None):
+        self.ctx, self.kind, self.p = ctx, kind, p
+        self.p2 = _nextpow2(p) if kind == "hadamard" else p
+        self.sign = None if sign is None else torch.tensor(sign, dtype=torch.float64, device=f"cuda:{ctx.device}")
+
+    def mix(self, x: torch.Tensor, premul: float = 1.0) -> torch.Tensor:
+        if self.kind == "none":
+            return x * premul if premul != 1.0 else x
+        # H(DD*upsample(x)) with H(x) = hadamard(x)/sqrt(p2)   (:241-248,286-295)
+        return mix_device(self.ctx, x.contiguous(), self.p2, self.sign, premul, float(np.sqrt(np.float64(self.p2))))
+
+    def unmix(self, y: torch.Tensor) -> torch.Tensor:
+        if self.kind == "none":
+            return y
+        # downsample(DD*Ht(y)), Ht = H (:255,296)
+        z = mix_device(self.ctx, y.contiguous(), self.p2, None, 1.0, float(np.sqrt(np.float64(self.p2))))
+        return (z * self.sign)[:, : self.p].contiguous()
+
+
+def findClusterAssignments(X, centers, tryBuiltinMex=None, gamma=None, ctx=None):
+    """[assignments, distances] = findClusterAssignments(X, centers, tryBuiltinMex, gamma)
+    (private/findClusterAssignments.m) for SPARSE X (p x n scipy matrix): dense centres use the
+    tiled HIP kernel, sparse centres (scipy matrix) the sparse-centres kernel.  assignments are
+    1-based.  The dense-X branch (:124-166) is out of scope."""
+    if not sp.issparse(X):
+        raise NotImplementedError("findClusterAssignments: dense X (pdist2 branch, findClusterAssignments.m:124-166) "
+                                  "is outside the sparsified hot path")
+    ctx = ctx or torch_context()
+    p, n = X.shape
+    if centers.shape[0] != p:
+        raise ValueError("Array of centers not of correct size")  # :55
+    K = centers.shape[1]
+    eng = LloydEngine(Shard.from_scipy(ctx, X), K, gamma if gamma else 1.0, unbiased=bool(gamma))
+    dev = f"cuda:{ctx.device}"
+    if sp.issparse(centers):
+        Cd = np.ascontiguousarray(centers.toarray().T)
+        M = np.ascontiguousarray((centers != 0).toarray().T.astype(np.uint8))
+        eng.assign_sparse_step(torch.tensor(Cd, device=dev), torch.tensor(M, device=dev))
+    else:
+        eng.assign_step(torch.tensor(np.ascontiguousarray(np.asarray(centers, np.float64).T), device=dev))
+    return eng.assign.cpu().numpy().astype(np.int64) + 1, eng.mind.cpu().numpy()
+
+
+def _weighted_draw(rng, w):
+    """randsample(n,1,true,w) (Arthur_initialization.m:50): one index, probability ∝ w."""
+    c = np.cumsum(w)
+    return int(min(np.searchsorted(c, rng.random() * c[-1], side="right"), len(w) - 1))
+
+
+def kmeans_sparsified(X, K, **options):
+    """[IDX, C, SUMD, D, OUTPUT] = kmeans_sparsified(X, K, 'Name', value, ...)   (kmeans_sparsified.m:1)
+
+    X: n x p array (points are rows; 'ColumnSamples',True for p x n).  Returns the tuple
+    (IDX, C, SUMD, D, OUTPUT); IDX is 1-based.  See module docstring for scope."""
+    t0 = time.time()
+    o = _parse(options)
+    if o["nargout"] > 5:
+        raise NotImplementedError("two-pass outputs (kmeans_sparsified.m:522-571) are outside the hot-path scope")
+    if o["DataFile"] is not None or isinstance(X, str):
+        raise NotImplementedError("'DataFile' streaming (sampleAndMixFromLargeFile.m) is not built yet (SURVEY §8f #3)")
+    if not o["Sparsify"]:
+        raise NotImplementedError("'Sparsify',false is the dense k-means path (pdist2 / expanded quadratic, "
+                                  "findClusterAssignments.m:124-166): outside the sparsified hot path")
+    MLcorrection = bool(o["MLcorrection"]) and bool(o["Sparsify"])   # :171
+    if not MLcorrection:
+        raise NotImplementedError("'MLcorrection',false densifies every cluster (kmeans_sparsified.m:449-451): "
+                                  "outside the sparsified hot path")
+    rng = o["rng"] if isinstance(o["rng"], np.random.Generator) else np.random.default_rng(o["rng"])
+    ctx = torch_context(o["device"])
+    dev = f"cuda:{ctx.device}"
+    Display = o["Display"] if isinstance(o["Display"], str) else "off"
+    OUTPUT = dict(LoadFromDisk=False, Options=dict(o), Sparsify=True)
+
+    X = np.asarray(X, np.float64)
+    if np.iscomplexobj(X):
+        raise ValueError("Code and distance computations require real data")   # :312-314
+    if not o["ColumnSamples"]:
+        X = X.T                                                                 # :214-216 (points become columns)
+    p, n = X.shape
+    if n < K:
+        raise ValueError("X must have more samples than the number of clusters.")  # :219-221
+
+    # ---- sketch (:224-296) ----
+    sk = o["SketchType"]
+    if isinstance(sk, (list, tuple)):
+        raise NotImplementedError("function-handle sketches run in MATLAB, not here")
+    sk = str(sk).lower()
+    if sk == "auto":
+        sk = "hadamard" if p == _nextpow2(p) else "dct"                          # :226-231
+        OUTPUT["SketchType"] = "Hadamard" if sk == "hadamard" else "DCT"
+    if sk == "dct":
+        raise NotImplementedError("the DCT sketch uses the Signal Processing Toolbox (kmeans_sparsified.m:256-258); "
+                                  "pass 'SketchType','Hadamard' (zero-pads to a power of two) or 'none'")
+    if sk in ("nothing", "none"):
+        sketch = _Sketch(ctx, "none", p, None)
+    elif sk == "hadamard":
+        p2 = _nextpow2(p)
+        d = np.sign(rng.random(p2)) if o["FORCE_BUG"] else np.sign(rng.standard_normal(p2))  # :283-287
+        d[d == 0] = 1.0
+        sketch = _Sketch(ctx, "hadamard", p, d)
+        OUTPUT["SlowHadamard"] = False
+    else:
+        raise ValueError('bad type for "SketchType"')                            # :273
+    p2 = sketch.p2
+
+    t1 = time.time()
+    Xdev = torch.tensor(np.ascontiguousarray(X.T), device=dev)                   # [n, p]
+    Xmixed = sketch.mix(Xdev, premul=1.0 + 2.0 * EPS)                            # :292,295 (X*(1+2eps) then mix)
+    torch.cuda.synchronize()
+    OUTPUT["TimeToSketch"] = time.time() - t1
+
+    small_p = synth.small_p_of(o["SparsityLevel"], p2)                           # :324-326
+    gamma = small_p / p                                                          # :329 (divides by p, not p2)
+    t1 = time.time()
+    Y = synth.sparsify_dense(Xmixed.cpu().numpy().T, small_p, rng)               # randsample_fixedNumberEntries (:334)
+    OUTPUT["TimeToSample"] = time.time() - t1
+    if Display in ("iter", "final"):
+        print(f"Randomly mixing of type {sk}")
+        print(f"Randomly taking {100 * gamma:.1f}% of the data; actual dataset is {100 * Y.nnz / (p2 * n):.1f}% sparse")
+
+    shard = Shard.from_scipy(ctx, Y)
+    unbiased = bool(o["unbiasedDistance"])                                       # :369-373
+    start = o["Start"]
+    Replicates = int(o["Replicates"])
+    OUTPUT.update(iterations=np.zeros(Replicates, int), stoppingDiff=np.zeros(Replicates),
+                  objectives=np.zeros(Replicates), replicateTimes=np.zeros(Replicates),
+                  replicateTimesJustInitialization=np.zeros(Replicates))
+    if isinstance(start, str) and start.lower() == "uniform":
+        mn, mx = float(Y.data.min(initial=0.0)), float(Y.data.max(initial=0.0))  # full(min(X(:))) incl. implicit zeros
+        if Y.nnz < p2 * n:
+            mn, mx = min(mn, 0.0), max(mx, 0.0)
+
+    best = dict(obj=np.inf)
+    distances = None
+    for trial in range(Replicates):
+        t1 = time.time()
+        Kc = K
+        sparse_mask = None                    # [K, p2] uint8 while the centres are sparse
+        if isinstance(start, str):
+            s = start.lower()
+            if s == "sample":
+                ind = rng.choice(n, K, replace=False)                            # randsample(n,K) (:387)
+                Cs = Y[:, ind]
+                centers_np, sparse_mask = Cs.toarray(), (Cs != 0).toarray().astype(np.uint8)
+            elif s == "uniform":
+                centers_np = (mx - mn) * rng.random((p2, K)) - mn                # :390 (the reference subtracts mn)
+            elif s in ("arthur", "++", "kmeans++", "k-means++", "k-means-++"):
+                g_init = gamma if o["unbiasedInitialization"] else None          # :392-396
+                centers_np, sparse_mask = _arthur(ctx, shard, Y, K, g_init, rng)
+            else:
+                raise ValueError('cannot handle other types of "Start" values')  # :398
+        else:
+            S = np.asarray(start, np.float64)
+            if not o["ColumnSamples"]:
+                S = S.T                                                          # want p x K (:403-405)
+            if S.shape != (p, K):
+                raise ValueError("Start matrix must be K x p (or p x K with ColumnSamples)")
+            centers_np = sketch.mix(torch.tensor(np.ascontiguousarray(S.T), device=dev)).cpu().numpy().T  # :406
+            if Replicates > 1:
+                warnings.warn("initialization is specified, so running more than 1 replicate is not helpful")
+        if o["denseCenters"]:
+            sparse_mask = None                                                   # centers = full(centers) (:412-414)
+        OUTPUT["replicateTimesJustInitialization"][trial] = time.time() - t1
+
+        eng = LloydEngine(shard, Kc, gamma, unbiased=unbiased)
+        centers = torch.tensor(np.ascontiguousarray(centers_np.T), device=dev)   # [K, p2]
+        mask_t = None if sparse_mask is None else torch.tensor(np.ascontiguousarray(sparse_mask.T), device=dev)
+        its = 0
+        dff = obj = np.nan
+        assignments = None
+        for its in range(1, int(o["MaxIter"]) + 1):
+            if mask_t is not None:
+                eng.assign_sparse_step(centers, mask_t)                          # findClusterAssignments.m:63-75
+            else:
+                eng.assign_step(centers)                                         # findClusterAssignments.m:76-82
+            old = centers.clone()
+            eng.accumulate_step()
+            eng.allreduce_step()
+            eng.finalize_step(centers)                                           # :447-448
+            nk = eng.global_nk().cpu().numpy()
+            empty = np.flatnonzero(nk == 0)
+            dropped = False
+            if empty.size:
+                warnings.warn("cluster has lost all its members")                # :433
+                act = str(o["EmptyAction"]).lower()
+                if act == "error":
+                    raise RuntimeError("One cluster lost all its members")      # :439
+                if act == "singleton":
+                    imax = int(eng.stats[2].item())                              # [~,iMax] = max(distances) (:436)
+                    col = torch.tensor(Y[:, imax].toarray().ravel(), device=dev)
+                    for ki in empty:
+                        centers[ki] = col                                        # centers(:,ki) = X(:,iMax) (:437)
+                else:                                                            # 'drop' (:441,454-459)
+                    keep = np.setdiff1d(np.arange(Kc), empty)
+                    centers = centers[keep].contiguous()
+                    old = old[keep].contiguous()
+                    Kc = keep.size
+                    eng = LloydEngine(shard, Kc, gamma, unbiased=unbiased)
+                    dropped = True
+            if mask_t is not None:
+                # after the first ML update the columns are (almost) full: issparse && nnz > .99 -> full (:460-464)
+                filled = float((centers != 0).double().mean().item())
+                if filled > 0.99 or dropped:
+                    mask_t = None
+                else:
+                    mask_t = (centers != 0).to(torch.uint8).contiguous()
+                    if dropped:
+                        mask_t = mask_t[: Kc]
+            dff = float(torch.linalg.norm(old - centers).item())                 # norm(centersOld-centers,'fro') (:470)
+            obj = float(np.sqrt(eng.reduce[-1].item()))                          # sqrt(sum(distances.^2)) (:471)
+            assignments = None if dropped else eng.assign
+            if Display == "iter" and its % int(o["PrintEvery"]) == 0:
+                print(f"Iter: {its:3d}; change in cluster centers: {dff:.2e}; objective: {obj:.2e}")
+            if dff < o["Tol"]:
+                break                                                            # :476-478
+            if bool(torch.isnan(centers).any().item()):
+                raise RuntimeError("Found NaN in centers")                       # :480-484
+        OUTPUT["replicateTimes"][trial] = time.time() - t1
+        OUTPUT["stoppingDiff"][trial], OUTPUT["objectives"][trial], OUTPUT["iterations"][trial] = dff, obj, its
+        distances = eng.mind.cpu().numpy()
+        if obj < best["obj"]:                                                    # :493-503
+            best = dict(obj=obj, K=Kc, centers=centers.clone(),
+                        assign=None if assignments is None else assignments.cpu().numpy().astype(np.int64) + 1,
+                        dist=distances.copy())
+        if Display == "iter" or (Display == "final" and best["obj"] == obj):
+            print(f"Trial {trial + 1:3d} of {Replicates:3d} total, objective {obj:.2e}")
+
+    OUTPUT["TimeInitialization"] = float(OUTPUT["replicateTimesJustInitialization"].sum())
+    OUTPUT["TimeAlgo_wo_initialization"] = float(OUTPUT["replicateTimes"].sum()) - OUTPUT["TimeInitialization"]
+    Kb = best["K"]
+    IDX = best["assign"] if best["assign"] is not None else np.zeros(0, np.int64)
+    SUMD = np.zeros(Kb)
+    for ki in range(Kb):                                                         # :514-518: the LAST trial's distances
+        SUMD[ki] = np.sum(distances[IDX == ki + 1] ** 2) if IDX.size else 0.0
+    OUTPUT["TimeOverall_OnePass"] = time.time() - t0
+    Cout = sketch.unmix(best["centers"]).cpu().numpy().T                         # p x K (:523)
+    D = best["dist"]
+    if not o["ColumnSamples"]:
+        Cout = Cout.T                                                            # K x p like MATLAB's kmeans (:586-590)
+    OUTPUT["TimeOverall"] = time.time() - t0
+    return IDX, Cout, SUMD, D, OUTPUT
+
+
+def _arthur(ctx, shard, Y, K, gamma, rng):
+    """K-means++ seeding, private/Arthur_initialization.m:24-69: first centre uniform; then K-1
+    rounds of [~,dist] = findClusterAssignments(X, full(centres), [], gamma) and a draw ∝ dist.^2
+    with the 400-retry duplicate rule.  Returns (p2 x K dense values, p2 x K support mask):
+    the centres are columns of the sparse X (:36,68)."""
+    if K < 1:
+        raise ValueError("K must be >= 1")
+    p2, n = Y.shape
+    dev = f"cuda:{ctx.device}"
+    chosen = [int(rng.integers(n))]                                              # randi(n,1) (:35)
+    for k in range(1, K):
+        Cd = Y[:, chosen].toarray()
+        eng = LloydEngine(shard, len(chosen), gamma if gamma else 1.0, unbiased=bool(gamma))
+        eng.assign_step(torch.tensor(np.ascontiguousarray(Cd.T), device=dev))    # full(ref) (:31,39)
+        dist = eng.mind.cpu().numpy()
+        w = dist ** 2
+        draw = (lambda: _weighted_draw(rng, w)) if np.linalg.norm(dist) > 0 else (lambda: int(rng.integers(n)))
+        i = draw()
+        counter = 1
+        while i in chosen and counter < 400:                                     # :54-61
+            i = draw()
+            counter += 1
+        if i in chosen:
+            raise RuntimeError("Cannot sample with replacement with this distribution")  # :62-65
+        chosen.append(i)
+    Cs = Y[:, chosen]
+    return Cs.toarray(), (Cs != 0).toarray().astype(np.uint8)

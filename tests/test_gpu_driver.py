@@ -1,0 +1,109 @@
+"""-m gpu: the host driver (kmeans_sparsified / findClusterAssignments mirrors)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from util import parts, random_csc
+
+pytestmark = pytest.mark.gpu
+
+
+def _accuracy(idx, labels, K):
+    """best one-to-one matching accuracy (greedy is enough for well-separated clusters)."""
+    from scipy.optimize import linear_sum_assignment
+
+    M = np.zeros((K, K))
+    for a, b in zip(idx - 1, labels):
+        M[a, b] += 1
+    r, c = linear_sum_assignment(-M)
+    return M[r, c].sum() / len(labels)
+
+
+def test_find_cluster_assignments_sparse_centres_matches_oracle(gpu_ctx, oracle):
+    """findClusterAssignments.m:63-75: centres are sparse columns of X; distance over the common
+    support with X/gamma_c and c/gamma."""
+    from sparsifiedkmeans_amd.kmeans import findClusterAssignments
+
+    p, n, K = 256, 3000, 9
+    X = random_csc(p, n, 13, seed=8, ragged=True, empty_cols=(4,))
+    Cs = X[:, [5, 17, 99, 100, 1500, 2000, 2500, 2999, 7]].tocsc()
+    for gamma in (13 / 256, None):
+        a, d = findClusterAssignments(X, Cs, None, gamma, ctx=gpu_ctx)
+        ref = oracle.dist_sparse_centers(p, n, *parts(X), *parts(Cs), K, gamma or 0.0)
+        rd, ra = oracle.min_cols(ref)
+        assert np.array_equal(a - 1, ra) and np.array_equal(d, rd)
+
+
+def test_find_cluster_assignments_dense_centres(gpu_ctx, oracle):
+    from sparsifiedkmeans_amd.kmeans import findClusterAssignments
+
+    p, n, K = 512, 2000, 12
+    X = random_csc(p, n, 26, seed=2)
+    Cm = np.random.default_rng(0).standard_normal((p, K))
+    a, d = findClusterAssignments(X, Cm, None, 0.05, ctx=gpu_ctx)
+    ra, rd = oracle.assign(p, n, *parts(X), Cm, 0.05)
+    assert np.array_equal(a - 1, ra) and np.array_equal(d, rd)
+    with pytest.raises(ValueError, match="correct size"):
+        findClusterAssignments(X, Cm[:-1], ctx=gpu_ctx)
+
+
+@pytest.mark.parametrize("start", ["Arthur", "sample"])
+def test_kmeans_sparsified_example_config(gpu_ctx, start):
+    """example_sparseKMeans.m: p=512, n=5000, k=5, gamma=0.05 -- the reference's own demo
+    recovers the planted clusters; so must we (checked on the labels, no RNG parity claimed)."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    X, centres, labels = synth.gmm_dense(512, 5000, 5, seed=234)
+    IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, 5, Sparsify=True, SparsityLevel=0.05, Replicates=5,
+                                             Start=start, rng=1, Display="off")
+    assert IDX.shape == (5000,) and IDX.min() >= 1 and IDX.max() <= 5
+    assert C.shape == (5, 512) and SUMD.shape == (5,) and D.shape == (5000,)
+    assert _accuracy(IDX, labels, 5) > 0.99
+    # centres come back un-mixed, in the original space: close to the planted ones
+    err = min(np.abs(C[None, :, :] - centres.T[:, None, :]).max(axis=2).min(axis=1).max(), 1e9)
+    assert err < 0.5
+    assert OUT["iterations"].shape == (5,) and np.all(OUT["iterations"] >= 1)
+
+
+def test_kmeans_sparsified_start_matrix_matches_oracle_loop(gpu_ctx, oracle):
+    """With the random products pinned (same sign vector / sample through the same rng) the Lloyd
+    loop started from a 'Start' matrix must follow the oracle's loop."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    p, n, K, g = 256, 3000, 4, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=5)
+    S = X[:, [0, 800, 1600, 2400]].T                      # K x p, original space
+    IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, Sparsify=True, SparsityLevel=g, Start=S, rng=3,
+                                             SketchType="Hadamard", MaxIter=50)
+    # replay the random products exactly as the driver drew them
+    rng = np.random.default_rng(3)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    Xm = oracle.mix(X, d, p)
+    s = synth.small_p_of(g, p)
+    Y = synth.sparsify_dense(Xm, s, rng)
+    C0 = oracle.fwht(S.T * d[:, None]) / np.sqrt(np.float64(p))
+    ref = oracle.lloyd(p, n, *parts(Y), C0, s / p, maxiter=50, tol=1e-6)
+    assert OUT["iterations"][0] == ref["iterations"]
+    assert np.array_equal(IDX - 1, ref["assign"])
+    # free-running: centroid sums differ in summation order (1e-16 relative), so distances agree to
+    # rounding, not bit-for-bit; the assignments above are nevertheless identical
+    assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
+    Cref = (oracle.fwht(ref["centers"]) / np.sqrt(np.float64(p))) * d[:, None]   # unmix
+    assert np.abs(C.T - Cref).max() <= 1e-6 * np.abs(Cref).max()
+    assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1]
+
+
+def test_kmeans_sparsified_option_errors(gpu_ctx):
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    X = np.random.default_rng(0).standard_normal((100, 8))
+    with pytest.raises(TypeError, match="not a recognized parameter"):
+        kmeans_sparsified(X, 3, Sparsify=True, Bogus=1)
+    with pytest.raises(ValueError, match="more samples"):
+        kmeans_sparsified(X[:2], 3, Sparsify=True)
+    with pytest.raises(NotImplementedError, match="DCT"):
+        kmeans_sparsified(np.zeros((100, 12)), 3, Sparsify=True)       # auto -> DCT for p not a power of two
+    with pytest.raises(NotImplementedError, match="dense k-means"):
+        kmeans_sparsified(X, 3)
