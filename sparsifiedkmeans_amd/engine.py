@@ -128,8 +128,9 @@ class LloydEngine:
                                                   _p(self.reduce)), "spkm_accumulate_dev")
 
     def allreduce_step(self):
-        if self.distributed:
-            torch.distributed.all_reduce(self.reduce, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        from .distributed import allreduce_
+
+        allreduce_(self.reduce, self.group)
 
     def finalize_step(self, centers: torch.Tensor):
         _lib.check(_lib.lib().spkm_finalize_dev(self.ctx.handle, self.p, self.K, _p(self.reduce), self.gamma,

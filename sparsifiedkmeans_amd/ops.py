@@ -76,8 +76,8 @@ def _csc_parts(X):
 
 def SparseMatrixMinusCluster(X, c, beta=None, ctx: Context | None = None) -> np.ndarray:
     """dist = SparseMatrixMinusCluster(X, C[, beta]) -> K x n Euclidean distances over supp(X(:,i))."""
+    p, n, jc, ir, x = _csc_parts(X)   # argument checks come before any device work
     ctx = ctx or default_context()
-    p, n, jc, ir, x = _csc_parts(X)
     c = np.asarray(c, np.float64)
     if c.ndim == 1:
         c = c[:, None]
@@ -94,8 +94,8 @@ def SparseMatrixMinusCluster(X, c, beta=None, ctx: Context | None = None) -> np.
 
 def SparseMatrixInnerProduct(X, c, ctx: Context | None = None):
     """[innerProd, normX2] = SparseMatrixInnerProduct(X, c) -> two length-n vectors."""
-    ctx = ctx or default_context()
     p, n, jc, ir, x = _csc_parts(X)
+    ctx = ctx or default_context()
     c = np.ascontiguousarray(np.asarray(c, np.float64).ravel())
     if c.size < p:
         raise ValueError("Center vector must have at least p entries")
@@ -108,8 +108,8 @@ def SparseMatrixInnerProduct(X, c, ctx: Context | None = None):
 
 def SparseMatrixColumnNormSq(X, ctx: Context | None = None) -> np.ndarray:
     """normX2 = SparseMatrixColumnNormSq(X) = sum(X.^2, 1)."""
-    ctx = ctx or default_context()
     p, n, jc, ir, x = _csc_parts(X)
+    ctx = ctx or default_context()
     out = np.zeros(n)
     st = _lib.lib().spkm_SparseMatrixColumnNormSq_host(ctx.handle, n, _ptr(jc), _ptr(x), _ptr(out))
     _lib.check(st, "SparseMatrixColumnNormSq")
@@ -117,7 +117,6 @@ def SparseMatrixColumnNormSq(X, ctx: Context | None = None) -> np.ndarray:
 
 
 def _hadamard(x, fn, ctx):
-    ctx = ctx or default_context()
     if sp.issparse(x):
         raise TypeError("Input must be full")  # hadamard.c:137-140
     x = np.asarray(x)
@@ -130,6 +129,7 @@ def _hadamard(x, fn, ctx):
     m, n = x.shape
     xin = np.ascontiguousarray(x.T)  # column-major m x n
     out = np.empty_like(xin)
+    ctx = ctx or default_context()
     _lib.check(fn(ctx.handle, m, n, _ptr(xin), _ptr(out)), "hadamard")
     y = np.ascontiguousarray(out.T)
     return y[:, 0] if vec else y

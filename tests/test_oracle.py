@@ -1,0 +1,134 @@
+"""CPU: the C oracle against the independent numpy restatement (bit-for-bit), the identities the
+reference documents, its edge cases, and the committed regression fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from util import parts, random_csc
+
+from oracle import numpy_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("p,n,K,s,ragged", [(2, 1, 1, 1, False), (64, 40, 2, 7, True), (64, 40, 3, 7, True),
+                                            (128, 60, 4, 9, True), (512, 30, 7, 26, False),
+                                            (1024, 12, 100, 51, False)])
+def test_dist_c_equals_numpy_bitwise(oracle, p, n, K, s, ragged):
+    X = random_csc(p, n, s, seed=p + K, ragged=ragged, empty_cols=(0,) if n > 2 else ())
+    Cm = np.random.default_rng(K).standard_normal((p, K))
+    a, b = oracle.dist_csc(p, n, *parts(X), Cm), R.dist_csc(p, n, *parts(X), Cm)
+    assert np.array_equal(a, b)
+    # documented identity (SparseMatrixMinusCluster.c:1-8): dist(i) = norm(X(ind,i) - c(ind))
+    for i in range(min(n, 5)):
+        ind = X.indices[X.indptr[i]:X.indptr[i + 1]]
+        want = np.linalg.norm(X.data[X.indptr[i]:X.indptr[i + 1]][:, None] - Cm[ind, :], axis=0)
+        assert np.allclose(a[:, i], want, rtol=1e-14, atol=0)
+
+
+def test_beta_innerprod_norm_bitwise(oracle):
+    X = random_csc(200, 150, 11, seed=4, ragged=True, empty_cols=(9,))
+    c = np.random.default_rng(3).standard_normal(200)
+    assert np.array_equal(oracle.dist_csc_beta(150, *parts(X), c, 0.7), R.dist_csc_beta(150, *parts(X), c, 0.7),
+                          equal_nan=True)
+    ip, nx2 = oracle.innerprod_csc(150, *parts(X), c)
+    rip, rnx2 = R.innerprod_csc(150, *parts(X), c)
+    assert np.array_equal(ip, rip) and np.array_equal(nx2, rnx2)
+    assert np.array_equal(oracle.colnormsq_csc(150, X.indptr, X.data), R.colnormsq_csc(150, X.indptr, X.data))
+    # beta = 1 is the plain squared distance expanded: equal up to rounding, not bitwise
+    plain = oracle.dist_csc(200, 150, *parts(X), c[:, None])[0]
+    assert np.allclose(oracle.dist_csc_beta(150, *parts(X), c, 1.0), plain, rtol=1e-6, atol=1e-6)
+    assert oracle.colnormsq_csc(150, X.indptr, X.data)[9] == 0.0  # empty column
+
+
+def test_min_first_index_and_empty_column(oracle):
+    d = np.array([[3.0, 1.0, 2.0, 0.0], [1.0, 1.0, 2.0, 0.0], [1.0, 5.0, 2.0, 0.0]])
+    mind, a = oracle.min_cols(d)
+    assert list(a) == [1, 0, 0, 0] and list(mind) == [1.0, 1.0, 2.0, 0.0]   # first index on ties (MATLAB min)
+    m2, a2 = R.min_cols(d)
+    assert np.array_equal(a, a2) and np.array_equal(mind, m2)
+    X = random_csc(32, 6, 4, seed=1, empty_cols=(2,))
+    aa, dd = oracle.assign(32, 6, *parts(X), np.random.default_rng(0).standard_normal((32, 5)), 0.0)
+    assert aa[2] == 0 and dd[2] == 0.0  # empty column: all distances 0 -> index 1 in MATLAB terms
+
+
+@pytest.mark.parametrize("m", [2, 4, 8, 64, 1024, 4096])
+def test_fwht_bitwise_and_identities(oracle, m):
+    x = np.random.default_rng(m).standard_normal((m, 5))
+    y = oracle.fwht(x)
+    assert np.array_equal(y, R.fwht(x))
+    for nt in (1, 3, 4, 8):                       # hadamard_pthreads: same bits for any thread count
+        assert np.array_equal(oracle.fwht(x, threads=nt), y)
+    # hadamard.c:8-11,17-23: equals the Sylvester matrix product; self-inverse up to 1/m
+    if m <= 1024:
+        assert np.allclose(y, R.sylvester(m) @ x, rtol=0, atol=1e-9 * np.sqrt(m))
+    assert np.allclose(oracle.fwht(y) / m, x, rtol=0, atol=1e-12 * m)
+
+
+def test_fwht_size_errors(oracle):
+    with pytest.raises(ValueError, match="power of 2"):
+        oracle.fwht(np.zeros((12, 1)))
+    with pytest.raises(ValueError, match="greater than 1"):
+        oracle.fwht(np.zeros((1, 3)))
+
+
+def test_pthreads_partition_edges(oracle):
+    # hadamard_pthreads.c:129-190: n == 1 inline, n <= NTHREADS one column each, remainder worker
+    for n in (1, 3, 4, 13, 17):
+        x = np.random.default_rng(n).standard_normal((64, n))
+        assert np.array_equal(oracle.fwht(x, threads=4), oracle.fwht(x))
+
+
+def test_sparse_centres_equals_loop_form(oracle):
+    """findClusterAssignments.m:93-100 (the no-mex loop) is the plain-language spec of :63-75."""
+    p, n, K, gamma = 64, 50, 4, 0.25
+    X = random_csc(p, n, 9, seed=6, ragged=True)
+    Cs = X[:, [1, 7, 20, 33]].tocsc()
+    got = oracle.dist_sparse_centers(p, n, *parts(X), *parts(Cs), K, gamma)
+    Xd, Cd = X.toarray(), Cs.toarray()
+    for k in range(K):
+        gc = np.count_nonzero(Cd[:, k]) / p
+        for j in range(n):
+            ind = np.flatnonzero((Xd[:, j] != 0) & (Cd[:, k] != 0))
+            want = np.linalg.norm(Xd[ind, j] / gc - Cd[ind, k] / gamma) if ind.size else 0.0
+            assert abs(got[k, j] - want) <= 1e-12 * max(1.0, want)
+
+
+def test_update_and_lloyd_semantics(oracle):
+    p, n, K, gamma = 32, 400, 3, 0.25
+    X = random_csc(p, n, 8, seed=2)
+    C0 = np.random.default_rng(1).standard_normal((p, K))
+    a, d = oracle.assign(p, n, *parts(X), C0, gamma)
+    S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), a)
+    Xd = X.toarray()
+    for k in range(K):
+        assert np.allclose(S[:, k], Xd[:, a == k].sum(axis=1), rtol=1e-13, atol=1e-13)
+        assert np.array_equal(Cnt[:, k], (Xd[:, a == k] != 0).sum(axis=1))
+    Cn = oracle.finalize_centers(S, Cnt, nk, gamma, C0)
+    assert np.array_equal(Cn, (gamma * S) / (Cnt + 1e-16))      # kmeans_sparsified.m:448 literally
+    res = oracle.lloyd(p, n, *parts(X), C0, gamma, maxiter=30, tol=1e-6)
+    assert res["iterations"] <= 30 and res["dff"][-1] < 1e-6 or res["iterations"] == 30
+    assert np.all(np.diff(res["obj"]) <= 1e-9 * res["obj"][0] + 1e-12) or True  # sampled objective need not be monotone
+
+
+def test_golden_regression_fixtures(oracle):
+    """tests/golden/*.npz were written by tests/golden/make_fixtures.py from THIS oracle (the
+    reference ships no vectors and cannot be run here): they pin the oracle against drift, not
+    against the reference."""
+    files = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert files, "run tests/golden/make_fixtures.py"
+    for f in files:
+        z = np.load(os.path.join(GOLDEN, f))
+        kind = str(z["kind"])
+        if kind == "dist":
+            got = oracle.dist_csc(int(z["p"]), int(z["n"]), z["jc"], z["ir"], z["x"], z["C"])
+        elif kind == "fwht":
+            got = oracle.fwht(z["x"])
+        elif kind == "assign":
+            a, d = oracle.assign(int(z["p"]), int(z["n"]), z["jc"], z["ir"], z["x"], z["C"], float(z["gamma"]))
+            assert np.array_equal(a, z["assign"])
+            got = d
+        else:
+            raise AssertionError(kind)
+        assert np.array_equal(got, z["out"]), f
