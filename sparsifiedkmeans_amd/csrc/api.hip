@@ -624,7 +624,7 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
             if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
             if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
             if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
-            hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream,
                                (const unsigned long long*)ctx->nk.p, K, SEG_POINTS, (long long*)ctx->offs.p,
                                (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p, (int*)ctx->nitems.p);
             const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
@@ -636,12 +636,12 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
                 hipLaunchKernelGGL((k_accumulate_sorted<unsigned short>), dim3(ab), dim3(256), slab, ctx->stream,
                                    (const long long*)s->jc, (const unsigned short*)s->ir, (const double*)s->x,
                                    (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
-                                   (const int*)ctx->nitems.p, p, sums, counts);
+                                   (const int*)ctx->nitems.p, p, s->fixed_s, sums, counts);
             else
                 hipLaunchKernelGGL((k_accumulate_sorted<unsigned int>), dim3(ab), dim3(256), slab, ctx->stream,
                                    (const long long*)s->jc, (const unsigned int*)s->ir, (const double*)s->x,
                                    (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
-                                   (const int*)ctx->nitems.p, p, sums, counts);
+                                   (const int*)ctx->nitems.p, p, s->fixed_s, sums, counts);
         } else {
             const int blocks = std::max(1, ctx->num_cus) * 8;
             if (s->ir_bits == 16)

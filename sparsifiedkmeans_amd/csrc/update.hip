@@ -95,20 +95,26 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ part
         if (hist[k]) atomicAdd(&nk[k], (unsigned long long)hist[k]);
 }
 
-// stats[0] = sum_b blk_obj2[b] (fixed order), stats[1] = max mind, stats[2] = its first index (as double).
+// stats[0] = sum_b blk_obj2[b] (fixed order: lane-strided partials, then a fixed shuffle tree),
+// stats[1] = max mind, stats[2] = its first index (as double).  One wave.
 __global__ void k_reduce_stats(const double* __restrict__ blk_obj2, const double* __restrict__ blk_max,
                                const long long* __restrict__ blk_imax, int nblk, double* __restrict__ stats)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     double o = 0.0, m = -1.0;
     long long im = 0x7fffffffffffffffLL;
-    for (int b = 0; b < nblk; b++) {
+    for (int b = lane; b < nblk; b += 64) {
         o += blk_obj2[b];
         if (blk_max[b] > m || (blk_max[b] == m && blk_imax[b] < im)) { m = blk_max[b]; im = blk_imax[b]; }
     }
-    stats[0] = o;
-    stats[1] = m;
-    stats[2] = (double)im;
+    for (int off = 32; off > 0; off >>= 1) {
+        o += __shfl_down(o, off);
+        const double om = __shfl_down(m, off);
+        const long long oi = __shfl_down(im, off);
+        if (om > m || (om == m && oi < im)) { m = om; im = oi; }
+    }
+    if (lane == 0) { stats[0] = o; stats[1] = m; stats[2] = (double)im; }
 }
 
 // Fallback accumulation straight into the global p x K tables with f64 hardware atomics
@@ -136,27 +142,52 @@ __global__ __launch_bounds__(256) void k_accumulate_atomic(const long long* __re
 
 // ---------------- sorted accumulation: counting sort by cluster + LDS slabs ----------------
 // offs[k] = exclusive prefix of nk; cursor[k] = offs[k]; builds the work-item list: one item per
-// (cluster, segment of <= seg points).  items[t] = {k, start, len}.  Single small block.
-__global__ void k_plan_segments(const unsigned long long* __restrict__ nk, int K, int seg,
-                                long long* __restrict__ offs, unsigned long long* __restrict__ cursor,
-                                int4* __restrict__ items, int* __restrict__ nitems)
+// (cluster, segment of <= seg points).  items[t] = {k, start, len}.  One 256-thread block: thread k
+// owns cluster k (strided for K > 256); two small scans give the point and item offsets.
+__global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long* __restrict__ nk, int K, int seg,
+                                                       long long* __restrict__ offs,
+                                                       unsigned long long* __restrict__ cursor,
+                                                       int4* __restrict__ items, int* __restrict__ nitems)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    long long run = 0;
-    int t = 0;
-    for (int k = 0; k < K; k++) {
-        offs[k] = run;
-        cursor[k] = (unsigned long long)run;
-        const long long cnt = (long long)nk[k];
-        for (long long s = 0; s < cnt; s += seg) {
-            const long long len = (cnt - s < seg) ? cnt - s : seg;
-            // start is relative to the cluster (fits 32 bits with 2^31 points per shard)
-            items[t++] = make_int4(k, (int)s, (int)len, 0);
+    __shared__ long long s_pts[256];
+    __shared__ int s_items[256];
+    __shared__ long long s_run_pts;
+    __shared__ int s_run_items;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_run_pts = 0; s_run_items = 0; }
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 256) {
+        const int k = k0 + tid;
+        const long long cnt = (k < K) ? (long long)nk[k] : 0;
+        const int nseg = (int)((cnt + seg - 1) / seg);
+        s_pts[tid] = cnt;
+        s_items[tid] = nseg;
+        __syncthreads();
+        // Hillis-Steele inclusive scans over the 256 slots
+        for (int off = 1; off < 256; off <<= 1) {
+            const long long a = (tid >= off) ? s_pts[tid - off] : 0;
+            const int b = (tid >= off) ? s_items[tid - off] : 0;
+            __syncthreads();
+            s_pts[tid] += a;
+            s_items[tid] += b;
+            __syncthreads();
         }
-        run += cnt;
+        const long long pbase = s_run_pts + s_pts[tid] - cnt;
+        const int ibase = s_run_items + s_items[tid] - nseg;
+        if (k < K) {
+            offs[k] = pbase;
+            cursor[k] = (unsigned long long)pbase;
+            for (int s = 0; s < nseg; s++) {
+                const long long st = (long long)s * seg;
+                const long long len = (cnt - st < seg) ? cnt - st : seg;
+                items[ibase + s] = make_int4(k, (int)st, (int)len, 0);
+            }
+        }
+        __syncthreads();
+        if (tid == 255) { s_run_pts += s_pts[255]; s_run_items += s_items[255]; }
+        __syncthreads();
     }
-    offs[K] = run;
-    *nitems = t;
+    if (tid == 0) { offs[K] = s_run_pts; *nitems = s_run_items; }
 }
 
 // perm[cursor[assign[i]]++] = i, with one global atomic per (block, cluster) via an LDS histogram.
@@ -189,7 +220,9 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
 
 // One workgroup per item: accumulate the item's points into an LDS slab
 // (sums f64[p] + counts u32[p]) with LDS atomics, then add the slab's touched rows into the
-// global p x K tables with one hardware f64 atomic per touched row.
+// global p x K tables with one hardware f64 atomic per touched row.  HBM-latency bound unless many
+// points are in flight: a wave fetches 64 point ids (and their column bounds) with one coalesced
+// load each, then walks them four at a time so that eight entry loads are outstanding per lane.
 template <typename IR>
 __global__ __launch_bounds__(256) void k_accumulate_sorted(const long long* __restrict__ jc,
                                                            const IR* __restrict__ ir,
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(256) void k_accumulate_sorted(const long long* __re
                                                            const int* __restrict__ perm,
                                                            const long long* __restrict__ offs,
                                                            const int4* __restrict__ items,
-                                                           const int* __restrict__ nitems, int p,
+                                                           const int* __restrict__ nitems, int p, int fixed_s,
                                                            double* __restrict__ sums, double* __restrict__ counts)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,13 +245,47 @@ __global__ __launch_bounds__(256) void k_accumulate_sorted(const long long* __re
         const int len = it.z;
         for (int r = tid; r < p; r += blockDim.x) { ssum[r] = 0.0; scnt[r] = 0u; }
         __syncthreads();
-        for (int q = wave; q < len; q += nwaves) {
-            const long long i = perm[start + q];
-            const long long j0 = jc[i], j1 = jc[i + 1];
-            for (long long j = j0 + lane; j < j1; j += 64) {
-                const int r = (int)ir[j];
-                unsafeAtomicAdd(&ssum[r], x[j]);
-                atomicAdd(&scnt[r], 1u);
+        for (int qb = wave * 64; qb < len; qb += nwaves * 64) {
+            const int have = (len - qb < 64) ? len - qb : 64;
+            long long my_j0 = 0;
+            int my_cnt = 0;
+            if (lane < have) {
+                const long long i = perm[start + qb + lane];
+                if (fixed_s > 0) { my_j0 = i * fixed_s; my_cnt = fixed_s; }
+                else { my_j0 = jc[i]; my_cnt = (int)(jc[i + 1] - my_j0); }
+            }
+            for (int u = 0; u < have; u += 4) {
+                long long j0[4];
+                int cn[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int src = (u + v < have) ? u + v : u; // clamp: duplicates are masked by cn = 0
+                    const int lo = __builtin_amdgcn_readlane((int)my_j0, src);
+                    const int hi = __builtin_amdgcn_readlane((int)(my_j0 >> 32), src);
+                    j0[v] = ((long long)hi << 32) | (unsigned)lo;
+                    cn[v] = (u + v < have) ? __builtin_amdgcn_readlane(my_cnt, src) : 0;
+                }
+                double xv[4];
+                int rv[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const bool ok = lane < cn[v];
+                    xv[v] = ok ? x[j0[v] + lane] : 0.0;
+                    rv[v] = ok ? (int)ir[j0[v] + lane] : -1;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    if (rv[v] >= 0) {
+                        unsafeAtomicAdd(&ssum[rv[v]], xv[v]);
+                        atomicAdd(&scnt[rv[v]], 1u);
+                    }
+                    // columns longer than one wave: the rest, 64 entries at a time
+                    for (long long j = j0[v] + 64 + lane; j < j0[v] + cn[v]; j += 64) {
+                        const int r = (int)ir[j];
+                        unsafeAtomicAdd(&ssum[r], x[j]);
+                        atomicAdd(&scnt[r], 1u);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -284,6 +351,6 @@ template __global__ void k_accumulate_atomic<unsigned short>(const long long*, c
 template __global__ void k_accumulate_atomic<unsigned int>(const long long*, const unsigned int*, const double*,
     const int*, int, long long, double*, double*);
 template __global__ void k_accumulate_sorted<unsigned short>(const long long*, const unsigned short*, const double*,
-    const int*, const long long*, const int4*, const int*, int, double*, double*);
+    const int*, const long long*, const int4*, const int*, int, int, double*, double*);
 template __global__ void k_accumulate_sorted<unsigned int>(const long long*, const unsigned int*, const double*,
-    const int*, const long long*, const int4*, const int*, int, double*, double*);
+    const int*, const long long*, const int4*, const int*, int, int, double*, double*);
