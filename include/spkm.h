@@ -135,6 +135,19 @@ int spkm_assign_sparse_centers_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t 
 int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const int32_t *d_assign,
                         double *d_reduce);
 
+/* spkm_assign_dev + spkm_accumulate_dev in one call -- the front half of a Lloyd iteration, up to the
+ * all-reduce.  Same outputs, bit for bit.  For K > 16 on a fixed-stride shard the library may run its
+ * fast path: a certified f32 screen over all centroids, exact reference arithmetic for every point the
+ * screen cannot certify, and the exact distance of every point to its assigned centroid fused into the
+ * accumulation pass (csrc/screen.hip).  Nothing computed in f32 reaches an output.  The environment
+ * variable SPKM_NO_SCREEN=1 forces the all-exact kernels. */
+int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers,
+                               double gamma, int32_t *d_assign, double *d_mind, double *d_stats,
+                               uint64_t *d_nk_u64, double *d_reduce);
+/* info[0] = path taken by the last spkm_assign_accumulate_dev (0 = exact tiles, 1 = screen + exact
+ * confirmation), info[1] = points the screen could not certify.  Blocks on the stream. */
+int spkm_last_path_info(spkm_ctx *ctx, int64_t info[2]);
+
 /* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
  * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;
  * d_out double[2] (device) = { ||old-new||_F^2, obj2 } (kmeans_sparsified.m:470-471 before sqrt). */

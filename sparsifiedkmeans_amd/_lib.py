@@ -97,6 +97,8 @@ def lib():
     L.spkm_assign_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp, _vp, _vp]
     L.spkm_assign_sparse_centers_dev.argtypes = [_vp, _vp, _u64, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]
     L.spkm_accumulate_dev.argtypes = [_vp, _vp, _u64, _vp, _vp]
+    L.spkm_assign_accumulate_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]
+    L.spkm_last_path_info.argtypes = [_vp, C.POINTER(C.c_int64)]
     L.spkm_finalize_dev.argtypes = [_vp, _u64, _u64, _vp, _dbl, _vp, _vp]
     L.spkm_fwht_dev.argtypes = [_vp, _u64, _u64, _vp, _vp]
     L.spkm_mix_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _dbl, _dbl, _vp]

@@ -4,12 +4,14 @@
 #include "fwht.hip"
 #include "sparse_ops.hip"
 #include "update.hip"
+#include "screen.hip"
 
 #include "../../include/spkm.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -29,7 +31,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -39,6 +41,8 @@ struct spkm_ctx {
     size_t tlog_used = 0;
     bool tlog_on = false;
     int assign_KT = 0, assign_G = 0; // of the last assign call
+    int last_path = 0;               // 0 = exact tiled/generic, 1 = f32 screen + exact confirmation
+    unsigned last_listed = 0;        // points sent to the exact list by the last screen (read lazily)
     char errmsg[256] = {0};
 };
 
@@ -52,6 +56,8 @@ struct spkm_shard {
     bool owned = false;
     int fixed_s = 0;   // > 0: every column has exactly this many entries
     uint64_t slack = 0; // entries readable past nnz in ir / x
+    double* xn1 = nullptr; // per-point sum |x| and sum x^2 (screen error bound), built on first use
+    double* xn2 = nullptr;
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -136,7 +142,8 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
-                     &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg};
+                     &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -271,8 +278,10 @@ extern "C" int spkm_shard_create_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint
 extern "C" void spkm_shard_destroy(spkm_shard* s)
 {
     if (!s) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->xn1) (void)hipFree(s->xn1);
+    if (s->xn2) (void)hipFree(s->xn2);
     if (s->owned) {
-        if (s->ctx) (void)hipSetDevice(s->ctx->device);
         if (s->jc) (void)hipFree(s->jc);
         if (s->ir) (void)hipFree(s->ir);
         if (s->x) (void)hipFree(s->x);
@@ -658,6 +667,172 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
                        (const unsigned long long*)ctx->nk.p, K, nk_f);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(obj2, ctx->stats.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused iteration front half: assignment + accumulation (everything before the all-reduce)
+// ------------------------------------------------------------------------------------------
+static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
+{
+    if (getenv("SPKM_NO_SCREEN")) return false;
+    if (s->fixed_s <= 0 || s->slack < 16 || s->nnz == 0) return false;
+    if (K <= 16) return false; // a single exact tile already streams X once
+    if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
+    const int G = (K + SCREEN_KT - 1) / SCREEN_KT;
+    const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    if (G > nb) return false;
+    // phase 2 needs the centroid column + slab + at least 8 staged points per wave
+    const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
+    if (s->p * 20 + 64 + 8 * 8 * per_pt > ctx->lds_max) return false;
+    return true;
+}
+
+template <typename IR>
+static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d_centers, double gamma,
+                      int32_t* d_assign, double* d_mind, double* d_reduce)
+{
+    const int p = (int)s->p;
+    const long long n = (long long)s->n;
+    const int G = (K + SCREEN_KT - 1) / SCREEN_KT;
+    const size_t pk = (size_t)p * K;
+    double* sums = d_reduce;
+    double* counts = d_reduce + pk;
+    double* nk_f = d_reduce + 2 * pk;
+    double* obj2 = nk_f + K;
+    int rc;
+    spkm_shard* sm = const_cast<spkm_shard*>(s);
+    if (!sm->xn1) {
+        HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
+        HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
+        hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0,
+                           ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2);
+    }
+    if ((rc = build_blockmap(ctx, G))) return rc;
+    const size_t tile_floats = (size_t)G * (p + 1) * SCREEN_KT;
+    if ((rc = ensure(ctx, ctx->t32, tile_floats * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cmax, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->scr_m1, (size_t)G * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->scr_m2, (size_t)G * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->scr_k, (size_t)G * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->list, (size_t)n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->nlist, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->ct, pk * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
+                       0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
+                       (unsigned long long*)ctx->cmax.p);
+    hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0,
+                       ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
+    // 1. screen
+    const int sweep = 16 * 8;
+    long long chunk = n / ((long long)ctx->bmap_streams * 8);
+    chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
+    chunk = (chunk / sweep) * sweep;
+    const size_t lds = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
+    auto kern = k_screen_tile<IR>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(timing_begin(ctx));
+    hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const IR*)s->ir,
+                       (const double*)s->x, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K,
+                       (const spkm_blockmap*)ctx->bmap.p, (int)chunk, (float*)ctx->scr_m1.p, (float*)ctx->scr_m2.p,
+                       (int*)ctx->scr_k.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(timing_end(ctx));
+    // 2. certification, 3. exact evaluation of the uncertified points
+    const int cb = (int)std::min<long long>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), 0, ctx->stream, (const float*)ctx->scr_m1.p,
+                       (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, G, (const double*)s->xn1,
+                       (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
+                       (int*)ctx->list.p, (unsigned int*)ctx->nlist.p);
+    hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
+                       (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
+                       s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign);
+    // 4. counting sort by cluster
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
+                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p);
+    const int max_items = (int)(n / SEG_POINTS) + K + 1;
+    if ((rc = ensure(ctx, ctx->perm, (size_t)n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->offs, (size_t)(K + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
+    hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
+                       SEG_POINTS, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                       (int*)ctx->nitems.p);
+    const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
+    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+    hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
+                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
+    // 5. exact distance to the assigned centroid + per-cluster accumulation
+    const int threads = 512, nw = threads / 64;
+    const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
+    const size_t fixed_lds = (size_t)p * 20 + 16;
+    int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 64) / nw / per_pt);
+    pts = std::max(8, pts & ~7);
+    const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
+    auto k2 = k_exact_accumulate<IR>;
+    HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 2);
+    if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;
+    hipLaunchKernelGGL(k2, dim3(ab), dim3(threads), lds2, ctx->stream, (const IR*)s->ir, (const double*)s->x,
+                       (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
+                       (const int*)ctx->nitems.p, d_centers, gamma, p, s->fixed_s, pts, d_mind, sums, counts,
+                       (double*)ctx->blk_obj.p, (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
+                       (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, ab, (double*)ctx->stats.p);
+    hipLaunchKernelGGL(k_nk_to_f64, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ctx->nk.p, K, nk_f);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(obj2, ctx->stats.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->last_path = 1;
+    return SPKM_OK;
+}
+
+extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const double* d_centers,
+                                          double gamma, int32_t* d_assign, double* d_mind, double* d_stats,
+                                          uint64_t* d_nk_u64, double* d_reduce)
+{
+    if (!ctx || !s || !d_centers || !d_assign || !d_mind || !d_reduce) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    if (s->n > 0 && screen_eligible(ctx, s, (int)K64)) {
+        ctx->ev_valid = false;
+        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce)
+                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce);
+        if (rc) return rc;
+        if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return SPKM_OK;
+    }
+    ctx->last_path = 0;
+    rc = spkm_assign_dev(ctx, s, K64, d_centers, gamma, d_assign, d_mind, d_stats, d_nk_u64);
+    if (rc) return rc;
+    return spkm_accumulate_dev(ctx, s, K64, d_assign, d_reduce);
+}
+
+// [0] = path of the last spkm_assign_accumulate_dev (0 exact tiles, 1 f32 screen + exact confirmation),
+// [1] = number of points the screen could not certify (evaluated exactly over all K).  Blocks on the stream.
+extern "C" int spkm_last_path_info(spkm_ctx* ctx, int64_t info[2])
+{
+    if (!ctx || !info) return SPKM_ERR_NULL_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    info[0] = ctx->last_path;
+    info[1] = 0;
+    if (ctx->last_path == 1 && ctx->nlist.p) {
+        unsigned v = 0;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(&v, ctx->nlist.p, 4, hipMemcpyDeviceToHost));
+        info[1] = v;
+    }
     return SPKM_OK;
 }
 

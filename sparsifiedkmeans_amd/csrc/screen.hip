@@ -1,0 +1,499 @@
+// Certified f32 screen + exact f64 confirmation: the fast path of the fused Lloyd iteration
+// for K > 16 (gfx950).  RESULTS ARE IDENTICAL to the exact kernel of assign.hip -- assignments
+// bit-for-bit, min-distances bit-for-bit -- because nothing computed in f32 is ever output:
+//
+//   1. k_screen_tile     for every point and centroid, an f32 estimate of the squared distance
+//                        (2 centroids per lane, 32 per DPP row: twice the rate of the f64 chain);
+//                        per (point, tile): smallest estimate, its centroid, second smallest.
+//   2. k_combine_screen  best / second-best over the tiles and a RIGOROUS bound on
+//                        |sqrt(estimate) - true distance| (below).  If best + bound < second - bound
+//                        the reference's argmin is certified (uniquely: no tie can occur inside the
+//                        gap); otherwise the point is appended to a list.
+//   3. k_assign_list     listed points: exact reference arithmetic over all K centroids
+//                        (SparseMatrixMinusCluster.c:173-180 + first-index min).
+//   4. k_exact_accumulate  (after the counting sort by cluster) per point, the distance to ITS centroid
+//                        in exact reference arithmetic -- the value the reference's min() returns --
+//                        fused with the per-cluster sum / count accumulation that reads the same entries.
+//
+// Error bound (u = 2^-24).  Reference value for centroid k: dist_k = fl64(sqrt(sum_j fl64((x_j-c_jk)^2))), c = C/gamma
+// in f64; true distance D_k = ||x - c_k|| over the point's support.  The screen uses x~ = fl32(x),
+// c~ = fl32(c), t~_j = fl32(x~_j - c~_jk):  |t~_j - (x_j - c_jk)| <= (2u+u^2)(|x_j|+|c_jk|) =: e_j, so by the
+// triangle inequality | ||t~|| - D_k | <= E := sqrt(sum e_j^2) <= (2u+u^2) sqrt(W),
+// W = sum_j (|x_j| + Cmax)^2 = xn2 + 2 Cmax xn1 + s Cmax^2  (per-point norms xn1, xn2 precomputed).
+// The f32 FMA accumulation of s terms gives a~ in ||t~||^2 (1 +- g), g = (s+1)u(1+1e-4), hence
+// |sqrt(a~) - ||t~||| <= g sqrt(a~).  Together |sqrt(a~_k) - D_k| <= eps_k := E + g sqrt(a~_k) + 1e-20
+// (the last term covers f32 subnormal products).  dist_k itself is within D_k (1 +- 2^-45).
+// Certified iff (r1 + eps_1)(1+2^-45) < (r2 - eps_2)(1-2^-45) with r = sqrt(a~) of the best and second best:
+// every other centroid has r_k >= r2 and r_k - eps_k is increasing in r_k, so dist_1 < dist_k for all k.
+// Overflow makes a~ = inf and fails the test (-> list).  Empty / duplicate columns fail it (-> list).
+#include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#define SCREEN_KT 32 // centroids per tile (two per lane of a 16-lane row)
+
+// T32[g][r][kk] = -fl32(C[(g*32+kk)*p + r] / gamma), row p zero; cmax_bits = max |C/gamma| (f64 bits, atomicMax)
+__global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
+                                 float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits)
+{
+    const size_t total = (size_t)G * (p + 1) * SCREEN_KT;
+    double mx = 0.0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(t % SCREEN_KT);
+        const size_t rest = t / SCREEN_KT;
+        const int r = (int)(rest % (p + 1));
+        const int g = (int)(rest / (p + 1));
+        const int k = g * SCREEN_KT + kk;
+        float v = 0.f;
+        if (r < p && k < K) {
+            double c = C[(size_t)k * p + r];
+            if (gamma > 0.0) c = c / gamma;
+            mx = fmax(mx, fabs(c));
+            v = -(float)c;
+        }
+        T32[t] = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(cmax_bits, __builtin_bit_cast(unsigned long long, mx));
+}
+
+// xn1[i] = sum_j |x_j|, xn2[i] = sum_j x_j^2 over column i (any order: used only inside an upper bound).
+// 16 lanes per point so that the loads of a wave cover four contiguous columns.
+__global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict__ jc, const double* __restrict__ x,
+                                                     long long n, int fixed_s, double* __restrict__ xn1,
+                                                     double* __restrict__ xn2)
+{
+    const int sub = threadIdx.x & 15;
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    const long long rounds = (n + ng - 1) / ng;
+    for (long long t = 0; t < rounds; t++) {
+        const long long i = g0 + t * ng;
+        double a = 0.0, b = 0.0;
+        if (i < n) {
+            const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
+            const long long j1 = fixed_s > 0 ? j0 + fixed_s : jc[i + 1];
+            for (long long j = j0 + sub; j < j1; j += 16) { const double v = x[j]; a += fabs(v); b += v * v; }
+        }
+        for (int off = 8; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        if (i < n && sub == 0) { xn1[i] = a; xn2[i] = b; }
+    }
+}
+
+template <int N, int IRB>
+struct RunScreenP {
+    static __device__ __forceinline__ void run(int nb, int koff, int roffA, double xA, int roffB, double xB,
+                                               double& accA, double& accB, const void* xbase, const void* rbase,
+                                               unsigned voxA, unsigned voxB, unsigned vorA, unsigned vorB,
+                                               double& xAn, double& xBn, int& rAn, int& rBn)
+    {
+        if (nb == N)
+            screen2p<N, IRB>(koff, roffA, xA, roffB, xB, accA, accB, xbase, rbase, voxA, voxB, vorA, vorB, xAn, xBn,
+                             rAn, rBn);
+        else
+            RunScreenP<N - 1, IRB>::run(nb, koff, roffA, xA, roffB, xB, accA, accB, xbase, rbase, voxA, voxB, vorA,
+                                        vorB, xAn, xBn, rAn, rBn);
+    }
+};
+template <int IRB>
+struct RunScreenP<0, IRB> {
+    static __device__ __forceinline__ void run(int, int, int, double, int, double, double&, double&, const void*,
+                                               const void*, unsigned, unsigned, unsigned, unsigned, double&, double&,
+                                               int&, int&) {}
+};
+
+__device__ __forceinline__ float dpp_f32(float v, int sel)
+{
+    const int b = __builtin_bit_cast(int, v);
+    int r;
+    switch (sel) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, false); break;  // quad_perm [1,0,3,2]
+    case 1: r = __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, false); break;  // quad_perm [2,3,0,1]
+    case 2: r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xf, 0xf, false); break; // row_half_mirror
+    default: r = __builtin_amdgcn_update_dpp(0, b, 0x140, 0xf, 0xf, false); break; // row_mirror
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+// (x, x) as one 64-bit register for v_pk_add_f32
+__device__ __forceinline__ double pack_xx(double x)
+{
+    const unsigned b = __builtin_bit_cast(unsigned, (float)x);
+    return __builtin_bit_cast(double, ((unsigned long long)b << 32) | b);
+}
+
+// smallest / second smallest of the 32 estimates of one point (16 lanes x 2) and the centroid of the smallest
+__device__ __forceinline__ void store_screen_winner(double acc2, int slot, int kk, int kbase, int K, int i, bool valid,
+                                                    float* __restrict__ m1o, float* __restrict__ m2o,
+                                                    int* __restrict__ ko)
+{
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, acc2);
+    float a0 = __builtin_bit_cast(float, (unsigned)bits), a1 = __builtin_bit_cast(float, (unsigned)(bits >> 32));
+    const int k0 = kbase + 2 * kk;
+    if (k0 >= K) a0 = __builtin_inff();
+    if (k0 + 1 >= K) a1 = __builtin_inff();
+    const float lo = fminf(a0, a1), hi = fmaxf(a0, a1);
+    float m1 = lo;
+#pragma unroll
+    for (int st = 0; st < 4; st++) m1 = fminf(m1, dpp_f32(m1, st));
+    const bool mine = (lo == m1);
+    const unsigned long long seg = (__ballot(mine) >> (slot * 16)) & 0xffffull;
+    const int first = __builtin_ctzll(seg | (1ull << 63));
+    const bool none = seg == 0ull; // NaN estimates are never equal to anything: report "no candidate"
+    // second smallest: the winning lane contributes its OTHER value, every other lane its smaller one
+    float m2 = (kk == first) ? hi : lo;
+#pragma unroll
+    for (int st = 0; st < 4; st++) m2 = fminf(m2, dpp_f32(m2, st));
+    if ((none ? kk == 0 : kk == first) && valid) {
+        m1o[i] = none ? __builtin_inff() : m1;
+        m2o[i] = none ? __builtin_inff() : m2;
+        ko[i] = none ? -1 : ((a0 == m1) ? k0 : k0 + 1);
+    }
+}
+
+// The f32 screen over one 32-centroid tile.  Same geometry as k_assign_tile<16,.,FIXED=true>
+// (workgroup = one tile in LDS, waves draw pairs of 4-point groups from an LDS ticket), fixed-stride
+// shards only.  T32 tile: (p+1) rows of 32 floats = the same 128 B per row as the f64 tile.
+template <typename IR>
+__global__ __launch_bounds__(1024) void k_screen_tile(
+    const IR* __restrict__ ir, const double* __restrict__ xval, const float* __restrict__ T32, int p, int n,
+    int fixed_s, int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
+    float* __restrict__ scr_m2, int* __restrict__ scr_k)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const spkm_blockmap bm = bmap[blockIdx.x];
+    if (bm.tile < 0) return;
+    const int g = bm.tile;
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const size_t tile_bytes = (size_t)(p + 1) * SCREEN_KT * 4;
+    {
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T32) + (size_t)g * tile_bytes);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (size_t t = tid; t < tile_bytes / 16; t += nthreads) dst[t] = src[t];
+        if (tid == 0) *reinterpret_cast<unsigned*>(smem + tile_bytes) = 0u;
+    }
+    __syncthreads();
+
+    constexpr int PPW = 4, PPS = 8, IRB = (int)sizeof(IR);
+    const int lane = tid & 63;
+    const int nwaves = nthreads >> 6;
+    (void)nwaves;
+    const int slot = lane >> 4;
+    const int kk = lane & 15;
+    const int koff = kk * 8;
+    const int jl = kk;
+    const int nchunks = (n + chunk_points - 1) / chunk_points;
+    float* m1o = scr_m1 + (size_t)g * n;
+    float* m2o = scr_m2 + (size_t)g * n;
+    int* ko = scr_k + (size_t)g * n;
+
+    const int R = chunk_points / PPS;
+    const int my_chunks = (nchunks > bm.stream) ? (nchunks - bm.stream + bm.nstreams - 1) / bm.nstreams : 0;
+    const int T = my_chunks * R;
+    const int nbatches = (fixed_s + 15) >> 4;
+    const int tail = fixed_s - 16 * (nbatches - 1);
+    unsigned* ticket = reinterpret_cast<unsigned*>(smem + tile_bytes);
+    auto draw = [&]() {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(ticket, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto base_of = [&](int u) {
+        const int ci = u / R, r = u - ci * R;
+        return (bm.stream + ci * bm.nstreams) * chunk_points + r * PPS;
+    };
+    auto lane_offs = [&](int base, unsigned& voxA, unsigned& voxB, unsigned& vorA, unsigned& vorB) {
+        const int iA = base + slot, iB = base + PPW + slot;
+        const int cA = iA < n ? iA : n - 1, cB = iB < n ? iB : n - 1;
+        const unsigned eA = (unsigned)(cA - base) * (unsigned)fixed_s + (unsigned)jl;
+        const unsigned eB = (unsigned)(cB - base) * (unsigned)fixed_s + (unsigned)jl;
+        voxA = eA * 8u; voxB = eB * 8u;
+        vorA = eA * (unsigned)IRB; vorB = eB * (unsigned)IRB;
+    };
+    int t = draw();
+    int tn = draw();
+    int base = (t < T) ? base_of(t) : n;
+    if (base < n && base >= 0) {
+        unsigned voxA, voxB, vorA, vorB;
+        lane_offs(base, voxA, voxB, vorA, vorB);
+        const char* xb = reinterpret_cast<const char*>(xval + (size_t)base * (size_t)fixed_s);
+        const char* rb = reinterpret_cast<const char*>(ir + (size_t)base * (size_t)fixed_s);
+        double xA = *reinterpret_cast<const double*>(xb + voxA), xB = *reinterpret_cast<const double*>(xb + voxB);
+        int rA = (int)*reinterpret_cast<const IR*>(rb + vorA), rB = (int)*reinterpret_cast<const IR*>(rb + vorB);
+        while (true) {
+            int nbase = (tn < T) ? base_of(tn) : n;
+            const bool more = (nbase < n) && (nbase >= 0);
+            if (!more) nbase = base;
+            unsigned nvoxA, nvoxB, nvorA, nvorB;
+            lane_offs(nbase, nvoxA, nvoxB, nvorA, nvorB);
+            const char* nxb = reinterpret_cast<const char*>(xval + (size_t)nbase * (size_t)fixed_s);
+            const char* nrb = reinterpret_cast<const char*>(ir + (size_t)nbase * (size_t)fixed_s);
+            double accA = 0.0, accB = 0.0; // two +0.0f each
+            double xAn, xBn;
+            int rAn, rBn;
+            for (int b = 0; b + 1 < nbatches; b++) {
+                xb += 16 * 8;
+                rb += 16 * IRB;
+                screen2p<16, IRB>(koff, rA * 128, pack_xx(xA), rB * 128, pack_xx(xB), accA, accB, xb, rb, voxA, voxB,
+                                  vorA, vorB, xAn, xBn, rAn, rBn);
+                xA = xAn; xB = xBn; rA = rAn; rB = rBn;
+            }
+            if (tail == 16)
+                screen2p<16, IRB>(koff, rA * 128, pack_xx(xA), rB * 128, pack_xx(xB), accA, accB, nxb, nrb, nvoxA,
+                                  nvoxB, nvorA, nvorB, xAn, xBn, rAn, rBn);
+            else
+                RunScreenP<15, IRB>::run(tail, koff, rA * 128, pack_xx(xA), rB * 128, pack_xx(xB), accA, accB, nxb,
+                                         nrb, nvoxA, nvoxB, nvorA, nvorB, xAn, xBn, rAn, rBn);
+            xA = xAn; xB = xBn; rA = rAn; rB = rBn;
+
+            const int iA = base + slot, iB = base + PPW + slot;
+            store_screen_winner(accA, slot, kk, g * SCREEN_KT, K, iA, iA < n, m1o, m2o, ko);
+            store_screen_winner(accB, slot, kk, g * SCREEN_KT, K, iB, iB < n, m1o, m2o, ko);
+            if (!more) break;
+            t = tn;
+            tn = draw();
+            base = nbase;
+            voxA = nvoxA; voxB = nvoxB; vorA = nvorA; vorB = nvorB;
+            xb = nxb; rb = nrb;
+        }
+    }
+}
+
+// Per point: best / second-best estimate over the G tiles, certification, candidate assignment.
+// Uncertified points are appended to list[] (count in *nlist); a tile that reports "no candidate"
+// (+inf, +inf, -1) can never certify.
+__global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict__ scr_m1,
+                                                        const float* __restrict__ scr_m2,
+                                                        const int* __restrict__ scr_k, long long n, int G,
+                                                        const double* __restrict__ xn1,
+                                                        const double* __restrict__ xn2, int fixed_s,
+                                                        const unsigned long long* __restrict__ cmax_bits,
+                                                        int* __restrict__ assign, int* __restrict__ list,
+                                                        unsigned int* __restrict__ nlist)
+{
+    const double cmax = __builtin_bit_cast(double, *cmax_bits);
+    const double u = 0x1p-24;
+    const double eu = (2.0 * u + u * u) * (1.0 + 1e-9);
+    const double gacc = (double)(fixed_s + 1) * u * (1.0 + 1e-4);
+    const double nu = 0x1p-45;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float b1 = __builtin_inff(), b2 = __builtin_inff();
+        int bk = -1;
+        for (int g = 0; g < G; g++) {
+            const float m1 = scr_m1[(size_t)g * n + i], m2 = scr_m2[(size_t)g * n + i];
+            const int k = scr_k[(size_t)g * n + i];
+            if (m1 < b1) { b2 = fminf(b1, m2); b1 = m1; bk = k; }
+            else { b2 = fminf(b2, m1); }
+        }
+        const double W = (xn2[i] + 2.0 * cmax * xn1[i] + (double)fixed_s * cmax * cmax) * (1.0 + 1e-9);
+        const double E = eu * sqrt(W) * (1.0 + 1e-9);
+        const double r1 = sqrt((double)b1), r2 = sqrt((double)b2);
+        const double e1 = E + gacc * r1 + 1e-20, e2 = E + gacc * r2 + 1e-20;
+        const bool certified = (bk >= 0) && ((r1 + e1) * (1.0 + nu) < (r2 - e2) * (1.0 - nu));
+        assign[i] = bk >= 0 ? bk : 0;
+        if (!certified) {
+            const unsigned at = atomicAdd(nlist, 1u);
+            list[at] = (int)i;
+        }
+    }
+}
+
+// Listed points: exact reference arithmetic over all K centroids (row-major scaled centres Cs in
+// global memory), sqrt, first-index min.  One wave per point.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict__ jc, const IR* __restrict__ ir,
+                                                     const double* __restrict__ xval, const double* __restrict__ Cs,
+                                                     int K, int fixed_s, const int* __restrict__ list,
+                                                     const unsigned int* __restrict__ nlist,
+                                                     int* __restrict__ assign)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long cnt = *nlist;
+    for (long long q = wave; q < cnt; q += nwaves) {
+        const long long i = list[q];
+        const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
+        const long long j1 = fixed_s > 0 ? j0 + fixed_s : jc[i + 1];
+        double best = __builtin_inf();
+        int bk = 0x7fffffff;
+        for (int k = lane; k < K; k += 64) {
+            double acc = 0.0;
+            for (long long j = j0; j < j1; j++) {
+                const double d = xval[j] - Cs[(size_t)ir[j] * K + k];
+                acc = acc + d * d;
+            }
+            const double dd = sqrt(acc);
+            if (dd < best) { best = dd; bk = k; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int ok = __shfl_xor(bk, off);
+            if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+        }
+        if (lane == 0) assign[i] = bk;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hist(const int* __restrict__ assign, long long n, int K,
+                                              unsigned long long* __restrict__ nk)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        atomicAdd(&hist[assign[i]], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+        if (hist[k]) atomicAdd(&nk[k], (unsigned long long)hist[k]);
+}
+
+// Phase 2: per (cluster k, segment) work item -- the segment's points are all assigned to k.
+//  (a) lanes <-> entries (coalesced): m_j = RN(RN(x_j - c_k[r_j])^2) against the f64 column -c_k/gamma held in
+//      LDS -- the reference's separately rounded subtract and multiply -- is staged in LDS, and the
+//      per-cluster sums / counts are updated with LDS atomics (as k_accumulate_sorted does);
+//  (b) lane q then adds point q's staged m_j IN STORAGE ORDER (the reference's accumulation order):
+//      mind[i] = sqrt(acc) is exactly the value the reference's min() returns for this point.
+// LDS: negc f64[p] | ssum f64[p] | scnt u32[p] | per wave: ms f64[PTS*S1]   (S1 = s|1: odd stride, conflict-free)
+// Also per-block partial statistics: sum mind^2, max mind and its first index.
+template <typename IR>
+__global__ __launch_bounds__(512) void k_exact_accumulate(const IR* __restrict__ ir, const double* __restrict__ x,
+                                                          const int* __restrict__ perm,
+                                                          const long long* __restrict__ offs,
+                                                          const int4* __restrict__ items,
+                                                          const int* __restrict__ nitems,
+                                                          const double* __restrict__ C, double gamma, int p,
+                                                          int fixed_s, int pts, double* __restrict__ mind,
+                                                          double* __restrict__ sums, double* __restrict__ counts,
+                                                          double* __restrict__ blk_obj2,
+                                                          double* __restrict__ blk_max,
+                                                          long long* __restrict__ blk_imax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* negc = reinterpret_cast<double*>(smem);
+    double* ssum = negc + p;
+    unsigned int* scnt = reinterpret_cast<unsigned int*>(ssum + p);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int S1 = fixed_s | 1;
+    char* wbase = smem + (size_t)p * 20 + (size_t)((p & 1) ? 4 : 0);
+    double* ms = reinterpret_cast<double*>(wbase) + (size_t)wave * pts * S1;
+    __shared__ double s_obj[8], s_max[8];
+    __shared__ long long s_imax[8];
+
+    double obj2 = 0.0, dmax = -1.0;
+    long long imax = 0x7fffffffffffffffLL;
+    for (int item = blockIdx.x; item < *nitems; item += gridDim.x) {
+        const int4 it = items[item];
+        const int k = it.x;
+        const long long start = offs[k] + it.y;
+        const int len = it.z;
+        for (int r = tid; r < p; r += blockDim.x) {
+            double c = C[(size_t)k * p + r];
+            if (gamma > 0.0) c = c / gamma;
+            negc[r] = -c;
+            ssum[r] = 0.0;
+            scnt[r] = 0u;
+        }
+        __syncthreads();
+        for (int qb = wave * pts; qb < len; qb += nwaves * pts) {
+            const int have = (len - qb < pts) ? len - qb : pts;
+            long long my_i = 0;
+            if (lane < have) my_i = perm[start + qb + lane];
+            // (a) eight points' loads in flight per lane
+            for (int u = 0; u < have; u += 8) {
+                double xv[8];
+                int rv[8];
+#pragma unroll
+                for (int v = 0; v < 8; v++) {
+                    const int src = (u + v < have) ? u + v : u;
+                    const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, src);
+                    const bool ok = (u + v < have) && lane < fixed_s;
+                    const long long j = i * fixed_s + lane;
+                    xv[v] = ok ? x[j] : 0.0;
+                    rv[v] = ok ? (int)ir[j] : -1;
+                }
+#pragma unroll
+                for (int v = 0; v < 8; v++) {
+                    if (rv[v] >= 0) {
+                        const double d = xv[v] + negc[rv[v]]; // RN(x - c): the reference's subtraction
+                        ms[(size_t)(u + v) * S1 + lane] = d * d;
+                        unsafeAtomicAdd(&ssum[rv[v]], xv[v]);
+                        atomicAdd(&scnt[rv[v]], 1u);
+                    }
+                    if (fixed_s > 64 && u + v < have) { // columns longer than one wave
+                        const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, u + v);
+                        for (int e = 64 + lane; e < fixed_s; e += 64) {
+                            const double xe = x[i * fixed_s + e];
+                            const int re = (int)ir[i * fixed_s + e];
+                            const double d = xe + negc[re];
+                            ms[(size_t)(u + v) * S1 + e] = d * d;
+                            unsafeAtomicAdd(&ssum[re], xe);
+                            atomicAdd(&scnt[re], 1u);
+                        }
+                    }
+                }
+            }
+            // (b) one lane per point, squared terms added in storage order (wave-synchronous: the
+            // staged data was written by this wave; LDS ops of a wave complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < have) {
+                double acc = 0.0;
+                const double* mq = ms + (size_t)lane * S1;
+                for (int j = 0; j < fixed_s; j++) acc = acc + mq[j];
+                const double dist = sqrt(acc);
+                mind[my_i] = dist;
+                obj2 += dist * dist;
+                if (dist > dmax || (dist == dmax && my_i < imax)) { dmax = dist; imax = my_i; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        for (int r = tid; r < p; r += blockDim.x) {
+            const unsigned int c = scnt[r];
+            if (c) {
+                unsafeAtomicAdd(&sums[(size_t)k * p + r], ssum[r]);
+                unsafeAtomicAdd(&counts[(size_t)k * p + r], (double)c);
+            }
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        obj2 += __shfl_down(obj2, off);
+        const double om = __shfl_down(dmax, off);
+        const long long oi = __shfl_down(imax, off);
+        if (om > dmax || (om == dmax && oi < imax)) { dmax = om; imax = oi; }
+    }
+    if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, m = -1.0;
+        long long im = 0x7fffffffffffffffLL;
+        for (int w = 0; w < nwaves; w++) {
+            o += s_obj[w];
+            if (s_max[w] > m || (s_max[w] == m && s_imax[w] < im)) { m = s_max[w]; im = s_imax[w]; }
+        }
+        blk_obj2[blockIdx.x] = o;
+        blk_max[blockIdx.x] = m;
+        blk_imax[blockIdx.x] = im;
+    }
+}
+
+template __global__ void k_screen_tile<unsigned short>(const unsigned short*, const double*, const float*, int, int,
+    int, int, const spkm_blockmap*, int, float*, float*, int*);
+template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const double*, const float*, int, int, int,
+    int, const spkm_blockmap*, int, float*, float*, int*);
+template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
+    const double*, int, int, const int*, const unsigned int*, int*);
+template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
+    const double*, int, int, const int*, const unsigned int*, int*);
+template __global__ void k_exact_accumulate<unsigned short>(const unsigned short*, const double*, const int*,
+    const long long*, const int4*, const int*, const double*, double, int, int, int, double*, double*, double*,
+    double*, double*, long long*);
+template __global__ void k_exact_accumulate<unsigned int>(const unsigned int*, const double*, const int*,
+    const long long*, const int4*, const int*, const double*, double, int, int, int, double*, double*, double*,
+    double*, double*, long long*);

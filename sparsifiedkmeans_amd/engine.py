@@ -136,11 +136,24 @@ class LloydEngine:
         _lib.check(_lib.lib().spkm_finalize_dev(self.ctx.handle, self.p, self.K, _p(self.reduce), self.gamma,
                                                 _p(centers), _p(self.out)), "spkm_finalize_dev")
 
+    def assign_accumulate_step(self, centers: torch.Tensor):
+        """assign_step + accumulate_step in one call (same outputs bit for bit; lets the library take its
+        certified-screen fast path when the shard qualifies)."""
+        assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)
+        g = self.gamma if self.unbiased else 0.0
+        _lib.check(_lib.lib().spkm_assign_accumulate_dev(self.ctx.handle, self.shard.handle, self.K, _p(centers), g,
+                                                         _p(self.assign), _p(self.mind), _p(self.stats), _p(self.nk),
+                                                         _p(self.reduce)), "spkm_assign_accumulate_dev")
+
+    def last_path_info(self) -> tuple[int, int]:
+        a = (C.c_int64 * 2)()
+        _lib.check(_lib.lib().spkm_last_path_info(self.ctx.handle, a))
+        return int(a[0]), int(a[1])
+
     def iterate(self, centers: torch.Tensor):
         """One full Lloyd iteration in place on ``centers``; returns the device tensor
         [dff^2, obj^2] (no host sync)."""
-        self.assign_step(centers)
-        self.accumulate_step()
+        self.assign_accumulate_step(centers)
         self.allreduce_step()
         self.finalize_step(centers)
         return self.out

@@ -1,0 +1,117 @@
+"""-m gpu: the certified f32 screen + exact confirmation path (csrc/screen.hip) must give exactly
+what the all-exact kernels and the oracle give: assignments and min distances bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from util import parts, random_csc
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, X, Cm, gamma):
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    K = Cm.shape[1]
+    eng = LloydEngine(Shard.from_scipy(ctx, X), K, gamma)
+    centers = torch.tensor(np.ascontiguousarray(Cm.T), device=f"cuda:{ctx.device}")
+    eng.assign_accumulate_step(centers)
+    torch.cuda.synchronize()
+    path, listed = eng.last_path_info()
+    return eng, path, listed
+
+
+def _check(eng, oracle, X, Cm, gamma):
+    p, n = X.shape
+    K = Cm.shape[1]
+    ra, rd = oracle.assign(p, n, *parts(X), Cm, gamma)
+    a, d = eng.assign.cpu().numpy(), eng.mind.cpu().numpy()
+    assert np.array_equal(a, ra)
+    assert np.array_equal(d, rd)
+    S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), ra)
+    red = eng.reduce.cpu().numpy()
+    pk = p * K
+    assert np.array_equal(red[pk:2 * pk].reshape(K, p).T, Cnt)
+    assert np.array_equal(red[2 * pk:2 * pk + K], nk.astype(float))
+    assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-12 * max(np.abs(S).max(), 1e-300)
+    assert abs(red[-1] - np.sum(rd * rd)) <= 1e-12 * np.sum(rd * rd)
+    st = eng.stats.cpu().numpy()
+    assert st[1] == rd.max() and int(st[2]) == int(np.argmax(rd))
+    assert np.array_equal(eng.nk.cpu().numpy(), nk)
+
+
+@pytest.mark.parametrize("p,n,K,s", [(1024, 20000, 100, 51), (512, 9000, 37, 26), (256, 5001, 17, 13),
+                                     (1024, 3000, 128, 51), (64, 2000, 33, 64)])
+def test_screen_path_equals_oracle(gpu_ctx, oracle, p, n, K, s):
+    X = random_csc(p, n, min(s, p), seed=p + K)           # fixed stride: eligible for the screen
+    Cm = np.random.default_rng(K).standard_normal((p, K)) * 0.2
+    eng, path, listed = _run(gpu_ctx, X, Cm, s / p)
+    assert path == 1, "screen path expected"
+    _check(eng, oracle, X, Cm, s / p)
+    assert listed < 0.05 * n                                # random data: almost everything certifies
+
+
+def test_screen_sends_ties_to_the_exact_list(gpu_ctx, oracle):
+    """Duplicate centroids (exact ties), near-duplicates (sqrt-collapse band) and empty-ish points
+    cannot be certified by any f32 screen: they must take the exact route and still match."""
+    p, n, K = 512, 6000, 40
+    X = random_csc(p, n, 26, seed=77)
+    rng = np.random.default_rng(5)
+    Cm = rng.standard_normal((p, K)) * 0.3
+    Cm[:, 21] = Cm[:, 4]                                    # same value, different screen tiles or same
+    Cm[:, 39] = Cm[:, 4]
+    Cm[:, 9] = np.nextafter(Cm[:, 8], np.inf)               # one ulp apart
+    eng, path, listed = _run(gpu_ctx, X, Cm, 26 / 512)
+    assert path == 1
+    _check(eng, oracle, X, Cm, 26 / 512)
+    a = eng.assign.cpu().numpy()
+    assert not np.any(np.isin(a, [21, 39]))                 # first index wins the exact ties
+    assert listed >= np.count_nonzero(np.isin(a, [4, 8, 9]))
+
+
+def test_screen_with_extreme_magnitudes(gpu_ctx, oracle):
+    """Values far outside f32 range make the estimates overflow: everything goes to the list, the
+    answer stays exact."""
+    p, n, K = 128, 1500, 20
+    X = random_csc(p, n, 9, seed=3)
+    X.data *= 1e30
+    Cm = np.random.default_rng(2).standard_normal((p, K)) * 1e30
+    eng, path, listed = _run(gpu_ctx, X, Cm, 9 / 128)
+    assert path == 1 and listed == n
+    _check(eng, oracle, X, Cm, 9 / 128)
+
+
+def test_exact_path_is_used_when_not_eligible(gpu_ctx, oracle):
+    X = random_csc(512, 4000, 26, seed=9, ragged=True)       # ragged: not fixed-stride
+    Cm = np.random.default_rng(1).standard_normal((512, 30))
+    eng, path, listed = _run(gpu_ctx, X, Cm, 0.05)
+    assert path == 0
+    _check(eng, oracle, X, Cm, 0.05)
+    X2 = random_csc(512, 4000, 26, seed=9)                   # K <= 16: single exact tile
+    eng, path, _ = _run(gpu_ctx, X2, Cm[:, :10], 0.05)
+    assert path == 0
+
+
+def test_full_lloyd_with_screen_matches_oracle_loop(gpu_ctx, oracle):
+    from sparsifiedkmeans_amd import synth
+
+    data = synth.sparsified_gmm_host(p=256, n=6000, K=24, gamma=0.06, seed=11, fwht=oracle.fwht)
+    Y, p2, gamma, K = data["Y"], data["p2"], data["gamma"], 24
+    rng = np.random.default_rng(4)
+    C0 = oracle.mix(data["X"][:, rng.choice(6000, K, replace=False)], data["d"], p2)
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, Y), K, gamma)
+    centers = torch.tensor(np.ascontiguousarray(C0.T), device="cuda:0")
+    Cref = C0.copy()
+    for it in range(5):                                      # teacher-forced
+        centers.copy_(torch.tensor(np.ascontiguousarray(Cref.T)))
+        out = eng.iterate(centers).cpu().numpy()
+        assert eng.last_path_info()[0] == 1
+        ref = oracle.lloyd(p2, Y.shape[1], *parts(Y), Cref, gamma, maxiter=1, tol=0.0)
+        assert np.array_equal(eng.assign.cpu().numpy(), ref["assign"])
+        assert np.array_equal(eng.mind.cpu().numpy(), ref["mind"])
+        got = centers.cpu().numpy().T
+        assert np.abs(got - ref["centers"]).max() <= 1e-6 * np.abs(ref["centers"]).max()
+        assert abs(np.sqrt(out[1]) - ref["obj"][0]) <= 1e-12 * ref["obj"][0]
+        Cref = ref["centers"]

@@ -76,6 +76,26 @@ __global__ __launch_bounds__(1024) void k(double* out, int iters, double seed)
                              "v_mov_b32_dpp %2, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
                              : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(addr));
                 addr ^= (b0 ^ b1 ^ b2 ^ b3) & 0;
+            } else if (MODE == 11) { // f32 screen step, packed: mov_b64_dpp + add_u32_dpp + pk_add_f32 + pk_fma_f32 (x2)
+                int b0, b1;
+                asm volatile("v_mov_b64_dpp %0, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %8, %10, %10 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_pk_add_f32 %1, %1, %11\n v_pk_fma_f32 %2, %2, %11, %2\n"
+                             "v_mov_b64_dpp %3, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %9, %10, %10 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_pk_add_f32 %4, %4, %11\n v_pk_fma_f32 %5, %5, %11, %5"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(b0), "=&v"(b1) : "v"(addr), "v"(one));
+                addr ^= (b0 ^ b1) & 0;
+            } else if (MODE == 12) { // f32 screen step, scalar f32 with DPP operand: add_u32_dpp + 2x v_sub_f32_dpp + 2x v_fmac_f32 (8 instr = 1.6 steps)
+                int b0, b1; float f0 = (float)seed, f1 = f0, f2 = f0, f3 = f0, g = f0;
+                asm volatile("v_add_u32_dpp %0, %6, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %2, %7, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %3, %7, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32 %4, %7, %7\n v_fmac_f32 %5, %7, %7\n"
+                             "v_add_u32_dpp %1, %6, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %2, %7, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %3, %7, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf"
+                             : "=&v"(b0), "=&v"(b1), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(addr), "v"(g));
+                addr ^= (b0 ^ b1) & 0; a0 += f0 + f1 + f2 + f3;
+            } else if (MODE == 13) { // v_pk_fma_f32 x8 independent
+                asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1, %8, %8\n v_pk_fma_f32 %2, %2, %8, %8\n v_pk_fma_f32 %3, %3, %8, %8\n"
+                             "v_pk_fma_f32 %4, %4, %8, %8\n v_pk_fma_f32 %5, %5, %8, %8\n v_pk_fma_f32 %6, %6, %8, %8\n v_pk_fma_f32 %7, %7, %8, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
+            } else if (MODE == 14) { // v_mov_b64_dpp x8
+                asm volatile("v_mov_b64_dpp %0, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %2, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b64_dpp %4, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %5, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %6, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %7, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
             } else if (MODE == 10) { // v_fma_f32 x8 independent
                 float f = (float)seed;
                 asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n"
@@ -129,7 +149,7 @@ int main()
         hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
         printf("s_memtime ticks=%lld  wall_clock64 ticks (100MHz)=%lld -> s_memtime runs at %.1f MHz under f64 load\n", h[0], h[1], h[0] / (h[1] / 100.0));
     }
-    for (int t : {256, 1024}) {
+    for (int t : {1024}) {
         run<0>("v_fma_f64 independent", t, 1);
         run<1>("v_mul_f64/v_add_f64 independent", t, 1);
         run<2>("v_fmac_f64_dpp independent", t, 1);
@@ -141,6 +161,10 @@ int main()
         run<8>("step mix (plain add)", t, 1);
         run<9>("v_mov_b32_dpp", t, 1);
         run<10>("v_fma_f32 dependent chain", t, 1);
+        run<11>("f32 screen step packed (4 instr)", t, 1);
+        run<12>("f32 screen step scalar+dpp (8 instr)", t, 1);
+        run<13>("v_pk_fma_f32 independent", t, 1);
+        run<14>("v_mov_b64_dpp", t, 1);
     }
     return 0;
 }
