@@ -112,6 +112,7 @@ def main():
     k_ms = float(kms.mean()) if kms.size else float("nan")
 
     out = eng.out.cpu().numpy()
+    path, listed = eng.last_path_info()
     nnz_local = int(shard.nnz)
     # algorithmic bytes of one Lloyd iteration over this GPU's points
     b_iter = nnz_local * 12 + (n_local + 1) * 8 + n_local * 12 + 24 * p2 * K
@@ -145,15 +146,19 @@ def main():
                                f"points sharded over {world} GPU(s), dense-centre Lloyd iteration",
                    "n_total": n_total, "n_per_gpu": n_local, "p2": p2, "K": K, "nnz_per_point": s,
                    "gamma": gamma, "parallelism": f"dp{world} (1 RCCL all-reduce/iter)" if world > 1 else "single GPU",
-                   "datagen_s": round(t_gen, 1), "final_obj": float(np.sqrt(out[1]))},
+                   "datagen_s": round(t_gen, 1), "final_obj": float(np.sqrt(out[1])),
+                   "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "
+                                  "bit-identical to the all-exact kernels)" if path == 1 else "exact f64 tiles",
+                   "uncertified_points_last_iter": listed},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "kernel": "k_assign_tile", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_iter,
-                     "note": "at K=100 the kernel is FP64-VALU-issue bound (3 non-fused f64 ops per nonzero per "
-                             "centroid for bit parity), see valu_f64"},
-        "valu_f64": {"achieved_Tops": ops / (k_ms * 1e-3) / 1e12 if k_ms == k_ms else None,
-                     "peak_Tops": FP64_VALU_PEAK_TOPS,
-                     "frac": (ops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS) if k_ms == k_ms else None},
+                     "kernel": "k_screen_tile" if path == 1 else "k_assign_tile", "kernel_ms": k_ms,
+                     "algorithmic_bytes_per_launch": b_iter,
+                     "note": "VALU-issue bound at K=100, not HBM bound: 4 issue slots of 4 cycles per stored entry per "
+                             "32 (screen, f32) or 16 (exact, f64) centroids; see DESIGN.md section 4"},
+        "valu": {"distance_terms_per_s": (nnz_local * K) / (k_ms * 1e-3) if k_ms == k_ms else None,
+                 "exact_f64_op_equivalent_Tops": ops / (k_ms * 1e-3) / 1e12 if k_ms == k_ms else None,
+                 "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS},
         "whole_iter_gbs": b_iter / (elapsed / args.steps) / 1e9,
     }
 

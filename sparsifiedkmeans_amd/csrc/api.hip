@@ -58,6 +58,7 @@ struct spkm_shard {
     uint64_t slack = 0; // entries readable past nnz in ir / x
     double* xn1 = nullptr; // per-point sum |x| and sum x^2 (screen error bound), built on first use
     double* xn2 = nullptr;
+    float* xf = nullptr;   // f32 copy of x for the screen (with the same 16 entries of slack)
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -281,6 +282,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     if (s->xn1) (void)hipFree(s->xn1);
     if (s->xn2) (void)hipFree(s->xn2);
+    if (s->xf) (void)hipFree(s->xf);
     if (s->owned) {
         if (s->jc) (void)hipFree(s->jc);
         if (s->ir) (void)hipFree(s->ir);
@@ -684,7 +686,7 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
     if (G > nb) return false;
     // phase 2 needs the centroid column + slab + at least 8 staged points per wave
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
-    if (s->p * 20 + 64 + 8 * 8 * per_pt > ctx->lds_max) return false;
+    if (s->p * 20 + 64 + 16 * 8 * per_pt > ctx->lds_max) return false;
     return true;
 }
 
@@ -705,8 +707,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (!sm->xn1) {
         HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
         HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
-        hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0,
-                           ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2);
+        HIP_TRY(hipMalloc((void**)&sm->xf, (size_t)(s->nnz + 16) * 4));
+        HIP_TRY(hipMemsetAsync(sm->xf, 0, (size_t)(s->nnz + 16) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256), 0,
+                           ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2,
+                           sm->xf);
     }
     if ((rc = build_blockmap(ctx, G))) return rc;
     const size_t tile_floats = (size_t)G * (p + 1) * SCREEN_KT;
@@ -739,7 +744,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(timing_begin(ctx));
     hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const IR*)s->ir,
-                       (const double*)s->x, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K,
+                       (const float*)s->xf, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K,
                        (const spkm_blockmap*)ctx->bmap.p, (int)chunk, (float*)ctx->scr_m1.p, (float*)ctx->scr_m2.p,
                        (int*)ctx->scr_k.p);
     HIP_TRY(hipGetLastError());
@@ -770,7 +775,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
                        (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
     // 5. exact distance to the assigned centroid + per-cluster accumulation
-    const int threads = 512, nw = threads / 64;
+    const int threads = 1024, nw = threads / 64;
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     const size_t fixed_lds = (size_t)p * 20 + 16;
     int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 64) / nw / per_pt);
@@ -778,7 +783,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
     auto k2 = k_exact_accumulate<IR>;
     HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 2);
+    const int ab = std::min(max_items, std::max(1, ctx->num_cus));
     if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;

@@ -114,8 +114,8 @@ def screen_block(n: int, irbytes: int) -> str:
         L.append(f"v_add_u32_dpp %[a{j % 4}], %[roffA], %[koff] row_newbcast:{j} {DPP}")
         L.append(f"ds_read_b64 %[tA{j}], %[a{j % 4}]")
     ld = "global_load_ushort" if irbytes == 2 else "global_load_dword"
-    L.append("global_load_dwordx2 %[xAn], %[voxA], %[xbase]")
-    L.append("global_load_dwordx2 %[xBn], %[voxB], %[xbase]")
+    L.append("global_load_dword %[xAn], %[voxA], %[xbase]")   # f32 copy of x
+    L.append("global_load_dword %[xBn], %[voxB], %[xbase]")
     L.append(f"{ld} %[rAn], %[vorA], %[rbase]")
     L.append(f"{ld} %[rBn], %[vorB], %[rbase]")
     for j in range(n + 2):
@@ -154,7 +154,7 @@ def screen_func(n: int, irbytes: int) -> str:
     return f"""template <>
 __device__ __forceinline__ void screen2p<{n}, {irbytes}>(int koff, int roffA, double xA, int roffB, double xB,
     double& accA, double& accB, const void* xbase, const void* rbase, unsigned voxA, unsigned voxB, unsigned vorA,
-    unsigned vorB, double& xAn, double& xBn, int& rAn, int& rBn)
+    unsigned vorB, float& xAn, float& xBn, int& rAn, int& rBn)
 {{
     int a0, a1, a2, a3;
     double xb0, xb1, xb2, xb3;
@@ -182,7 +182,7 @@ def main():
                "// the two f32 accumulators of the lane's centroid pair.\n"
                "template <int N, int IRBYTES>\n__device__ __forceinline__ void screen2p(int koff, int roffA, double xA, "
                "int roffB, double xB,\n    double& accA, double& accB, const void* xbase, const void* rbase, unsigned voxA, "
-               "unsigned voxB, unsigned vorA,\n    unsigned vorB, double& xAn, double& xBn, int& rAn, int& rBn);\n\n")
+               "unsigned voxB, unsigned vorA,\n    unsigned vorB, float& xAn, float& xBn, int& rAn, int& rBn);\n\n")
     for irb in (2, 4):
         out += [screen_func(n, irb) for n in range(1, 17)]
     with open(os.path.join(here, "assign_steps.inc"), "w") as f:

@@ -56,11 +56,12 @@ __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int
     if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(cmax_bits, __builtin_bit_cast(unsigned long long, mx));
 }
 
-// xn1[i] = sum_j |x_j|, xn2[i] = sum_j x_j^2 over column i (any order: used only inside an upper bound).
+// xn1[i] = sum_j |x_j|, xn2[i] = sum_j x_j^2 over column i (any order: used only inside an upper bound),
+// and the f32 copy of the values the screen streams (4 B instead of 8 B per entry).
 // 16 lanes per point so that the loads of a wave cover four contiguous columns.
 __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict__ jc, const double* __restrict__ x,
                                                      long long n, int fixed_s, double* __restrict__ xn1,
-                                                     double* __restrict__ xn2)
+                                                     double* __restrict__ xn2, float* __restrict__ xf)
 {
     const int sub = threadIdx.x & 15;
     const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -72,7 +73,12 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
         if (i < n) {
             const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
             const long long j1 = fixed_s > 0 ? j0 + fixed_s : jc[i + 1];
-            for (long long j = j0 + sub; j < j1; j += 16) { const double v = x[j]; a += fabs(v); b += v * v; }
+            for (long long j = j0 + sub; j < j1; j += 16) {
+                const double v = x[j];
+                a += fabs(v);
+                b += v * v;
+                xf[j] = (float)v; // the screen's x~ = fl32(x)
+            }
         }
         for (int off = 8; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
         if (i < n && sub == 0) { xn1[i] = a; xn2[i] = b; }
@@ -84,7 +90,7 @@ struct RunScreenP {
     static __device__ __forceinline__ void run(int nb, int koff, int roffA, double xA, int roffB, double xB,
                                                double& accA, double& accB, const void* xbase, const void* rbase,
                                                unsigned voxA, unsigned voxB, unsigned vorA, unsigned vorB,
-                                               double& xAn, double& xBn, int& rAn, int& rBn)
+                                               float& xAn, float& xBn, int& rAn, int& rBn)
     {
         if (nb == N)
             screen2p<N, IRB>(koff, roffA, xA, roffB, xB, accA, accB, xbase, rbase, voxA, voxB, vorA, vorB, xAn, xBn,
@@ -97,27 +103,29 @@ struct RunScreenP {
 template <int IRB>
 struct RunScreenP<0, IRB> {
     static __device__ __forceinline__ void run(int, int, int, double, int, double, double&, double&, const void*,
-                                               const void*, unsigned, unsigned, unsigned, unsigned, double&, double&,
+                                               const void*, unsigned, unsigned, unsigned, unsigned, float&, float&,
                                                int&, int&) {}
 };
 
-__device__ __forceinline__ float dpp_f32(float v, int sel)
+// min over the 16-lane DPP row with the DPP operand folded into v_min_f32 (one instruction per
+// stage; IEEE minnum, so NaNs lose against numbers)
+__device__ __forceinline__ float row_min16_f32(float v)
 {
-    const int b = __builtin_bit_cast(int, v);
-    int r;
-    switch (sel) {
-    case 0: r = __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, false); break;  // quad_perm [1,0,3,2]
-    case 1: r = __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, false); break;  // quad_perm [2,3,0,1]
-    case 2: r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xf, 0xf, false); break; // row_half_mirror
-    default: r = __builtin_amdgcn_update_dpp(0, b, 0x140, 0xf, 0xf, false); break; // row_mirror
-    }
-    return __builtin_bit_cast(float, r);
+    asm("v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
 }
 
 // (x, x) as one 64-bit register for v_pk_add_f32
-__device__ __forceinline__ double pack_xx(double x)
+__device__ __forceinline__ double pack_xx(float x)
 {
-    const unsigned b = __builtin_bit_cast(unsigned, (float)x);
+    const unsigned b = __builtin_bit_cast(unsigned, x);
     return __builtin_bit_cast(double, ((unsigned long long)b << 32) | b);
 }
 
@@ -129,20 +137,22 @@ __device__ __forceinline__ void store_screen_winner(double acc2, int slot, int k
     const unsigned long long bits = __builtin_bit_cast(unsigned long long, acc2);
     float a0 = __builtin_bit_cast(float, (unsigned)bits), a1 = __builtin_bit_cast(float, (unsigned)(bits >> 32));
     const int k0 = kbase + 2 * kk;
-    if (k0 >= K) a0 = __builtin_inff();
-    if (k0 + 1 >= K) a1 = __builtin_inff();
+    if (kbase + SCREEN_KT > K) { // wave-uniform: only the last tile has padding slots
+        if (k0 >= K) a0 = __builtin_inff();
+        if (k0 + 1 >= K) a1 = __builtin_inff();
+    }
     const float lo = fminf(a0, a1), hi = fmaxf(a0, a1);
     float m1 = lo;
-#pragma unroll
-    for (int st = 0; st < 4; st++) m1 = fminf(m1, dpp_f32(m1, st));
+    asm volatile("s_nop 1" : "+v"(m1)); // VALU write -> DPP read of the same VGPR: 2 wait states
+    m1 = row_min16_f32(m1);
     const bool mine = (lo == m1);
     const unsigned long long seg = (__ballot(mine) >> (slot * 16)) & 0xffffull;
     const int first = __builtin_ctzll(seg | (1ull << 63));
     const bool none = seg == 0ull; // NaN estimates are never equal to anything: report "no candidate"
     // second smallest: the winning lane contributes its OTHER value, every other lane its smaller one
     float m2 = (kk == first) ? hi : lo;
-#pragma unroll
-    for (int st = 0; st < 4; st++) m2 = fminf(m2, dpp_f32(m2, st));
+    asm volatile("s_nop 1" : "+v"(m2));
+    m2 = row_min16_f32(m2);
     if ((none ? kk == 0 : kk == first) && valid) {
         m1o[i] = none ? __builtin_inff() : m1;
         m2o[i] = none ? __builtin_inff() : m2;
@@ -155,7 +165,7 @@ __device__ __forceinline__ void store_screen_winner(double acc2, int slot, int k
 // shards only.  T32 tile: (p+1) rows of 32 floats = the same 128 B per row as the f64 tile.
 template <typename IR>
 __global__ __launch_bounds__(1024) void k_screen_tile(
-    const IR* __restrict__ ir, const double* __restrict__ xval, const float* __restrict__ T32, int p, int n,
+    const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n,
     int fixed_s, int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k)
 {
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
         const int cA = iA < n ? iA : n - 1, cB = iB < n ? iB : n - 1;
         const unsigned eA = (unsigned)(cA - base) * (unsigned)fixed_s + (unsigned)jl;
         const unsigned eB = (unsigned)(cB - base) * (unsigned)fixed_s + (unsigned)jl;
-        voxA = eA * 8u; voxB = eB * 8u;
+        voxA = eA * 4u; voxB = eB * 4u;
         vorA = eA * (unsigned)IRB; vorB = eB * (unsigned)IRB;
     };
     int t = draw();
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
         lane_offs(base, voxA, voxB, vorA, vorB);
         const char* xb = reinterpret_cast<const char*>(xval + (size_t)base * (size_t)fixed_s);
         const char* rb = reinterpret_cast<const char*>(ir + (size_t)base * (size_t)fixed_s);
-        double xA = *reinterpret_cast<const double*>(xb + voxA), xB = *reinterpret_cast<const double*>(xb + voxB);
+        float xA = *reinterpret_cast<const float*>(xb + voxA), xB = *reinterpret_cast<const float*>(xb + voxB);
         int rA = (int)*reinterpret_cast<const IR*>(rb + vorA), rB = (int)*reinterpret_cast<const IR*>(rb + vorB);
         while (true) {
             int nbase = (tn < T) ? base_of(tn) : n;
@@ -229,10 +239,10 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
             const char* nxb = reinterpret_cast<const char*>(xval + (size_t)nbase * (size_t)fixed_s);
             const char* nrb = reinterpret_cast<const char*>(ir + (size_t)nbase * (size_t)fixed_s);
             double accA = 0.0, accB = 0.0; // two +0.0f each
-            double xAn, xBn;
+            float xAn, xBn;
             int rAn, rBn;
             for (int b = 0; b + 1 < nbatches; b++) {
-                xb += 16 * 8;
+                xb += 16 * 4;
                 rb += 16 * IRB;
                 screen2p<16, IRB>(koff, rA * 128, pack_xx(xA), rB * 128, pack_xx(xB), accA, accB, xb, rb, voxA, voxB,
                                   vorA, vorB, xAn, xBn, rAn, rBn);
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(256) void k_hist(const int* __restrict__ assign, lo
 // LDS: negc f64[p] | ssum f64[p] | scnt u32[p] | per wave: ms f64[PTS*S1]   (S1 = s|1: odd stride, conflict-free)
 // Also per-block partial statistics: sum mind^2, max mind and its first index.
 template <typename IR>
-__global__ __launch_bounds__(512) void k_exact_accumulate(const IR* __restrict__ ir, const double* __restrict__ x,
+__global__ __launch_bounds__(1024) void k_exact_accumulate(const IR* __restrict__ ir, const double* __restrict__ x,
                                                           const int* __restrict__ perm,
                                                           const long long* __restrict__ offs,
                                                           const int4* __restrict__ items,
@@ -381,8 +391,8 @@ __global__ __launch_bounds__(512) void k_exact_accumulate(const IR* __restrict__
     const int S1 = fixed_s | 1;
     char* wbase = smem + (size_t)p * 20 + (size_t)((p & 1) ? 4 : 0);
     double* ms = reinterpret_cast<double*>(wbase) + (size_t)wave * pts * S1;
-    __shared__ double s_obj[8], s_max[8];
-    __shared__ long long s_imax[8];
+    __shared__ double s_obj[16], s_max[16];
+    __shared__ long long s_imax[16];
 
     double obj2 = 0.0, dmax = -1.0;
     long long imax = 0x7fffffffffffffffLL;
@@ -483,9 +493,9 @@ __global__ __launch_bounds__(512) void k_exact_accumulate(const IR* __restrict__
     }
 }
 
-template __global__ void k_screen_tile<unsigned short>(const unsigned short*, const double*, const float*, int, int,
+template __global__ void k_screen_tile<unsigned short>(const unsigned short*, const float*, const float*, int, int,
     int, int, const spkm_blockmap*, int, float*, float*, int*);
-template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const double*, const float*, int, int, int,
+template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const float*, const float*, int, int, int,
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*);
