@@ -50,10 +50,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # developer aid (1-GPU boxes): SPKM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # SPKM_BENCH_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised there
+    if os.environ.get("SPKM_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SPKM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from sparsifiedkmeans_amd import _lib, synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_device, torch_context
@@ -103,6 +111,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    path, listed = eng.last_path_info()
     # dominant kernel (tiled assignment) durations of exactly the timed launches, HIP events on our stream
     buf = (C.c_double * max(args.steps, 1))()
     cnt = C.c_int()
@@ -112,7 +121,6 @@ def main():
     k_ms = float(kms.mean()) if kms.size else float("nan")
 
     out = eng.out.cpu().numpy()
-    path, listed = eng.last_path_info()
     nnz_local = int(shard.nnz)
     # algorithmic bytes of one Lloyd iteration over this GPU's points
     b_iter = nnz_local * 12 + (n_local + 1) * 8 + n_local * 12 + 24 * p2 * K
@@ -124,7 +132,9 @@ def main():
         try:
             with open(pmc) as f:
                 rec = json.load(f)
-            if rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2:
+            kern = "k_screen_tile" if path == 1 else "k_assign_tile"
+            if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
+                    and str(rec.get("kernel", "")).startswith(kern)):
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
