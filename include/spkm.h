@@ -162,6 +162,18 @@ int spkm_fwht_dev(spkm_ctx *ctx, uint64_t m, uint64_t n, const double *d_x, doub
 int spkm_mix_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, const double *d_x, const double *d_sign,
                  double premul, double postdiv, double *d_y);
 
+/* Device sparsifier (the producer of the hot path's input):
+ *   X = randsample_fixedNumberEntries(mix(X), s)    kmeans_sparsified.m:316-334,
+ *                                                   private/randsample_fixedNumberEntries.m:30-64
+ * d_x: p x n dense chunk (columns = points).  For column c (global index col0 + c): s distinct rows,
+ * uniform without replacement (Philox4x32-10 keyed by (seed, col0 + c): independent of chunking and of
+ * the number of GPUs), ascending, into d_ir_out[c*s .. c*s+s) (uint16 / uint32 by ir_bits) and the values
+ * (mix(x)[row] ) / (s/p2) into d_x_out[c*s ..).  The dense mixed column never reaches HBM.
+ * premul / postdiv / d_sign as in spkm_mix_dev.  Needs 16 <= p2 <= 16384. */
+int spkm_mix_sample_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, const double *d_x,
+                        const double *d_sign, double premul, double postdiv, uint64_t s, uint64_t seed,
+                        uint64_t col0, void *d_ir_out, int ir_bits, double *d_x_out);
+
 /* Timing hooks for bench.py: hipEvents recorded on the context's stream around the dominant
  * kernel of the last spkm_assign_dev call.  Returns its duration in milliseconds (blocks). */
 int spkm_last_assign_kernel_ms(spkm_ctx *ctx, double *ms);

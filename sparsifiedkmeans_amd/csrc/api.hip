@@ -5,6 +5,7 @@
 #include "sparse_ops.hip"
 #include "update.hip"
 #include "screen.hip"
+#include "sample.hip"
 
 #include "../../include/spkm.h"
 
@@ -871,7 +872,9 @@ static int check_pow2(uint64_t m)
 }
 
 static int fwht_launch(spkm_ctx* ctx, uint64_t p_in, uint64_t m, uint64_t n, const double* d_x,
-                       const double* d_sign, double premul, double postdiv, double* d_y)
+                       const double* d_sign, double premul, double postdiv, double* d_y,
+                       const void* gather_ir = nullptr, int gather_bits = 0, int gather_s = 0,
+                       double gather_level = 1.0)
 {
     int rc = check_pow2(m);
     if (rc) return rc;
@@ -880,6 +883,7 @@ static int fwht_launch(spkm_ctx* ctx, uint64_t p_in, uint64_t m, uint64_t n, con
     int logm = 0;
     while ((1ull << logm) < m) logm++;
     const int blocks_cap = std::max(1, ctx->num_cus) * 16;
+    if (gather_ir && !(m >= 16 && m <= 16384 && (m + m / 8) * 8 <= ctx->lds_max)) return SPKM_ERR_UNSUPPORTED;
     if (m < 16) {
         hipLaunchKernelGGL(k_fwht_small, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 30)), dim3(256), 0,
                            ctx->stream, d_x, d_y, (int)m, (long long)n, (int)p_in, d_sign, premul, postdiv);
@@ -892,7 +896,7 @@ static int fwht_launch(spkm_ctx* ctx, uint64_t p_in, uint64_t m, uint64_t n, con
         const uint64_t want = (n + cpb - 1) / cpb;
         hipLaunchKernelGGL(k_fwht_lds, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)blocks_cap)), dim3(threads),
                            lds, ctx->stream, d_x, d_y, (int)m, logm, (long long)n, (int)p_in, d_sign, premul,
-                           postdiv, cpb);
+                           postdiv, cpb, gather_ir, gather_bits, gather_s, gather_level);
     } else {
         hipLaunchKernelGGL(k_fwht_load, dim3(blocks_cap), dim3(256), 0, ctx->stream, d_x, d_y, (long long)m,
                            (long long)n, (long long)p_in, d_sign, premul);
@@ -917,6 +921,29 @@ extern "C" int spkm_mix_dev(spkm_ctx* ctx, uint64_t p, uint64_t p2, uint64_t n, 
     if (!ctx || (n && (!d_x || !d_y))) return SPKM_ERR_NULL_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     return fwht_launch(ctx, p, p2, n, d_x, d_sign, premul, postdiv, d_y);
+}
+
+extern "C" int spkm_mix_sample_dev(spkm_ctx* ctx, uint64_t p, uint64_t p2, uint64_t n, const double* d_x,
+                                   const double* d_sign, double premul, double postdiv, uint64_t s, uint64_t seed,
+                                   uint64_t col0, void* d_ir_out, int ir_bits, double* d_x_out)
+{
+    if (!ctx || (n && (!d_x || !d_ir_out || !d_x_out))) return SPKM_ERR_NULL_ARG;
+    if (s == 0 || s > p2 || (ir_bits != 16 && ir_bits != 32) || (ir_bits == 16 && p2 > 65536)) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return SPKM_OK;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)std::max(1, ctx->num_cus) * 16);
+    if (ir_bits == 16)
+        hipLaunchKernelGGL((k_sample_rows<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (unsigned long long)seed, (long long)col0, (long long)n, (int)p2, (int)s,
+                           (unsigned short*)d_ir_out);
+    else
+        hipLaunchKernelGGL((k_sample_rows<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (unsigned long long)seed, (long long)col0, (long long)n, (int)p2, (int)s,
+                           (unsigned int*)d_ir_out);
+    HIP_TRY(hipGetLastError());
+    // SparsityLevel = small_p / p with p the row count of the mixed matrix (randsample_fixedNumberEntries.m:30-31)
+    const double level = (double)s / (double)p2;
+    return fwht_launch(ctx, p, p2, n, d_x, d_sign, premul, postdiv, d_x_out, d_ir_out, ir_bits, (int)s, level);
 }
 
 // ------------------------------------------------------------------------------------------

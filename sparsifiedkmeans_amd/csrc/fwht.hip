@@ -20,8 +20,12 @@ __device__ __forceinline__ int padidx(int e) { return e + ((e >> 4) << 1); }
 __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x, double* __restrict__ y, int m,
                                                    int logm, long long n, int p_in,
                                                    const double* __restrict__ dsign, double premul,
-                                                   double postdiv, int cols_per_block)
+                                                   double postdiv, int cols_per_block,
+                                                   const void* __restrict__ gather_ir, int gather_bits, int gather_s,
+                                                   double gather_level)
 {
+    // gather epilogue (sample.hip): when gather_ir != null the transformed column stays in LDS and only
+    // its gather_s sampled rows are written, y[c*gather_s + t] = (Y[row_t] / postdiv) / gather_level.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int T = m >> 4;                    // threads per column
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x,
                         }
                     }
                 }
-                if (b + nb >= logm && postdiv > 0.0) {
+                if (b + nb >= logm && postdiv > 0.0 && !gather_ir) {
 #pragma unroll
                     for (int q = 0; q < 16; q++) a[q] = a[q] / postdiv;
                 }
@@ -95,10 +99,23 @@ __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x,
             }
         }
 
-        // ---- coalesced store ----
-        for (int t = threadIdx.x; t < total; t += nthreads) {
-            const int c = t / m, r = t - c * m;
-            y[(size_t)(cbase + c) * m + r] = lds[(size_t)c * colstride + padidx(r)];
+        // ---- coalesced store (dense), or gather of the sampled rows ----
+        if (!gather_ir) {
+            for (int t = threadIdx.x; t < total; t += nthreads) {
+                const int c = t / m, r = t - c * m;
+                y[(size_t)(cbase + c) * m + r] = lds[(size_t)c * colstride + padidx(r)];
+            }
+        } else {
+            const int gtotal = (int)ncols * gather_s;
+            for (int t = threadIdx.x; t < gtotal; t += nthreads) {
+                const int c = t / gather_s;
+                const size_t at = (size_t)cbase * gather_s + t;
+                const int r = (gather_bits == 16) ? (int)reinterpret_cast<const unsigned short*>(gather_ir)[at]
+                                                  : (int)reinterpret_cast<const unsigned int*>(gather_ir)[at];
+                double v = lds[(size_t)c * colstride + padidx(r)];
+                if (postdiv > 0.0) v = v / postdiv;
+                y[at] = v / gather_level;
+            }
         }
         __syncthreads();
     }

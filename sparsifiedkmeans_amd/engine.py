@@ -186,3 +186,64 @@ def mix_device(ctx: Context, x: torch.Tensor, p2: int, sign: torch.Tensor | None
     _lib.check(_lib.lib().spkm_mix_dev(ctx.handle, p, p2, n, _p(x), _p(sign) if sign is not None else None,
                                        float(premul), float(postdiv), _p(y)), "spkm_mix_dev")
     return y
+
+
+def mix_sample_device(ctx: Context, x: torch.Tensor, p2: int, sign: torch.Tensor | None, premul: float,
+                      postdiv: float, s: int, seed: int, col0: int, ir_out: torch.Tensor, x_out: torch.Tensor):
+    """Fused mix + sparsify of a dense device chunk [n, p] (kmeans_sparsified.m:316-334): writes the s sampled
+    row ids of every point into ``ir_out`` (int16 viewed as uint16, or int32) and the values into ``x_out``
+    (both flat, n*s entries).  The sample of a point depends only on (seed, col0 + index)."""
+    assert x.dtype == torch.float64 and x.is_contiguous() and x.dim() == 2
+    n, p = x.shape
+    assert ir_out.numel() >= n * s and x_out.numel() >= n * s and x_out.dtype == torch.float64
+    bits = ir_out.element_size() * 8
+    _lib.check(_lib.lib().spkm_mix_sample_dev(ctx.handle, p, p2, n, _p(x), _p(sign) if sign is not None else None,
+                                              float(premul), float(postdiv), int(s), int(seed) & (2**64 - 1),
+                                              int(col0), _p(ir_out), bits, _p(x_out)), "spkm_mix_sample_dev")
+
+
+class StreamingSparsifier:
+    """One-pass ingest of a dense dataset that never fits in HBM at once: chunk -> X*(1+2eps) -> mix ->
+    sample -> append to the resident sparse shard (private/sampleAndMixFromLargeFile.m:79-129).  Only the
+    sparse form (10 B per kept entry) stays on the device; the dense intermediate of a chunk lives in one
+    reusable buffer and the mixed chunk never leaves LDS.
+
+    ``first`` is the global index of this rank's first point (the sample of a point depends on
+    (seed, global index) only, so any chunking / sharding yields the same dataset)."""
+
+    def __init__(self, ctx: Context, p: int, n_local: int, s: int, seed: int, sign: torch.Tensor | None,
+                 first: int = 0, sketch: bool = True):
+        self.ctx, self.p, self.n, self.s, self.seed, self.first = ctx, int(p), int(n_local), int(s), int(seed), int(first)
+        self.p2 = (1 << max(1, int(np.ceil(np.log2(p))))) if sketch else int(p)
+        if not sketch:
+            raise NotImplementedError("the fused sampler sits behind the Hadamard sketch (power-of-two row count)")
+        dev = torch.device("cuda", ctx.device)
+        self.sign = sign
+        self.ir = torch.zeros(self.n * self.s + 16, dtype=torch.int16 if self.p2 <= 65536 else torch.int32, device=dev)
+        self.x = torch.zeros(self.n * self.s + 16, dtype=torch.float64, device=dev)
+        self.filled = 0
+        self._buf = None
+
+    def append(self, chunk) -> None:
+        """chunk: [m, p] points as rows (numpy or torch, any float / integer dtype; converted to float64)."""
+        dev = self.x.device
+        if isinstance(chunk, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(chunk))
+        else:
+            t = chunk
+        m = t.shape[0]
+        assert t.shape[1] == self.p and self.filled + m <= self.n
+        if self._buf is None or self._buf.shape[0] < m:
+            self._buf = torch.empty((m, self.p), dtype=torch.float64, device=dev)
+        buf = self._buf[:m]
+        buf.copy_(t, non_blocking=True)        # H2D (+ dtype conversion on device)
+        o = self.filled * self.s
+        mix_sample_device(self.ctx, buf, self.p2, self.sign, 1.0 + 2.0 * float(np.finfo(np.float64).eps),
+                          float(np.sqrt(np.float64(self.p2))), self.s, self.seed, self.first + self.filled,
+                          self.ir[o:], self.x[o:])
+        self.filled += m
+
+    def finish(self) -> Shard:
+        assert self.filled == self.n, f"expected {self.n} points, got {self.filled}"
+        jc = torch.arange(0, (self.n + 1) * self.s, self.s, dtype=torch.int64, device=self.x.device)
+        return Shard.from_device(self.ctx, self.p2, jc, self.ir, self.x, nnz=self.n * self.s)

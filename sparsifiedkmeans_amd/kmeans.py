@@ -24,7 +24,7 @@ import scipy.sparse as sp
 import torch
 
 from . import synth
-from .engine import LloydEngine, Shard, mix_device, torch_context
+from .engine import LloydEngine, Shard, StreamingSparsifier, mix_device, torch_context
 
 EPS = np.finfo(np.float64).eps
 
@@ -120,8 +120,9 @@ def kmeans_sparsified(X, K, **options):
     o = _parse(options)
     if o["nargout"] > 5:
         raise NotImplementedError("two-pass outputs (kmeans_sparsified.m:522-571) are outside the hot-path scope")
-    if o["DataFile"] is not None or isinstance(X, str):
-        raise NotImplementedError("'DataFile' streaming (sampleAndMixFromLargeFile.m) is not built yet (SURVEY §8f #3)")
+    if isinstance(X, str):
+        o["DataFile"], X = X, None                                                # kmeans_sparsified.m:179-183
+    LoadFromDisk = o["DataFile"] is not None
     if not o["Sparsify"]:
         raise NotImplementedError("'Sparsify',false is the dense k-means path (pdist2 / expanded quadratic, "
                                   "findClusterAssignments.m:124-166): outside the sparsified hot path")
@@ -133,14 +134,29 @@ def kmeans_sparsified(X, K, **options):
     ctx = torch_context(o["device"])
     dev = f"cuda:{ctx.device}"
     Display = o["Display"] if isinstance(o["Display"], str) else "off"
-    OUTPUT = dict(LoadFromDisk=False, Options=dict(o), Sparsify=True)
+    OUTPUT = dict(LoadFromDisk=LoadFromDisk, Options=dict(o), Sparsify=True)
 
-    X = np.asarray(X, np.float64)
-    if np.iscomplexobj(X):
-        raise ValueError("Code and distance computations require real data")   # :312-314
-    if not o["ColumnSamples"]:
-        X = X.T                                                                 # :214-216 (points become columns)
-    p, n = X.shape
+    if LoadFromDisk:
+        # the reference streams a MATLAB v7.3 (HDF5) file through matfile(); here: a .npy file, memory-mapped
+        # and read MB_limit megabytes at a time (private/sampleAndMixFromLargeFile.m:79-129)
+        t1 = time.time()
+        fn = o["DataFile"] if str(o["DataFile"]).endswith(".npy") else str(o["DataFile"]) + ".npy"
+        try:
+            Xmm = np.load(fn, mmap_mode="r")
+        except FileNotFoundError:
+            raise FileNotFoundError("Cannot find specified data file to load")      # :190
+        if Xmm.ndim != 2:
+            raise ValueError("Error reading file; returned bad size for matrix")    # :210-212
+        p, n = (Xmm.shape if o["ColumnSamples"] else Xmm.shape[::-1])
+        OUTPUT["TimeToReadSizeOfFile"] = time.time() - t1
+        X = None
+    else:
+        X = np.asarray(X, np.float64)
+        if np.iscomplexobj(X):
+            raise ValueError("Code and distance computations require real data")   # :312-314
+        if not o["ColumnSamples"]:
+            X = X.T                                                                 # :214-216 (points become columns)
+        p, n = X.shape
     if n < K:
         raise ValueError("X must have more samples than the number of clusters.")  # :219-221
 
@@ -167,22 +183,55 @@ def kmeans_sparsified(X, K, **options):
         raise ValueError('bad type for "SketchType"')                            # :273
     p2 = sketch.p2
 
-    t1 = time.time()
-    Xdev = torch.tensor(np.ascontiguousarray(X.T), device=dev)                   # [n, p]
-    Xmixed = sketch.mix(Xdev, premul=1.0 + 2.0 * EPS)                            # :292,295 (X*(1+2eps) then mix)
-    torch.cuda.synchronize()
-    OUTPUT["TimeToSketch"] = time.time() - t1
-
     small_p = synth.small_p_of(o["SparsityLevel"], p2)                           # :324-326
     gamma = small_p / p                                                          # :329 (divides by p, not p2)
-    t1 = time.time()
-    Y = synth.sparsify_dense(Xmixed.cpu().numpy().T, small_p, rng)               # randsample_fixedNumberEntries (:334)
-    OUTPUT["TimeToSample"] = time.time() - t1
+    sample_seed = int(rng.integers(0, 2**63 - 1))
+    Y = None
+    if sk == "hadamard" and 16 <= p2 <= 16384:
+        # device sparsifier: chunk -> X*(1+2eps) -> mix -> sample -> resident CSC (kmeans_sparsified.m:292-334;
+        # for 'DataFile': sampleAndMixFromLargeFile.m:100-129).  The dense mixed data never reaches HBM.
+        t1 = time.time()
+        sp_ = StreamingSparsifier(ctx, p, n, small_p, sample_seed, sketch.sign, first=0)
+        nn = max(1, min(n, int(o["MB_limit"] * 2**20 // (8 * p))))               # sampleAndMixFromLargeFile.m:82-84
+        if LoadFromDisk and o["DataFileVerbose"]:
+            print(f"Splitting {p} x {n} matrix into {-(-n // nn)} {p} x {nn} chunks")
+        for c0 in range(0, n, nn):
+            if LoadFromDisk:
+                blk = Xmm[:, c0:c0 + nn].T if o["ColumnSamples"] else Xmm[c0:c0 + nn, :]
+            else:
+                blk = X[:, c0:c0 + nn].T
+            sp_.append(np.ascontiguousarray(blk))
+        shard = sp_.finish()
+        torch.cuda.synchronize()
+        OUTPUT["TimeToSketch"] = OUTPUT["TimeToSample"] = time.time() - t1       # fused: one number for both
+        nnz = n * small_p
+    else:
+        if LoadFromDisk:
+            raise NotImplementedError("'DataFile' needs the Hadamard sketch (fused device sparsifier)")
+        t1 = time.time()
+        Xdev = torch.tensor(np.ascontiguousarray(X.T), device=dev)               # [n, p]
+        Xmixed = sketch.mix(Xdev, premul=1.0 + 2.0 * EPS)                        # :292,295 (X*(1+2eps) then mix)
+        torch.cuda.synchronize()
+        OUTPUT["TimeToSketch"] = time.time() - t1
+        t1 = time.time()
+        Y = synth.sparsify_dense(Xmixed.cpu().numpy().T, small_p, np.random.default_rng(sample_seed))  # :334
+        OUTPUT["TimeToSample"] = time.time() - t1
+        shard = Shard.from_scipy(ctx, Y)
+        nnz = Y.nnz
     if Display in ("iter", "final"):
         print(f"Randomly mixing of type {sk}")
-        print(f"Randomly taking {100 * gamma:.1f}% of the data; actual dataset is {100 * Y.nnz / (p2 * n):.1f}% sparse")
+        print(f"Randomly taking {100 * gamma:.1f}% of the data; actual dataset is {100 * nnz / (p2 * n):.1f}% sparse")
 
-    shard = Shard.from_scipy(ctx, Y)
+    def column(i):
+        """dense copy of sparse column i (for 'sample' / k-means++ starts and EmptyAction='singleton')"""
+        if Y is not None:
+            return Y[:, i].toarray().ravel()
+        o_ = i * small_p
+        rows = sp_.ir[o_:o_ + small_p].cpu().numpy().view(np.uint16 if sp_.ir.element_size() == 2 else np.uint32)
+        col = np.zeros(p2)
+        col[rows.astype(np.int64)] = sp_.x[o_:o_ + small_p].cpu().numpy()
+        return col
+
     unbiased = bool(o["unbiasedDistance"])                                       # :369-373
     start = o["Start"]
     Replicates = int(o["Replicates"])
@@ -190,8 +239,9 @@ def kmeans_sparsified(X, K, **options):
                   objectives=np.zeros(Replicates), replicateTimes=np.zeros(Replicates),
                   replicateTimesJustInitialization=np.zeros(Replicates))
     if isinstance(start, str) and start.lower() == "uniform":
-        mn, mx = float(Y.data.min(initial=0.0)), float(Y.data.max(initial=0.0))  # full(min(X(:))) incl. implicit zeros
-        if Y.nnz < p2 * n:
+        vals = Y.data if Y is not None else sp_.x[: n * small_p].cpu().numpy()
+        mn, mx = float(vals.min(initial=0.0)), float(vals.max(initial=0.0))      # full(min(X(:))) incl. implicit zeros
+        if nnz < p2 * n:
             mn, mx = min(mn, 0.0), max(mx, 0.0)
 
     best = dict(obj=np.inf)
@@ -204,13 +254,13 @@ def kmeans_sparsified(X, K, **options):
             s = start.lower()
             if s == "sample":
                 ind = rng.choice(n, K, replace=False)                            # randsample(n,K) (:387)
-                Cs = Y[:, ind]
-                centers_np, sparse_mask = Cs.toarray(), (Cs != 0).toarray().astype(np.uint8)
+                centers_np = np.stack([column(int(i)) for i in ind], axis=1)
+                sparse_mask = (centers_np != 0).astype(np.uint8)
             elif s == "uniform":
                 centers_np = (mx - mn) * rng.random((p2, K)) - mn                # :390 (the reference subtracts mn)
             elif s in ("arthur", "++", "kmeans++", "k-means++", "k-means-++"):
                 g_init = gamma if o["unbiasedInitialization"] else None          # :392-396
-                centers_np, sparse_mask = _arthur(ctx, shard, Y, K, g_init, rng)
+                centers_np, sparse_mask = _arthur(ctx, shard, column, n, K, g_init, rng)
             else:
                 raise ValueError('cannot handle other types of "Start" values')  # :398
         else:
@@ -251,7 +301,7 @@ def kmeans_sparsified(X, K, **options):
                     raise RuntimeError("One cluster lost all its members")      # :439
                 if act == "singleton":
                     imax = int(eng.stats[2].item())                              # [~,iMax] = max(distances) (:436)
-                    col = torch.tensor(Y[:, imax].toarray().ravel(), device=dev)
+                    col = torch.tensor(column(imax), device=dev)
                     for ki in empty:
                         centers[ki] = col                                        # centers(:,ki) = X(:,iMax) (:437)
                 else:                                                            # 'drop' (:441,454-459)
@@ -305,18 +355,18 @@ def kmeans_sparsified(X, K, **options):
     return IDX, Cout, SUMD, D, OUTPUT
 
 
-def _arthur(ctx, shard, Y, K, gamma, rng):
+def _arthur(ctx, shard, column, n, K, gamma, rng):
     """K-means++ seeding, private/Arthur_initialization.m:24-69: first centre uniform; then K-1
     rounds of [~,dist] = findClusterAssignments(X, full(centres), [], gamma) and a draw ∝ dist.^2
     with the 400-retry duplicate rule.  Returns (p2 x K dense values, p2 x K support mask):
     the centres are columns of the sparse X (:36,68)."""
     if K < 1:
         raise ValueError("K must be >= 1")
-    p2, n = Y.shape
     dev = f"cuda:{ctx.device}"
     chosen = [int(rng.integers(n))]                                              # randi(n,1) (:35)
+    cols = [column(chosen[0])]
     for k in range(1, K):
-        Cd = Y[:, chosen].toarray()
+        Cd = np.stack(cols, axis=1)
         eng = LloydEngine(shard, len(chosen), gamma if gamma else 1.0, unbiased=bool(gamma))
         eng.assign_step(torch.tensor(np.ascontiguousarray(Cd.T), device=dev))    # full(ref) (:31,39)
         dist = eng.mind.cpu().numpy()
@@ -330,5 +380,6 @@ def _arthur(ctx, shard, Y, K, gamma, rng):
         if i in chosen:
             raise RuntimeError("Cannot sample with replacement with this distribution")  # :62-65
         chosen.append(i)
-    Cs = Y[:, chosen]
-    return Cs.toarray(), (Cs != 0).toarray().astype(np.uint8)
+        cols.append(column(i))
+    Cd = np.stack(cols, axis=1)
+    return Cd, (Cd != 0).astype(np.uint8)

@@ -87,7 +87,7 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
     owns it (chunks are aligned to global multiples of ``chunk``)."""
     import torch
 
-    from .engine import mix_device
+    from .engine import mix_sample_device
 
     dev = torch.device("cuda", ctx.device)
     p2 = 1 << int(np.ceil(np.log2(p))) if p > 1 else 2
@@ -97,11 +97,10 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
     means = torch.randn((K, p), generator=g0, device=dev, dtype=torch.float64)
     sign = torch.sign(torch.randn(p2, generator=g0, device=dev, dtype=torch.float64))
     sign[sign == 0] = 1.0
-    ir_dtype = torch.int16 if p2 <= 32768 else torch.int32  # int16 holds row ids < 32768 (reinterpreted as u16)
+    ir_dtype = torch.int16 if p2 <= 65536 else torch.int32   # int16 storage is read as uint16 row ids
     # 16 entries of slack: the fixed-stride kernel reads (and ignores) up to 15 entries past a column
     x = torch.zeros(n_local * s + 16, dtype=torch.float64, device=dev)
     ir = torch.zeros(n_local * s + 16, dtype=ir_dtype, device=dev)
-    level = float(np.float64(s) / np.float64(p2))
     premul = float(1.0 + 2.0 * EPS)
     postdiv = float(np.sqrt(np.float64(p2)))
     last = first + n_local
@@ -115,16 +114,11 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
         ids = torch.arange(c * chunk, c * chunk + m, device=dev)
         lab = (ids * K) // n_total
         dense = means[lab] + noise * torch.randn((m, p), generator=gen, device=dev, dtype=torch.float32).double()
-        keys = torch.rand((m, p2), generator=gen, device=dev, dtype=torch.float32)
         a, b = lo - c * chunk, hi - c * chunk
-        dense, keys = dense[a:b].contiguous(), keys[a:b]
-        mixed = mix_device(ctx, dense, p2, sign, premul, postdiv)          # [m', p2]
-        rows = torch.topk(keys, s, dim=1, largest=False, sorted=False).indices
-        rows, _ = torch.sort(rows, dim=1)
-        vals = torch.gather(mixed, 1, rows) / level
+        dense = dense[a:b].contiguous()
         o = (lo - first) * s
-        x[o:o + (hi - lo) * s] = vals.reshape(-1)
-        ir[o:o + (hi - lo) * s] = rows.reshape(-1).to(ir_dtype)
+        # the product's own device sparsifier: mix -> sample (Philox keyed by the GLOBAL point index) -> CSC
+        mix_sample_device(ctx, dense, p2, sign, premul, postdiv, s, seed, lo, ir[o:], x[o:])
         c += 1
     jc = torch.arange(0, (n_local + 1) * s, s, dtype=torch.int64, device=dev)
     return dict(jc=jc, ir=ir, x=x, nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means)

@@ -78,11 +78,17 @@ def test_kmeans_sparsified_start_matrix_matches_oracle_loop(gpu_ctx, oracle):
     IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, Sparsify=True, SparsityLevel=g, Start=S, rng=3,
                                              SketchType="Hadamard", MaxIter=50)
     # replay the random products exactly as the driver drew them
+    from util import sample_rows_reference
+    import scipy.sparse as sp_
+
     rng = np.random.default_rng(3)
     d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    sample_seed = int(rng.integers(0, 2**63 - 1))
     Xm = oracle.mix(X, d, p)
     s = synth.small_p_of(g, p)
-    Y = synth.sparsify_dense(Xm, s, rng)
+    rows = sample_rows_reference(sample_seed, 0, n, p, s)
+    vals = Xm[rows, np.arange(n)[:, None]] / (np.float64(s) / np.float64(p))
+    Y = sp_.csc_matrix((vals.ravel(), rows.ravel(), np.arange(0, (n + 1) * s, s)), shape=(p, n))
     C0 = oracle.fwht(S.T * d[:, None]) / np.sqrt(np.float64(p))
     ref = oracle.lloyd(p, n, *parts(Y), C0, s / p, maxiter=50, tol=1e-6)
     assert OUT["iterations"][0] == ref["iterations"]
@@ -107,3 +113,37 @@ def test_kmeans_sparsified_option_errors(gpu_ctx):
         kmeans_sparsified(np.zeros((100, 12)), 3, Sparsify=True)       # auto -> DCT for p not a power of two
     with pytest.raises(NotImplementedError, match="dense k-means"):
         kmeans_sparsified(X, 3)
+
+
+def test_datafile_streaming_equals_in_memory(gpu_ctx, tmp_path):
+    """'DataFile' (here a .npy file read MB_limit at a time, sampleAndMixFromLargeFile.m:79-129) must give the
+    same clustering as the in-memory call: the sample of a point depends on (seed, index) only."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    X, centres, labels = synth.gmm_dense(128, 3000, 4, seed=8)
+    fn = str(tmp_path / "data.npy")
+    np.save(fn, X.T)                                     # n x p on disk
+    S = X[:, [0, 800, 1600, 2400]].T
+    a = kmeans_sparsified(X.T, 4, Sparsify=True, SparsityLevel=0.1, Start=S, rng=7)
+    b = kmeans_sparsified(fn, 4, Sparsify=True, SparsityLevel=0.1, Start=S, rng=7, MB_limit=0.25, DataFileVerbose=True)
+    # identical data on the device; the per-cluster sums use hardware atomics, so two runs agree to rounding
+    assert np.array_equal(a[0], b[0]) and np.allclose(a[3], b[3], rtol=1e-9, atol=0)
+    assert np.abs(a[1] - b[1]).max() <= 1e-9 * np.abs(a[1]).max()
+    assert b[4]["LoadFromDisk"] and not a[4]["LoadFromDisk"]
+    with pytest.raises(FileNotFoundError, match="Cannot find specified data file"):
+        kmeans_sparsified(str(tmp_path / "missing"), 4, Sparsify=True)
+
+
+def test_mnist_shaped_surrogate(gpu_ctx):
+    """BASELINE.json config 3 by shape (MNIST itself is not available offline): 784 -> 1024 by zero padding,
+    K=10, Hadamard sketch passed explicitly ('auto' would pick the DCT for p=784, kmeans_sparsified.m:226-231)."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    X, centres, labels = synth.gmm_dense(784, 6000, 10, seed=1, noise=0.5)
+    IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, 10, Sparsify=True, SparsityLevel=0.05, SketchType="Hadamard",
+                                             Replicates=3, rng=0)
+    assert C.shape == (10, 784) and IDX.shape == (6000,)
+    assert _accuracy(IDX, labels, 10) > 0.98
+    assert abs(SUMD.sum() - OUT["objectives"].min() ** 2) <= 1e-6 * SUMD.sum() or OUT["objectives"].argmin() != 2

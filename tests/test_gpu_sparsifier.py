@@ -1,0 +1,76 @@
+"""-m gpu: the device sparsifier (mix -> sample -> CSC), SURVEY section 8(f) #1."""
+import numpy as np
+import pytest
+import torch
+
+from util import sample_rows_reference
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, X, d, p2, s, seed, col0):
+    from sparsifiedkmeans_amd.engine import mix_sample_device
+
+    n = X.shape[1]
+    ir = torch.zeros(n * s + 16, dtype=torch.int16, device="cuda:0")
+    xv = torch.zeros(n * s + 16, dtype=torch.float64, device="cuda:0")
+    mix_sample_device(ctx, torch.tensor(np.ascontiguousarray(X.T), device="cuda:0"), p2,
+                      torch.tensor(d, device="cuda:0"), 1.0 + 2 * np.finfo(float).eps, float(np.sqrt(np.float64(p2))),
+                      s, seed, col0, ir, xv)
+    torch.cuda.synchronize()
+    rows = ir[: n * s].cpu().numpy().view(np.uint16).astype(np.int64).reshape(n, s)
+    return rows, xv[: n * s].cpu().numpy().reshape(n, s)
+
+
+@pytest.mark.parametrize("p,s", [(784, 51), (1024, 51), (512, 26), (100, 13), (64, 64), (2048, 1)])
+def test_mix_sample_matches_reference_pipeline(gpu_ctx, oracle, p, s):
+    p2 = 1 << int(np.ceil(np.log2(p)))
+    n, seed, col0 = 777, 0x1234_5678_9ABC, 10_000_000_000
+    rng = np.random.default_rng(p)
+    X = rng.standard_normal((p, n))
+    d = np.sign(rng.standard_normal(p2))
+    rows, vals = _run(gpu_ctx, X, d, p2, s, seed, col0)
+    # sampler: exactly s distinct ascending rows per column, identical to the numpy restatement of the generator
+    assert np.all(np.diff(rows, axis=1) > 0) and rows.min() >= 0 and rows.max() < p2
+    assert np.array_equal(rows, sample_rows_reference(seed, col0, n, p2, s))
+    # values: mix(X)(rows) / (s/p2), the reference's two divisions, bit for bit against the oracle's mix
+    Xm = oracle.mix(X, d, p2)
+    want = Xm[rows, np.arange(n)[:, None]] / (np.float64(s) / np.float64(p2))
+    assert np.array_equal(vals, want)
+
+
+def test_sample_is_independent_of_chunking_and_uniform(gpu_ctx, oracle):
+    p, p2, s, seed = 256, 256, 16, 99
+    X = np.random.default_rng(0).standard_normal((p, 6000))
+    d = np.ones(p2)
+    whole, _ = _run(gpu_ctx, X, d, p2, s, seed, 0)
+    part, _ = _run(gpu_ctx, X[:, 2500:4000], d, p2, s, seed, 2500)
+    assert np.array_equal(part, whole[2500:4000])          # a column's sample depends on (seed, global index) only
+    other, _ = _run(gpu_ctx, X, d, p2, s, seed + 1, 0)
+    assert not np.array_equal(other, whole)
+    cnt = np.bincount(whole.ravel(), minlength=p2)           # every row equally likely: 6000*16/256 = 375 expected
+    assert abs(cnt.mean() - 375) < 1e-9 and cnt.min() > 290 and cnt.max() < 460
+    # pairs of adjacent rows are not correlated beyond chance (selection sampling is exact)
+    both = np.mean([(np.isin(7, r) and np.isin(8, r)) for r in whole])
+    assert abs(both - (16 / 256) * (15 / 255)) < 0.004
+
+
+def test_device_pipeline_feeds_the_engine(gpu_ctx, oracle):
+    """End to end on device: dense chunk -> mix+sample -> adopted shard -> assignment equals the oracle on the
+    same CSC matrix."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, p2, s, n, K = 512, 512, 26, 4000, 7
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((p, n))
+    d = np.sign(rng.standard_normal(p2))
+    rows, vals = _run(gpu_ctx, X, d, p2, s, 5, 0)
+    ir = torch.tensor(rows.astype(np.uint16).view(np.int16).ravel(), device="cuda:0")
+    ir = torch.cat([ir, torch.zeros(16, dtype=torch.int16, device="cuda:0")])
+    xv = torch.cat([torch.tensor(vals.ravel(), device="cuda:0"), torch.zeros(16, dtype=torch.float64, device="cuda:0")])
+    jc = torch.arange(0, (n + 1) * s, s, dtype=torch.int64, device="cuda:0")
+    eng = LloydEngine(Shard.from_device(gpu_ctx, p2, jc, ir, xv, nnz=n * s), K, s / p)
+    Cm = rng.standard_normal((p2, K))
+    eng.assign_step(torch.tensor(np.ascontiguousarray(Cm.T), device="cuda:0"))
+    ra, rd = oracle.assign(p2, n, jc.cpu().numpy().astype(np.uint64), rows.ravel().astype(np.uint64), vals.ravel(), Cm, s / p)
+    assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)

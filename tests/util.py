@@ -26,3 +26,42 @@ def random_csc(p, n, nnz_per_col, seed, ragged=False, empty_cols=(), dtype=np.fl
 
 def parts(X):
     return X.indptr.astype(np.uint64), X.indices.astype(np.uint64), X.data.astype(np.float64)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """numpy restatement of the counter-based generator of csrc/sample.hip (arrays of uint32)."""
+    c0, c1, c2, c3 = (np.asarray(v, np.uint64) for v in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M
+        n1 = p1 & M
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M
+        n3 = p0 & M
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    return c0, c1, c2, c3
+
+
+def sample_rows_reference(seed, col0, n, p2, s):
+    """Selection sampling (Knuth Algorithm S) exactly as k_sample_rows draws it: [n, s] ascending rows."""
+    cols = np.arange(col0, col0 + n, dtype=np.uint64)
+    out = np.zeros((n, s), np.int64)
+    taken = np.zeros(n, np.int64)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for r0 in range(0, p2, 4):
+        u = philox4x32_10(cols & np.uint64(0xFFFFFFFF), cols >> np.uint64(32), np.full(n, r0 >> 2), np.zeros(n), k0, k1)
+        for q in range(4):
+            r = r0 + q
+            if r >= p2:
+                break
+            t = (u[q] * np.uint64(p2 - r)) >> np.uint64(32)
+            take = (t < (s - taken).astype(np.uint64)) & (taken < s)
+            idx = np.flatnonzero(take)
+            out[idx, taken[idx]] = r
+            taken[idx] += 1
+    assert np.all(taken == s)
+    return out
