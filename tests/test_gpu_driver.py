@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import scipy.sparse as sp
+import torch
 
 from util import parts, random_csc
 
@@ -147,3 +148,23 @@ def test_mnist_shaped_surrogate(gpu_ctx):
     assert C.shape == (10, 784) and IDX.shape == (6000,)
     assert _accuracy(IDX, labels, 10) > 0.98
     assert abs(SUMD.sum() - OUT["objectives"].min() ** 2) <= 1e-6 * SUMD.sum() or OUT["objectives"].argmin() != 2
+
+
+def test_kmeanspp_running_minimum_equals_full_recompute(gpu_ctx, oracle):
+    """Arthur_initialization.m:38-69 recomputes distances to all chosen centres each round; the running
+    minimum over single-centre evaluations must reproduce that vector bit for bit."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n = 256, 3000
+    X = random_csc(p, n, 13, seed=21)
+    shard = Shard.from_scipy(gpu_ctx, X)
+    picks = [5, 700, 1500, 2999, 42]
+    eng1 = LloydEngine(shard, 1, 13 / 256)
+    run = None
+    for t, i in enumerate(picks):
+        c = torch.tensor(X[:, i].toarray().ravel()[None, :], device="cuda:0")
+        eng1.assign_step(c)
+        run = eng1.mind.clone() if run is None else torch.minimum(run, eng1.mind)
+        Cd = X[:, picks[: t + 1]].toarray()
+        _, full = oracle.assign(p, n, *parts(X), Cd, 13 / 256)      # what the reference recomputes
+        assert np.array_equal(run.cpu().numpy(), full)
