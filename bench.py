@@ -87,6 +87,32 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
+    # the one-off preconditioner, reported separately: dense mix() and the fused mix+sample on one chunk
+    fw = None
+    if rank == 0:
+        from sparsifiedkmeans_amd.engine import mix_sample_device
+
+        mcols = min(131072, n_local)
+        xd = torch.randn((mcols, p), device="cuda", dtype=torch.float64)
+        irt = torch.zeros(mcols * s + 16, dtype=torch.int16 if p2 <= 65536 else torch.int32, device="cuda")
+        xt = torch.zeros(mcols * s + 16, dtype=torch.float64, device="cuda")
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        mix_device(ctx, xd, p2, data["sign"], 1.0, 32.0)
+        ev[0].record()
+        for _ in range(5):
+            mix_device(ctx, xd, p2, data["sign"], 1.0, float(np.sqrt(np.float64(p2))))
+        ev[1].record()
+        for _ in range(5):
+            mix_sample_device(ctx, xd, p2, data["sign"], 1.0, float(np.sqrt(np.float64(p2))), s, 1, 0, irt, xt)
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_dense, t_fused = ev[0].elapsed_time(ev[1]) / 5e3, ev[1].elapsed_time(ev[2]) / 5e3
+        fw = {"columns": mcols, "m": p2,
+              "dense_mix_GBs": mcols * (p + p2) * 8 / t_dense / 1e9, "dense_mix_columns_per_s": mcols / t_dense,
+              "fused_mix_sample_GBs": mcols * (p * 8 + s * 12) / t_fused / 1e9,
+              "fused_mix_sample_columns_per_s": mcols / t_fused}
+        del xd, irt, xt
+
     eng = LloydEngine(shard, K, gamma)
     centers = centers0.clone()
 
@@ -170,6 +196,7 @@ def main():
                  "exact_f64_op_equivalent_Tops": ops / (k_ms * 1e-3) / 1e12 if k_ms == k_ms else None,
                  "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS},
         "whole_iter_gbs": b_iter / (elapsed / args.steps) / 1e9,
+        "fwht": fw,
     }
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:

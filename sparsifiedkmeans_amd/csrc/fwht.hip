@@ -17,6 +17,43 @@
 
 __device__ __forceinline__ int padidx(int e) { return e + ((e >> 4) << 1); }
 
+// One round of NB (<= 4) butterfly stages, bits b .. b+NB-1, on the 16 elements this thread owns:
+//   NB == 4: e(q) = (H << (b+4)) | (q << b) | L      with tau = (H << b) | L
+//   NB <  4 (last round, b + NB == logm): the 4-NB spare bits of q come from the top of L
+// Stages are applied in ascending bit order (the reference's order, hadamard.c:66-77).
+template <int NB>
+__device__ __forceinline__ void fwht_round(double* __restrict__ col, int tau, int b, double postdiv)
+{
+    auto idx = [&](int q) {
+        if constexpr (NB == 4) {
+            const int L = tau & ((1 << b) - 1), H = tau >> b;
+            return (H << (b + 4)) | (q << b) | L;
+        } else {
+            return ((q & ((1 << NB) - 1)) << b) | ((q >> NB) << (b - (4 - NB))) | tau;
+        }
+    };
+    double a[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) a[q] = col[padidx(idx(q))];
+#pragma unroll
+    for (int s = 0; s < NB; s++) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if ((q & (1 << s)) == 0) {
+                const double u = a[q], w = a[q | (1 << s)];
+                a[q] = u + w;
+                a[q | (1 << s)] = u - w;
+            }
+        }
+    }
+    if (postdiv > 0.0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) a[q] = a[q] / postdiv;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) col[padidx(idx(q))] = a[q];
+}
+
 __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x, double* __restrict__ y, int m,
                                                    int logm, long long n, int p_in,
                                                    const double* __restrict__ dsign, double premul,
@@ -30,94 +67,106 @@ __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x,
     double* lds = reinterpret_cast<double*>(smem);
     const int T = m >> 4;                    // threads per column
     const int csub = threadIdx.x / T;        // which column of this block
-    const int tau = threadIdx.x % T;
+    const int tau0_ = threadIdx.x % T;
     const int colstride = m + (m >> 3);      // padded doubles per column
     double* col = lds + (size_t)csub * colstride;
-    const int nthreads = blockDim.x;
 
+    const int tau_c = tau0_;
+    // T <= 64: a column lives inside one wave, whose LDS operations complete in program order -- a compiler
+    // fence is enough and the four waves of a workgroup never wait for each other
+    const bool wave_local = T <= 64;
+    auto sync = [&]() {
+        if (wave_local) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
     for (long long cbase = (long long)blockIdx.x * cols_per_block; cbase < n;
          cbase += (long long)gridDim.x * cols_per_block) {
+        // hipcc hoists the ~100 per-thread index expressions of an iteration out of this loop and then spills
+        // them to scratch (428 B per lane); making the thread index opaque per iteration keeps them in flight
+        int tau = tau_c;
+        asm volatile("" : "+v"(tau));
         // ---- coalesced load of cols_per_block columns into LDS (with the fused input ops) ----
+        // thread (csub, tau) fetches elements tau + T*i, i = 0..15, of its own column: 16 independent loads
+        // in flight per lane (a rolled loop would expose 16 HBM latencies one after the other)
         const long long ncols = (n - cbase < cols_per_block) ? (n - cbase) : cols_per_block;
-        const int total = (int)ncols * m;
-        for (int t = threadIdx.x; t < total; t += nthreads) {
-            const int c = t / m, r = t - c * m;
-            double v = 0.0;
-            if (r < p_in) {
-                v = x[(size_t)(cbase + c) * p_in + r];
-                if (premul != 1.0) v = v * premul;
+        {
+            double v[16];
+            double sg[16];
+            const bool have = csub < ncols;
+            // unconditional loads on clamped indices (a predicated load would be waited for before the next
+            // one is issued); out-of-range rows / columns are zeroed afterwards
+            const double* xc = x + (size_t)(cbase + (have ? csub : 0)) * p_in;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = tau + T * i;
+                v[i] = xc[r < p_in ? r : p_in - 1];
             }
-            if (dsign) v = dsign[r] * v;
-            lds[(size_t)c * colstride + padidx(r)] = v;
+            if (dsign) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) sg[i] = dsign[tau + T * i];
+            }
+            if (have) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int r = tau + T * i;
+                    double w = (r < p_in) ? v[i] : 0.0;
+                    if (premul != 1.0) w = w * premul;
+                    if (dsign) w = sg[i] * w;
+                    col[padidx(r)] = w;
+                }
+            }
         }
-        __syncthreads();
+        sync();
 
         // barriers must be reached by every lane of every wave the same number of times: the
         // rounds are predicated per column instead of branching around them
         const bool active = cbase + csub < n;
-        {
-            for (int b = 0; b < logm; b += 4) {
-              if (active) {
+        for (int b = 0; b < logm; b += 4) {
+            if (active) {
                 const int nb = (logm - b < 4) ? (logm - b) : 4;
-                double a[16];
-                int e[16];
-                if (nb == 4) {
-                    const int L = tau & ((1 << b) - 1), H = tau >> b;
-#pragma unroll
-                    for (int q = 0; q < 16; q++) e[q] = (H << (b + 4)) | (q << b) | L;
-                } else {
-                    const int xb = 4 - nb;
-#pragma unroll
-                    for (int q = 0; q < 16; q++)
-                        e[q] = ((q & ((1 << nb) - 1)) << b) | ((q >> nb) << (b - xb)) | tau;
+                const bool last = b + nb >= logm;
+                const double pd = (last && !gather_ir) ? postdiv : 0.0;
+                switch (nb) {
+                case 4: fwht_round<4>(col, tau, b, pd); break;
+                case 3: fwht_round<3>(col, tau, b, pd); break;
+                case 2: fwht_round<2>(col, tau, b, pd); break;
+                default: fwht_round<1>(col, tau, b, pd); break;
                 }
-#pragma unroll
-                for (int q = 0; q < 16; q++) a[q] = col[padidx(e[q])];
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    if (s < nb) {
-#pragma unroll
-                        for (int q = 0; q < 16; q++) {
-                            if ((q & (1 << s)) == 0) {
-                                const double u = a[q], w = a[q | (1 << s)];
-                                a[q] = u + w;
-                                a[q | (1 << s)] = u - w;
-                            }
-                        }
-                    }
-                }
-                if (b + nb >= logm && postdiv > 0.0 && !gather_ir) {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) a[q] = a[q] / postdiv;
-                }
-                // rounds touch disjoint element sets per thread within a round, but the next
-                // round reads other threads' elements: block-wide barrier on both sides.
-#pragma unroll
-                for (int q = 0; q < 16; q++) col[padidx(e[q])] = a[q];
-              }
-                __syncthreads();
             }
+            // a round touches disjoint element sets per thread, but the next round reads other threads'
+            // elements: block-wide barrier
+            sync();
         }
 
         // ---- coalesced store (dense), or gather of the sampled rows ----
         if (!gather_ir) {
-            for (int t = threadIdx.x; t < total; t += nthreads) {
-                const int c = t / m, r = t - c * m;
-                y[(size_t)(cbase + c) * m + r] = lds[(size_t)c * colstride + padidx(r)];
+            if (csub < ncols) {
+                double* yc = y + (size_t)(cbase + csub) * m;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int r = tau + T * i;
+                    yc[r] = col[padidx(r)];
+                }
             }
         } else {
-            const int gtotal = (int)ncols * gather_s;
-            for (int t = threadIdx.x; t < gtotal; t += nthreads) {
-                const int c = t / gather_s;
-                const size_t at = (size_t)cbase * gather_s + t;
-                const int r = (gather_bits == 16) ? (int)reinterpret_cast<const unsigned short*>(gather_ir)[at]
-                                                  : (int)reinterpret_cast<const unsigned int*>(gather_ir)[at];
-                double v = lds[(size_t)c * colstride + padidx(r)];
-                if (postdiv > 0.0) v = v / postdiv;
-                y[at] = v / gather_level;
+            // each column is gathered by the threads that own it (stays wave-local for T <= 64)
+            if (csub < ncols) {
+                for (int t = tau; t < gather_s; t += T) {
+                    const size_t at = (size_t)(cbase + csub) * gather_s + t;
+                    const int r = (gather_bits == 16) ? (int)reinterpret_cast<const unsigned short*>(gather_ir)[at]
+                                                      : (int)reinterpret_cast<const unsigned int*>(gather_ir)[at];
+                    double v = col[padidx(r)];
+                    if (postdiv > 0.0) v = v / postdiv;
+                    y[at] = v / gather_level;
+                }
             }
         }
-        __syncthreads();
+        sync();
     }
 }
 
