@@ -200,7 +200,7 @@ extern "C" int spkm_shard_create_host(spkm_ctx* ctx, uint64_t p, uint64_t n, con
     spkm_shard* s = new spkm_shard();
     s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->owned = true;
     s->ir_bits = (p <= 65536) ? 16 : 32;
-    s->slack = 16;
+    s->slack = 48;
     if (n > 0 && nnz > 0 && nnz % n == 0) {
         const uint64_t st = nnz / n;
         bool fixed = st <= 0x7fffffffull;
@@ -208,10 +208,12 @@ extern "C" int spkm_shard_create_host(spkm_ctx* ctx, uint64_t p, uint64_t n, con
         if (fixed) s->fixed_s = (int)st;
     }
     const size_t irb = (size_t)s->ir_bits / 8;
-    // +16 entries of slack so that clamped batch loads never leave the allocation
+    // +48 entries of slack so that the batch loads of the fixed-stride kernels never leave the allocation
     hipError_t e = hipMalloc((void**)&s->jc, (n + 1) * sizeof(long long));
-    if (e == hipSuccess) e = hipMalloc(&s->ir, (nnz + 16) * irb);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->x, (nnz + 16) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&s->ir, (nnz + 48) * irb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->x, (nnz + 48) * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(s->ir, 0, (nnz + 48) * irb, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->x, 0, (nnz + 48) * sizeof(double), ctx->stream);
     if (e != hipSuccess) { spkm_shard_destroy(s); return (int)e; }
     std::vector<long long> jcn(n + 1);
     for (uint64_t i = 0; i <= n; i++) jcn[i] = (long long)jc[i];
@@ -679,7 +681,7 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
 static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
 {
     if (getenv("SPKM_NO_SCREEN")) return false;
-    if (s->fixed_s <= 0 || s->slack < 16 || s->nnz == 0) return false;
+    if (s->fixed_s <= 0 || s->slack < 48 || s->nnz == 0) return false; // the screen reads up to 33 entries past a column
     if (K <= 16) return false; // a single exact tile already streams X once
     if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
     const int G = (K + SCREEN_KT - 1) / SCREEN_KT;
@@ -708,8 +710,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (!sm->xn1) {
         HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
         HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
-        HIP_TRY(hipMalloc((void**)&sm->xf, (size_t)(s->nnz + 16) * 4));
-        HIP_TRY(hipMemsetAsync(sm->xf, 0, (size_t)(s->nnz + 16) * 4, ctx->stream));
+        HIP_TRY(hipMalloc((void**)&sm->xf, (size_t)(s->nnz + 48) * 4));
+        HIP_TRY(hipMemsetAsync(sm->xf, 0, (size_t)(s->nnz + 48) * 4, ctx->stream));
         hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256), 0,
                            ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2,
                            sm->xf);

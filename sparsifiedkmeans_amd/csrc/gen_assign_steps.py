@@ -165,6 +165,116 @@ __device__ __forceinline__ void screen2p<{n}, {irbytes}>(int koff, int roffA, do
 }}
 """
 
+def screen32_block(n: int, irbytes: int) -> str:
+    """f32 SCREEN block, second generation: up to 32 entries of a point per block, two entries per DPP
+    broadcast.  Lane l of a 16-lane row holds the pairs (x_2l, x_2l+1) [two f32 in one 64-bit register] and
+    (roff_2l, roff_2l+1) [two LDS row offsets in one 64-bit register] of its point.  Per pair i:
+        v[R:R+1] = rp[row lane i]                      v_mov_b64_dpp      (two row offsets at once)
+        a = v[R] + koff ; t_2i   = LDS[a]              v_add_u32 (plain, 2 cycles) ; ds_read_b64
+        a = v[R+1]+koff ; t_2i+1 = LDS[a]              v_add_u32 ; ds_read_b64
+        xb = xp[row lane i]                            v_mov_b64_dpp      (x_2i, x_2i+1)
+        t_2i   += (xb.lo, xb.lo)                       v_pk_add_f32 op_sel_hi:[1,0]
+        t_2i+1 += (xb.hi, xb.hi)                       v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,1]
+        acc = t*t + acc  (x2)                          v_pk_fma_f32
+    i.e. 2 DPP + 2 plain + 4 packed instructions per 2 entries per 32 centroids (28 issue cycles instead of
+    35).  The broadcast row offsets need their two halves as separate 32-bit operands, which inline-asm operands
+    cannot express: they live in v[124:127], named literally and declared as clobbers (they never hold anything
+    across the statement).  Entries 0..15 come from lanes 0..7, entries 16..31 from lanes 8..15; each half
+    follows the two-group schedule of the first generation with at most 16 LDS reads in flight (waits are
+    derived from the issue order below).  The next batch's global loads are issued after the first reads and
+    waited for at the end of the statement."""
+    L = ["s_waitcnt lgkmcnt(0)", "s_nop 1"]
+    issued = []  # LDS reads in issue order (names)
+
+    def wait_for(name):
+        younger = len(issued) - 1 - issued.index(name)
+        assert younger <= 15, (n, name, younger)
+        L.append(f"s_waitcnt lgkmcnt({younger})")
+
+    def issue_pair(grp, i, lane, nent, tbase):
+        R = 124 + 2 * (i & 1)
+        L.append(f"v_mov_b64_dpp v[{R}:{R+1}], %[rp{grp}] row_newbcast:{lane} {DPP}")
+        for h in range(2):
+            e = 2 * i + h
+            if e < nent:
+                L.append(f"v_add_u32 %[a{(2*i+h) % 4}], v{R+h}, %[koff]")
+                L.append(f"ds_read_b64 %[t{grp}{e}], %[a{(2*i+h) % 4}]")
+                issued.append(f"{grp}{tbase}{e}")
+
+    first = True
+    for half in range(2):
+        nent = max(0, min(16, n - 16 * half))
+        if nent == 0:
+            break
+        P = (nent + 1) // 2
+        tb = f"h{half}_"
+        for i in range(P):
+            issue_pair("A", i, 8 * half + i, nent, tb)
+        if first:
+            ld2 = "global_load_ushort" if irbytes == 2 else "global_load_dword"
+            L.append("global_load_dwordx2 %[xAn], %[voxA], %[xbase]")
+            L.append("global_load_dwordx2 %[xBn], %[voxB], %[xbase]")
+            if irbytes == 2:
+                L.append(f"{ld2} %[rA0n], %[vorA], %[rbase]")
+                L.append(f"{ld2} %[rA1n], %[vorA], %[rbase] offset:2")
+                L.append(f"{ld2} %[rB0n], %[vorB], %[rbase]")
+                L.append(f"{ld2} %[rB1n], %[vorB], %[rbase] offset:2")
+            else:
+                L.append(f"{ld2} %[rA0n], %[vorA], %[rbase]")
+                L.append(f"{ld2} %[rA1n], %[vorA], %[rbase] offset:4")
+                L.append(f"{ld2} %[rB0n], %[vorB], %[rbase]")
+                L.append(f"{ld2} %[rB1n], %[vorB], %[rbase] offset:4")
+            first = False
+        for grp, other in (("A", "B"), ("B", None)):
+            for i in range(P + 2):
+                if i < P:
+                    last_e = min(2 * i + 1, nent - 1)
+                    wait_for(f"{grp}{tb}{last_e}")
+                    L.append(f"v_mov_b64_dpp %[xb{i % 4}], %[xp{grp}] row_newbcast:{8 * half + i} {DPP}")
+                    if other:
+                        issue_pair(other, i, 8 * half + i, nent, tb)
+                if 0 <= i - 1 < P:
+                    e = 2 * (i - 1)
+                    L.append(f"v_pk_add_f32 %[t{grp}{e}], %[t{grp}{e}], %[xb{(i-1) % 4}] op_sel_hi:[1,0]")
+                    if e + 1 < nent:
+                        L.append(f"v_pk_add_f32 %[t{grp}{e+1}], %[t{grp}{e+1}], %[xb{(i-1) % 4}] op_sel:[0,1] op_sel_hi:[1,1]")
+                if 0 <= i - 2 < P:
+                    e = 2 * (i - 2)
+                    L.append(f"v_pk_fma_f32 %[acc{grp}], %[t{grp}{e}], %[t{grp}{e}], %[acc{grp}]")
+                    if e + 1 < nent:
+                        L.append(f"v_pk_fma_f32 %[acc{grp}], %[t{grp}{e+1}], %[t{grp}{e+1}], %[acc{grp}]")
+    L.append("s_waitcnt vmcnt(0)")
+    return "\\n\\t".join(L)
+
+
+def screen32_func(n: int, irbytes: int) -> str:
+    nt = min(n, 16)
+    outs = ['[accA] "+v"(accA)', '[accB] "+v"(accB)']
+    outs += [f'[a{j}] "=&v"(a{j})' for j in range(4)]
+    outs += [f'[xb{j}] "=&v"(xb{j})' for j in range(4)]
+    outs += [f'[tA{j}] "=&v"(tA{j})' for j in range(nt)]
+    outs += [f'[tB{j}] "=&v"(tB{j})' for j in range(nt)]
+    outs += ['[xAn] "=&v"(xAn)', '[xBn] "=&v"(xBn)', '[rA0n] "=&v"(rA0n)', '[rA1n] "=&v"(rA1n)',
+             '[rB0n] "=&v"(rB0n)', '[rB1n] "=&v"(rB1n)']
+    ins = ['[xpA] "v"(xpA)', '[xpB] "v"(xpB)', '[rpA] "v"(rpA)', '[rpB] "v"(rpB)', '[koff] "v"(koff)',
+           '[xbase] "s"(xbase)', '[rbase] "s"(rbase)', '[voxA] "v"(voxA)', '[voxB] "v"(voxB)',
+           '[vorA] "v"(vorA)', '[vorB] "v"(vorB)']
+    decl_t = ", ".join([f"tA{j}" for j in range(nt)] + [f"tB{j}" for j in range(nt)])
+    return f"""template <>
+__device__ __forceinline__ void screen32p<{n}, {irbytes}>(int koff, double rpA, double xpA, double rpB, double xpB,
+    double& accA, double& accB, const void* xbase, const void* rbase, unsigned voxA, unsigned voxB, unsigned vorA,
+    unsigned vorB, double& xAn, double& xBn, int& rA0n, int& rA1n, int& rB0n, int& rB1n)
+{{
+    int a0, a1, a2, a3;
+    double xb0, xb1, xb2, xb3;
+    double {decl_t};
+    asm volatile("{screen32_block(n, irbytes)}"
+                 : {", ".join(outs)}
+                 : {", ".join(ins)}
+                 : "v124", "v125", "v126", "v127");
+}}
+"""
+
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
@@ -185,6 +295,13 @@ def main():
                "unsigned voxB, unsigned vorA,\n    unsigned vorB, float& xAn, float& xBn, int& rAn, int& rBn);\n\n")
     for irb in (2, 4):
         out += [screen_func(n, irb) for n in range(1, 17)]
+    out.append("// second-generation f32 screen blocks: up to 32 entries, two per DPP broadcast (see gen_assign_steps.py)\n"
+               "template <int N, int IRBYTES>\n__device__ __forceinline__ void screen32p(int koff, double rpA, double xpA, "
+               "double rpB, double xpB,\n    double& accA, double& accB, const void* xbase, const void* rbase, "
+               "unsigned voxA, unsigned voxB, unsigned vorA,\n    unsigned vorB, double& xAn, double& xBn, int& rA0n, "
+               "int& rA1n, int& rB0n, int& rB1n);\n\n")
+    for irb in (2, 4):
+        out += [screen32_func(n, irb) for n in range(1, 33)]
     with open(os.path.join(here, "assign_steps.inc"), "w") as f:
         f.write("".join(out))
 

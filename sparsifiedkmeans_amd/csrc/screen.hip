@@ -107,6 +107,34 @@ struct RunScreenP<0, IRB> {
                                                int&, int&) {}
 };
 
+template <int N, int IRB>
+struct RunScreen32P {
+    static __device__ __forceinline__ void run(int nb, int koff, double rpA, double xpA, double rpB, double xpB,
+                                               double& accA, double& accB, const void* xbase, const void* rbase,
+                                               unsigned voxA, unsigned voxB, unsigned vorA, unsigned vorB,
+                                               double& xAn, double& xBn, int& rA0n, int& rA1n, int& rB0n, int& rB1n)
+    {
+        if (nb == N)
+            screen32p<N, IRB>(koff, rpA, xpA, rpB, xpB, accA, accB, xbase, rbase, voxA, voxB, vorA, vorB, xAn, xBn,
+                              rA0n, rA1n, rB0n, rB1n);
+        else
+            RunScreen32P<N - 1, IRB>::run(nb, koff, rpA, xpA, rpB, xpB, accA, accB, xbase, rbase, voxA, voxB, vorA,
+                                          vorB, xAn, xBn, rA0n, rA1n, rB0n, rB1n);
+    }
+};
+template <int IRB>
+struct RunScreen32P<0, IRB> {
+    static __device__ __forceinline__ void run(int, int, double, double, double, double, double&, double&,
+                                               const void*, const void*, unsigned, unsigned, unsigned, unsigned,
+                                               double&, double&, int&, int&, int&, int&) {}
+};
+
+// two 32-bit values in one 64-bit register (low, high)
+__device__ __forceinline__ double pack2(unsigned lo, unsigned hi)
+{
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // min over the 16-lane DPP row with the DPP operand folded into v_min_f32 (one instruction per
 // stage; IEEE minnum, so NaNs lose against numbers)
 __device__ __forceinline__ float row_min16_f32(float v)
@@ -200,8 +228,9 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
     const int R = chunk_points / PPS;
     const int my_chunks = (nchunks > bm.stream) ? (nchunks - bm.stream + bm.nstreams - 1) / bm.nstreams : 0;
     const int T = my_chunks * R;
-    const int nbatches = (fixed_s + 15) >> 4;
-    const int tail = fixed_s - 16 * (nbatches - 1);
+    // batches of 32 entries: lane l of a row owns entries 2l, 2l+1 of the batch (screen32p)
+    const int nbatches = (fixed_s + 31) >> 5;
+    const int tail = fixed_s - 32 * (nbatches - 1);
     unsigned* ticket = reinterpret_cast<unsigned*>(smem + tile_bytes);
     auto draw = [&]() {
         unsigned v = 0;
@@ -215,8 +244,8 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
     auto lane_offs = [&](int base, unsigned& voxA, unsigned& voxB, unsigned& vorA, unsigned& vorB) {
         const int iA = base + slot, iB = base + PPW + slot;
         const int cA = iA < n ? iA : n - 1, cB = iB < n ? iB : n - 1;
-        const unsigned eA = (unsigned)(cA - base) * (unsigned)fixed_s + (unsigned)jl;
-        const unsigned eB = (unsigned)(cB - base) * (unsigned)fixed_s + (unsigned)jl;
+        const unsigned eA = (unsigned)(cA - base) * (unsigned)fixed_s + 2u * (unsigned)jl;
+        const unsigned eB = (unsigned)(cB - base) * (unsigned)fixed_s + 2u * (unsigned)jl;
         voxA = eA * 4u; voxB = eB * 4u;
         vorA = eA * (unsigned)IRB; vorB = eB * (unsigned)IRB;
     };
@@ -228,8 +257,13 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
         lane_offs(base, voxA, voxB, vorA, vorB);
         const char* xb = reinterpret_cast<const char*>(xval + (size_t)base * (size_t)fixed_s);
         const char* rb = reinterpret_cast<const char*>(ir + (size_t)base * (size_t)fixed_s);
-        float xA = *reinterpret_cast<const float*>(xb + voxA), xB = *reinterpret_cast<const float*>(xb + voxB);
-        int rA = (int)*reinterpret_cast<const IR*>(rb + vorA), rB = (int)*reinterpret_cast<const IR*>(rb + vorB);
+        auto ldx = [&](const char* b_, unsigned off) {
+            const float* q = reinterpret_cast<const float*>(b_ + off);
+            return pack2(__builtin_bit_cast(unsigned, q[0]), __builtin_bit_cast(unsigned, q[1]));
+        };
+        double xpA = ldx(xb, voxA), xpB = ldx(xb, voxB);
+        int rA0 = (int)reinterpret_cast<const IR*>(rb + vorA)[0], rA1 = (int)reinterpret_cast<const IR*>(rb + vorA)[1];
+        int rB0 = (int)reinterpret_cast<const IR*>(rb + vorB)[0], rB1 = (int)reinterpret_cast<const IR*>(rb + vorB)[1];
         while (true) {
             int nbase = (tn < T) ? base_of(tn) : n;
             const bool more = (nbase < n) && (nbase >= 0);
@@ -239,22 +273,25 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
             const char* nxb = reinterpret_cast<const char*>(xval + (size_t)nbase * (size_t)fixed_s);
             const char* nrb = reinterpret_cast<const char*>(ir + (size_t)nbase * (size_t)fixed_s);
             double accA = 0.0, accB = 0.0; // two +0.0f each
-            float xAn, xBn;
-            int rAn, rBn;
+            double xAn, xBn;
+            int rA0n, rA1n, rB0n, rB1n;
             for (int b = 0; b + 1 < nbatches; b++) {
-                xb += 16 * 4;
-                rb += 16 * IRB;
-                screen2p<16, IRB>(koff, rA * 128, pack_xx(xA), rB * 128, pack_xx(xB), accA, accB, xb, rb, voxA, voxB,
-                                  vorA, vorB, xAn, xBn, rAn, rBn);
-                xA = xAn; xB = xBn; rA = rAn; rB = rBn;
+                xb += 32 * 4;
+                rb += 32 * IRB;
+                screen32p<32, IRB>(koff, pack2((unsigned)rA0 * 128u, (unsigned)rA1 * 128u), xpA,
+                                   pack2((unsigned)rB0 * 128u, (unsigned)rB1 * 128u), xpB, accA, accB, xb, rb, voxA,
+                                   voxB, vorA, vorB, xAn, xBn, rA0n, rA1n, rB0n, rB1n);
+                xpA = xAn; xpB = xBn; rA0 = rA0n; rA1 = rA1n; rB0 = rB0n; rB1 = rB1n;
             }
-            if (tail == 16)
-                screen2p<16, IRB>(koff, rA * 128, pack_xx(xA), rB * 128, pack_xx(xB), accA, accB, nxb, nrb, nvoxA,
-                                  nvoxB, nvorA, nvorB, xAn, xBn, rAn, rBn);
+            if (tail == 32)
+                screen32p<32, IRB>(koff, pack2((unsigned)rA0 * 128u, (unsigned)rA1 * 128u), xpA,
+                                   pack2((unsigned)rB0 * 128u, (unsigned)rB1 * 128u), xpB, accA, accB, nxb, nrb, nvoxA,
+                                   nvoxB, nvorA, nvorB, xAn, xBn, rA0n, rA1n, rB0n, rB1n);
             else
-                RunScreenP<15, IRB>::run(tail, koff, rA * 128, pack_xx(xA), rB * 128, pack_xx(xB), accA, accB, nxb,
-                                         nrb, nvoxA, nvoxB, nvorA, nvorB, xAn, xBn, rAn, rBn);
-            xA = xAn; xB = xBn; rA = rAn; rB = rBn;
+                RunScreen32P<31, IRB>::run(tail, koff, pack2((unsigned)rA0 * 128u, (unsigned)rA1 * 128u), xpA,
+                                           pack2((unsigned)rB0 * 128u, (unsigned)rB1 * 128u), xpB, accA, accB, nxb, nrb,
+                                           nvoxA, nvoxB, nvorA, nvorB, xAn, xBn, rA0n, rA1n, rB0n, rB1n);
+            xpA = xAn; xpB = xBn; rA0 = rA0n; rA1 = rA1n; rB0 = rB0n; rB1 = rB1n;
 
             const int iA = base + slot, iB = base + PPW + slot;
             store_screen_winner(accA, slot, kk, g * SCREEN_KT, K, iA, iA < n, m1o, m2o, ko);

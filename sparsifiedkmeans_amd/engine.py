@@ -49,7 +49,7 @@ class Shard:
     def from_device(cls, ctx: Context, p: int, jc: torch.Tensor, ir: torch.Tensor, x: torch.Tensor,
                     nnz: int | None = None) -> "Shard":
         """Adopt device tensors: jc int64[n+1], ir int16/uint16 or int32, x float64.  ``nnz`` is the
-        number of stored entries; ir / x may be longer (>= nnz + 16 unlocks the fixed-stride kernel)."""
+        number of stored entries; ir / x may be longer (>= nnz + 16 unlocks the fixed-stride exact kernel, >= nnz + 48 the screen)."""
         assert jc.dtype == torch.int64 and x.dtype == torch.float64 and jc.is_cuda and x.is_cuda and ir.is_cuda
         bits = ir.element_size() * 8
         n = jc.numel() - 1
@@ -219,8 +219,8 @@ class StreamingSparsifier:
             raise NotImplementedError("the fused sampler sits behind the Hadamard sketch (power-of-two row count)")
         dev = torch.device("cuda", ctx.device)
         self.sign = sign
-        self.ir = torch.zeros(self.n * self.s + 16, dtype=torch.int16 if self.p2 <= 65536 else torch.int32, device=dev)
-        self.x = torch.zeros(self.n * self.s + 16, dtype=torch.float64, device=dev)
+        self.ir = torch.zeros(self.n * self.s + 48, dtype=torch.int16 if self.p2 <= 65536 else torch.int32, device=dev)
+        self.x = torch.zeros(self.n * self.s + 48, dtype=torch.float64, device=dev)
         self.filled = 0
         self._buf = None
 

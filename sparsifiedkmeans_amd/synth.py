@@ -98,9 +98,9 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
     sign = torch.sign(torch.randn(p2, generator=g0, device=dev, dtype=torch.float64))
     sign[sign == 0] = 1.0
     ir_dtype = torch.int16 if p2 <= 65536 else torch.int32   # int16 storage is read as uint16 row ids
-    # 16 entries of slack: the fixed-stride kernel reads (and ignores) up to 15 entries past a column
-    x = torch.zeros(n_local * s + 16, dtype=torch.float64, device=dev)
-    ir = torch.zeros(n_local * s + 16, dtype=ir_dtype, device=dev)
+    # 48 entries of slack: the fixed-stride kernels read (and ignore) up to 33 entries past a column
+    x = torch.zeros(n_local * s + 48, dtype=torch.float64, device=dev)
+    ir = torch.zeros(n_local * s + 48, dtype=ir_dtype, device=dev)
     premul = float(1.0 + 2.0 * EPS)
     postdiv = float(np.sqrt(np.float64(p2)))
     last = first + n_local
