@@ -783,10 +783,13 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const size_t fixed_lds = (size_t)p * 20 + 16;
     int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 64) / nw / per_pt);
     pts = std::max(8, pts & ~7);
+    if (const char* ev = getenv("SPKM_PTS")) pts = std::max(8, atoi(ev) & ~7);
     const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
     auto k2 = k_exact_accumulate<IR>;
     HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    const int ab = std::min(max_items, std::max(1, ctx->num_cus));
+    int per_cu = 1;
+    if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
+    const int ab = std::min(max_items, std::max(1, ctx->num_cus) * per_cu);
     if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;
