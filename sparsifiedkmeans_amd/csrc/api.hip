@@ -59,7 +59,12 @@ struct spkm_shard {
     uint64_t slack = 0; // entries readable past nnz in ir / x
     double* xn1 = nullptr; // per-point sum |x| and sum x^2 (screen error bound), built on first use
     double* xn2 = nullptr;
-    float* xf = nullptr;   // f32 copy of x for the screen (with the same 16 entries of slack)
+    float* xf = nullptr;   // f32 copy of x for the screen (with the same slack)
+    // screen bookkeeping of THIS data set (see spkm_assign_accumulate_dev)
+    unsigned* h_nlist = nullptr; // pinned: uncertified count of the previous screen call, copied back asynchronously
+    hipEvent_t ev_nlist = nullptr;
+    bool nlist_pending = false;
+    int exact_cooldown = 0;      // calls left on the all-exact kernels after a poorly certifying screen
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -286,6 +291,8 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xn1) (void)hipFree(s->xn1);
     if (s->xn2) (void)hipFree(s->xn2);
     if (s->xf) (void)hipFree(s->xf);
+    if (s->h_nlist) (void)hipHostFree(s->h_nlist);
+    if (s->ev_nlist) (void)hipEventDestroy(s->ev_nlist);
     if (s->owned) {
         if (s->jc) (void)hipFree(s->jc);
         if (s->ir) (void)hipFree(s->ir);
@@ -815,11 +822,31 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
-    if (s->n > 0 && screen_eligible(ctx, s, (int)K64)) {
+    spkm_shard* sm = const_cast<spkm_shard*>(s);
+    // The screen pays K-fold exact work for every point it cannot certify.  Its count is copied back
+    // asynchronously and looked at one call later (no host sync on the hot path): if more than 5 % of the
+    // points needed the exact list, the next 8 calls use the all-exact kernels, then the screen is retried.
+    if (sm->nlist_pending && hipEventQuery(sm->ev_nlist) == hipSuccess) {
+        sm->nlist_pending = false;
+        ctx->last_listed = *sm->h_nlist;
+        if ((double)ctx->last_listed > 0.05 * (double)s->n) sm->exact_cooldown = 8;
+    }
+    const bool cooling = sm->exact_cooldown > 0;
+    if (cooling) sm->exact_cooldown--;
+    if (s->n > 0 && !cooling && screen_eligible(ctx, s, (int)K64)) {
         ctx->ev_valid = false;
         rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce)
                                 : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce);
         if (rc) return rc;
+        if (!sm->h_nlist) {
+            HIP_TRY(hipHostMalloc((void**)&sm->h_nlist, 64, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
+        }
+        if (!sm->nlist_pending) {
+            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
+            sm->nlist_pending = true;
+        }
         if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return SPKM_OK;

@@ -81,3 +81,18 @@ def test_near_ties_sqrt_collapse(gpu_ctx, oracle):
     a, d, _, _ = run_assign(gpu_ctx, X, Cm, 0.0)
     ra, rd = oracle.assign(p, n, *parts(X), Cm, 0.0)
     assert np.array_equal(a, ra) and np.array_equal(d, rd)
+
+
+@pytest.mark.parametrize("p,n,K,s", [(64, 3000, 1000, 8), (256, 2000, 513, 13)])
+def test_many_centroids(gpu_ctx, oracle, p, n, K, s):
+    """K far above one tile: 63 exact tiles / 32 screen tiles on 256 workgroups."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    X = random_csc(p, n, s, seed=K)
+    Cm = np.random.default_rng(K).standard_normal((p, K))
+    a, d, _, nk = run_assign(gpu_ctx, X, Cm, s / p)
+    ra, rd = oracle.assign(p, n, *parts(X), Cm, s / p)
+    assert np.array_equal(a, ra) and np.array_equal(d, rd)
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, X), K, s / p)
+    eng.assign_accumulate_step(torch.tensor(np.ascontiguousarray(Cm.T), device="cuda:0"))
+    assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)

@@ -115,3 +115,26 @@ def test_full_lloyd_with_screen_matches_oracle_loop(gpu_ctx, oracle):
         assert np.abs(got - ref["centers"]).max() <= 1e-6 * np.abs(ref["centers"]).max()
         assert abs(np.sqrt(out[1]) - ref["obj"][0]) <= 1e-12 * ref["obj"][0]
         Cref = ref["centers"]
+
+
+def test_poorly_certifying_screen_backs_off_to_exact_kernels(gpu_ctx, oracle):
+    """When more than 5 % of the points need the exact list, later iterations use the all-exact kernels
+    (decided one call late, from an asynchronous copy of the count); results stay exact throughout."""
+    import time
+
+    p, n, K = 128, 3000, 20
+    X = random_csc(p, n, 9, seed=3)
+    X.data *= 1e30                                            # nothing certifies (f32 overflow)
+    Cm = np.random.default_rng(2).standard_normal((p, K)) * 1e30
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, X), K, 9 / 128)
+    centers = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda:0")
+    paths = []
+    for it in range(4):
+        eng.assign_accumulate_step(centers)
+        torch.cuda.synchronize()
+        time.sleep(0.01)
+        paths.append(eng.last_path_info()[0])
+        _check(eng, oracle, X, Cm, 9 / 128)
+    assert paths[0] == 1 and 0 in paths[1:]
