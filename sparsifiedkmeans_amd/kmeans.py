@@ -13,6 +13,12 @@ not bit-comparable with a MATLAB run.  Given the same random products the Lloyd 
 is: assignments bit-exact, centroids within 1e-6 relative (tests/).
 
 Indices follow the reference: IDX is 1-based (values 1..K).
+
+Multi-GPU (one process per GPU, torch.distributed initialised): every rank calls kmeans_sparsified with ITS
+block of points, the same ``rng`` seed, ``first`` = global index of its first point and ``n_total``.  Random
+products are drawn identically on all ranks; the sample of a point depends on (seed, global index) only, so
+the run clusters exactly the dataset a single process would.  IDX / D come back for the local block, C and
+SUMD are global.
 """
 from __future__ import annotations
 
@@ -23,6 +29,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
+from . import distributed as D_
 from . import synth
 from .engine import LloydEngine, Shard, StreamingSparsifier, mix_device, torch_context
 
@@ -34,7 +41,7 @@ _DEFAULTS = dict(
     SparsityLevel=0.01, SketchType="auto", EmptyAction="singleton", ColumnSamples=False, MLcorrection=True,
     DataFile=None, MB_limit=500, DataFileVerbose=False, SparsityIgnoreUpsampling=False, FORCE_BUG=False,
     tryBuiltinMex=True, unbiasedDistance=True, unbiasedInitialization=True, denseCenters=False)
-_EXTRA = dict(rng=None, device=None, nargout=5)  # Python-side additions (not reference options)
+_EXTRA = dict(rng=None, device=None, nargout=5, first=0, n_total=None)  # Python-side additions (not reference options)
 
 
 def _parse(opts: dict) -> dict:
@@ -157,7 +164,12 @@ def kmeans_sparsified(X, K, **options):
         if not o["ColumnSamples"]:
             X = X.T                                                                 # :214-216 (points become columns)
         p, n = X.shape
-    if n < K:
+    dist_on = D_.is_distributed()
+    first = int(o["first"]) if dist_on else 0
+    n_glob = int(o["n_total"]) if (dist_on and o["n_total"]) else n
+    if dist_on and o["n_total"] is None:
+        raise ValueError("distributed run: pass n_total (and first) so that all ranks agree on the dataset")
+    if n_glob < K:
         raise ValueError("X must have more samples than the number of clusters.")  # :219-221
 
     # ---- sketch (:224-296) ----
@@ -191,7 +203,7 @@ def kmeans_sparsified(X, K, **options):
         # device sparsifier: chunk -> X*(1+2eps) -> mix -> sample -> resident CSC (kmeans_sparsified.m:292-334;
         # for 'DataFile': sampleAndMixFromLargeFile.m:100-129).  The dense mixed data never reaches HBM.
         t1 = time.time()
-        sp_ = StreamingSparsifier(ctx, p, n, small_p, sample_seed, sketch.sign, first=0)
+        sp_ = StreamingSparsifier(ctx, p, n, small_p, sample_seed, sketch.sign, first=first)
         nn = max(1, min(n, int(o["MB_limit"] * 2**20 // (8 * p))))               # sampleAndMixFromLargeFile.m:82-84
         if LoadFromDisk and o["DataFileVerbose"]:
             print(f"Splitting {p} x {n} matrix into {-(-n // nn)} {p} x {nn} chunks")
@@ -222,8 +234,8 @@ def kmeans_sparsified(X, K, **options):
         print(f"Randomly mixing of type {sk}")
         print(f"Randomly taking {100 * gamma:.1f}% of the data; actual dataset is {100 * nnz / (p2 * n):.1f}% sparse")
 
-    def column(i):
-        """dense copy of sparse column i (for 'sample' / k-means++ starts and EmptyAction='singleton')"""
+    def local_column(i):
+        """dense copy of local sparse column i"""
         if Y is not None:
             return Y[:, i].toarray().ravel()
         o_ = i * small_p
@@ -231,6 +243,18 @@ def kmeans_sparsified(X, K, **options):
         col = np.zeros(p2)
         col[rows.astype(np.int64)] = sp_.x[o_:o_ + small_p].cpu().numpy()
         return col
+
+    def column(gi):
+        """dense copy of the sparse column with GLOBAL index gi ('sample' / k-means++ starts,
+        EmptyAction='singleton'); in a distributed run its owner broadcasts it"""
+        if not dist_on:
+            return local_column(gi)
+        mine = first <= gi < first + n
+        flag = torch.tensor([float(torch.distributed.get_rank()) if mine else -1.0], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        col = torch.tensor(local_column(gi - first), device=dev) if mine else torch.zeros(p2, dtype=torch.float64, device=dev)
+        D_.broadcast_column(col, int(flag.item()))
+        return col.cpu().numpy()
 
     unbiased = bool(o["unbiasedDistance"])                                       # :369-373
     start = o["Start"]
@@ -243,6 +267,10 @@ def kmeans_sparsified(X, K, **options):
         mn, mx = float(vals.min(initial=0.0)), float(vals.max(initial=0.0))      # full(min(X(:))) incl. implicit zeros
         if nnz < p2 * n:
             mn, mx = min(mn, 0.0), max(mx, 0.0)
+        if dist_on:
+            mm = torch.tensor([-mn, mx], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(mm, op=torch.distributed.ReduceOp.MAX)
+            mn, mx = -float(mm[0].item()), float(mm[1].item())
 
     best = dict(obj=np.inf)
     distances = None
@@ -253,14 +281,14 @@ def kmeans_sparsified(X, K, **options):
         if isinstance(start, str):
             s = start.lower()
             if s == "sample":
-                ind = rng.choice(n, K, replace=False)                            # randsample(n,K) (:387)
+                ind = rng.choice(n_glob, K, replace=False)                       # randsample(n,K) (:387)
                 centers_np = np.stack([column(int(i)) for i in ind], axis=1)
                 sparse_mask = (centers_np != 0).astype(np.uint8)
             elif s == "uniform":
                 centers_np = (mx - mn) * rng.random((p2, K)) - mn                # :390 (the reference subtracts mn)
             elif s in ("arthur", "++", "kmeans++", "k-means++", "k-means-++"):
                 g_init = gamma if o["unbiasedInitialization"] else None          # :392-396
-                centers_np, sparse_mask = _arthur(ctx, shard, column, n, K, g_init, rng)
+                centers_np, sparse_mask = _arthur(ctx, shard, column, n, K, g_init, rng, first, n_glob, dist_on)
             else:
                 raise ValueError('cannot handle other types of "Start" values')  # :398
         else:
@@ -300,7 +328,8 @@ def kmeans_sparsified(X, K, **options):
                 if act == "error":
                     raise RuntimeError("One cluster lost all its members")      # :439
                 if act == "singleton":
-                    imax = int(eng.stats[2].item())                              # [~,iMax] = max(distances) (:436)
+                    st = eng.stats.cpu().numpy()                                 # [~,iMax] = max(distances) (:436)
+                    _, imax, _ = D_.global_first_argmax(float(st[1]), int(st[2]), first)
                     col = torch.tensor(column(imax), device=dev)
                     for ki in empty:
                         centers[ki] = col                                        # centers(:,ki) = X(:,iMax) (:437)
@@ -346,6 +375,10 @@ def kmeans_sparsified(X, K, **options):
     SUMD = np.zeros(Kb)
     for ki in range(Kb):                                                         # :514-518: the LAST trial's distances
         SUMD[ki] = np.sum(distances[IDX == ki + 1] ** 2) if IDX.size else 0.0
+    if dist_on:                                                                  # SUMD is a sum over all points
+        sd = torch.tensor(SUMD, dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(sd, op=torch.distributed.ReduceOp.SUM)
+        SUMD = sd.cpu().numpy()
     OUTPUT["TimeOverall_OnePass"] = time.time() - t0
     Cout = sketch.unmix(best["centers"]).cpu().numpy().T                         # p x K (:523)
     D = best["dist"]
@@ -355,18 +388,20 @@ def kmeans_sparsified(X, K, **options):
     return IDX, Cout, SUMD, D, OUTPUT
 
 
-def _arthur(ctx, shard, column, n, K, gamma, rng):
+def _arthur(ctx, shard, column, n, K, gamma, rng, first=0, n_glob=None, dist_on=False):
     """K-means++ seeding, private/Arthur_initialization.m:24-69: first centre uniform; then K-1 rounds of
     [~,dist] = findClusterAssignments(X, full(centres), [], gamma) and a draw ∝ dist.^2 with the 400-retry
     duplicate rule.  The reference recomputes the distances to ALL chosen centres every round (K^2/2
     centre evaluations); since min() is exact and each (point, centre) distance does not depend on the other
     centres, keeping a running minimum and evaluating only the NEW centre gives the same ``dist`` vector bit for
-    bit at 1/K of the work.  Everything stays on the device; the draw is a cumulative sum + binary search.
+    bit at 1/K of the work.  Everything stays on the device; the draw is a cumulative sum + binary search
+    (distributed: the rank is picked from the all-gathered block totals first, with the same random number).
     Returns (p2 x K dense values, p2 x K support mask): the centres are columns of the sparse X (:36,68)."""
     if K < 1:
         raise ValueError("K must be >= 1")
+    n_glob = n if n_glob is None else n_glob
     dev = f"cuda:{ctx.device}"
-    chosen = [int(rng.integers(n))]                                              # randi(n,1) (:35)
+    chosen = [int(rng.integers(n_glob))]                                         # randi(n,1) (:35)
     cols = [column(chosen[0])]
     eng = LloydEngine(shard, 1, gamma if gamma else 1.0, unbiased=bool(gamma))
     dist = None
@@ -374,15 +409,32 @@ def _arthur(ctx, shard, column, n, K, gamma, rng):
         c_new = torch.tensor(cols[-1][None, :], device=dev)                      # full(ref) (:31,39), newest centre only
         eng.assign_step(c_new)
         dist = eng.mind.clone() if dist is None else torch.minimum(dist, eng.mind)
-        w = dist * dist
-        cum = torch.cumsum(w, 0)
-        total = float(cum[-1].item())
+        cum = torch.cumsum(dist * dist, 0)
+        local_total = float(cum[-1].item()) if n > 0 else 0.0
+        if dist_on:
+            world = torch.distributed.get_world_size()
+            tt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            torch.distributed.all_gather(tt, torch.tensor([local_total], dtype=torch.float64, device=dev))
+            totals = np.array([float(t.item()) for t in tt])
+        else:
+            totals = np.array([local_total])
+        total = float(totals.sum())
+        edges = np.concatenate([[0.0], np.cumsum(totals)])
 
         def draw():
             if total > 0:                                                        # norm(dist) > 0 (:49)
-                t = torch.tensor([rng.random() * total], dtype=torch.float64, device=dev)
-                return int(min(torch.searchsorted(cum, t, right=True).item(), n - 1))
-            return int(rng.integers(n))
+                u = rng.random() * total                                         # same number on every rank
+                r = int(min(np.searchsorted(edges, u, side="right") - 1, len(totals) - 1))
+                if not dist_on:
+                    t = torch.tensor([u], dtype=torch.float64, device=dev)
+                    return int(min(torch.searchsorted(cum, t, right=True).item(), n - 1))
+                gi = torch.zeros(1, dtype=torch.float64, device=dev)
+                if torch.distributed.get_rank() == r:
+                    t = torch.tensor([u - edges[r]], dtype=torch.float64, device=dev)
+                    gi[0] = float(first + int(min(torch.searchsorted(cum, t, right=True).item(), n - 1)))
+                torch.distributed.broadcast(gi, src=r)
+                return int(gi.item())
+            return int(rng.integers(n_glob))
 
         i = draw()
         counter = 1
