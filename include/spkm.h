@@ -174,6 +174,23 @@ int spkm_mix_sample_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, cons
                         const double *d_sign, double premul, double postdiv, uint64_t s, uint64_t seed,
                         uint64_t col0, void *d_ir_out, int ir_bits, double *d_x_out);
 
+/* Dense (unsampled) data behind the reference's two-pass outputs.
+ * d_X: n x p, point i at d_X + i*p (= column-major p x n); d_centers: K x p, centre k at d_centers + k*p.
+ *
+ * spkm_dense_assign_dev replaces findClusterAssignments(full(X), centers), dense branch, expanded quadratic
+ * (private/findClusterAssignments.m:157-165,168-171; called from kmeans_sparsified.m:558 and
+ * private/recalculateAssignmentLargeFile.m:96): d_dist[i] = min_k sqrt(|x_i|^2 - 2 x_i'c_k + |c_k|^2),
+ * d_assign[i] = first k attaining it (0-based).  The Gram block runs on the f64 matrix cores.
+ *
+ * spkm_dense_accumulate_dev replaces the numerators / counts of mean(full(XFull(:,ind)),2)
+ * (kmeans_sparsified.m:545-550; recalculateAssignmentLargeFile.m:100-107): d_sums[k*p + r] += sum of
+ * X(r, i) over points with d_assign[i] == k, d_counts[k] += their number.  Both outputs ACCUMULATE so that
+ * a file can be streamed through in chunks; zero them first.  d_assign values must lie in [0, K). */
+int spkm_dense_assign_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, const double *d_X, uint64_t K,
+                          const double *d_centers, int32_t *d_assign, double *d_dist);
+int spkm_dense_accumulate_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, const double *d_X, uint64_t K,
+                              const int32_t *d_assign, double *d_sums, double *d_counts);
+
 /* Timing hooks for bench.py: hipEvents recorded on the context's stream around the dominant
  * kernel of the last spkm_assign_dev call.  Returns its duration in milliseconds (blocks). */
 int spkm_last_assign_kernel_ms(spkm_ctx *ctx, double *ms);

@@ -93,3 +93,33 @@ def sylvester(m):
     while H.shape[0] < m:
         H = np.block([[H, H], [H, -H]])
     return H
+
+
+def dense_assign(X, Cmat):
+    """private/findClusterAssignments.m:157-165 (expanded quadratic, dense X) + :168-171 (min, first index):
+    distances(k,:) = nrm2 - 2*(X'*c_k)' + norm(c_k)^2 ; sqrt ; [distances, assignments] = min(distances,[],1).
+    X is p x n, Cmat p x K.  Returns (assignments 0-based, distances).  The summation order inside X'*c and
+    norm() is the BLAS's in the reference (undefined): tests compare to a tolerance.  Rounded values below 0
+    are clamped before the sqrt (MATLAB would go complex)."""
+    X = np.asarray(X, np.float64)
+    Cmat = np.asarray(Cmat, np.float64)
+    nrm2 = np.sum(X * X, axis=0)
+    K = Cmat.shape[1]
+    d = np.empty((K, X.shape[1]))
+    for k in range(K):
+        c = Cmat[:, k]
+        d[k] = nrm2 - 2.0 * (X.T @ c) + np.linalg.norm(c) ** 2
+    d = np.sqrt(np.maximum(d, 0.0))
+    a = np.argmin(d, axis=0)
+    return a, d[a, np.arange(X.shape[1])], d
+
+
+def two_pass_centers(X, assign0, K):
+    """kmeans_sparsified.m:543-550: centers_twoPass(:,k) = mean(full(XFull(:,ind)),2), zeros for empty clusters."""
+    X = np.asarray(X, np.float64)
+    out = np.zeros((X.shape[0], K))
+    for k in range(K):
+        ind = np.flatnonzero(np.asarray(assign0) == k)
+        if ind.size:
+            out[:, k] = X[:, ind].mean(axis=1)
+    return out

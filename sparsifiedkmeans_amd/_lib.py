@@ -103,6 +103,8 @@ def lib():
     L.spkm_fwht_dev.argtypes = [_vp, _u64, _u64, _vp, _vp]
     L.spkm_mix_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _dbl, _dbl, _vp]
     L.spkm_mix_sample_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _dbl, _dbl, _u64, _u64, _u64, _vp, C.c_int, _vp]
+    L.spkm_dense_assign_dev.argtypes = [_vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp]
+    L.spkm_dense_accumulate_dev.argtypes = [_vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp]
     L.spkm_last_assign_kernel_ms.argtypes = [_vp, C.POINTER(_dbl)]
     L.spkm_timing_log.argtypes = [_vp, C.c_int]
     L.spkm_timing_read.argtypes = [_vp, C.POINTER(_dbl), C.c_int, C.POINTER(C.c_int)]

@@ -6,6 +6,7 @@
 #include "update.hip"
 #include "screen.hip"
 #include "sample.hip"
+#include "dense.hip"
 
 #include "../../include/spkm.h"
 
@@ -32,7 +33,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -150,7 +151,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -685,15 +686,38 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
 // ------------------------------------------------------------------------------------------
 // fused iteration front half: assignment + accumulation (everything before the all-reduce)
 // ------------------------------------------------------------------------------------------
+// Number of tiles for the entry-parallel screen: the smallest G >= ceil(K/32) whose largest tile
+// ((p+1) rows of an odd number of 16-B slots) fits in LDS, as long as a tile still holds >= 16 centroids
+// (or all of them).  0: not usable.
+static int screen_rows_tiles(const spkm_ctx* ctx, uint64_t p, int K)
+{
+    const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const int P = (K + 1) / 2;
+    for (int G = (K + 31) / 32; G <= nb && G <= P; G++) {
+        const int kp = (P + G - 1) / G;
+        if (kp < 8 && G > 1) return 0;
+        if ((p + 1) * (uint64_t)screen_rows_slots(kp) * 16 + 16 <= ctx->lds_max) return G;
+    }
+    return 0;
+}
+
+// The entry-parallel screen holds a point's entries in registers: up to 64 per column.
+static bool screen_use_rows(const spkm_ctx* ctx, const spkm_shard* s, int K)
+{
+    if (!getenv("SPKM_SCREEN_ROWS")) return false; // experimental: slower than the tiled screen (LDS bank conflicts)
+    return s->fixed_s <= 64 && screen_rows_tiles(ctx, s->p, K) > 0;
+}
+
 static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
 {
     if (getenv("SPKM_NO_SCREEN")) return false;
     if (s->fixed_s <= 0 || s->slack < 48 || s->nnz == 0) return false; // the screen reads up to 33 entries past a column
     if (K <= 16) return false; // a single exact tile already streams X once
-    if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
-    const int G = (K + SCREEN_KT - 1) / SCREEN_KT;
-    const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    if (G > nb) return false;
+    if (!screen_use_rows(ctx, s, K)) { // first-generation tiled screen
+        if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
+        const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        if ((K + SCREEN_KT - 1) / SCREEN_KT > nb) return false;
+    }
     // phase 2 needs the centroid column + slab + at least 8 staged points per wave
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     if (s->p * 20 + 64 + 16 * 8 * per_pt > ctx->lds_max) return false;
@@ -706,7 +730,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
-    const int G = (K + SCREEN_KT - 1) / SCREEN_KT;
+    const bool rows = screen_use_rows(ctx, s, K);
+    const int G = rows ? screen_rows_tiles(ctx, s->p, K) : (K + SCREEN_KT - 1) / SCREEN_KT;
     const size_t pk = (size_t)p * K;
     double* sums = d_reduce;
     double* counts = d_reduce + pk;
@@ -724,7 +749,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                            sm->xf);
     }
     if ((rc = build_blockmap(ctx, G))) return rc;
-    const size_t tile_floats = (size_t)G * (p + 1) * SCREEN_KT;
+    const size_t tile_floats = (size_t)G * (p + 1) * (rows ? SCREEN_ROWS_MAX_STRIDE : SCREEN_KT);
     if ((rc = ensure(ctx, ctx->t32, tile_floats * 4))) return rc;
     if ((rc = ensure(ctx, ctx->cmax, 64))) return rc;
     if ((rc = ensure(ctx, ctx->scr_m1, (size_t)G * n * 4))) return rc;
@@ -739,9 +764,14 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
-    hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
-                       0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
-                       (unsigned long long*)ctx->cmax.p);
+    if (rows)
+        hipLaunchKernelGGL(k_prep_rows_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)),
+                           dim3(256), 0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
+                           (unsigned long long*)ctx->cmax.p);
+    else
+        hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)),
+                           dim3(256), 0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
+                           (unsigned long long*)ctx->cmax.p);
     hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0,
                        ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
     // 1. screen
@@ -749,14 +779,26 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     long long chunk = n / ((long long)ctx->bmap_streams * 8);
     chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
     chunk = (chunk / sweep) * sweep;
-    const size_t lds = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
-    auto kern = k_screen_tile<IR>;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(timing_begin(ctx));
-    hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const IR*)s->ir,
-                       (const float*)s->xf, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K,
-                       (const spkm_blockmap*)ctx->bmap.p, (int)chunk, (float*)ctx->scr_m1.p, (float*)ctx->scr_m2.p,
-                       (int*)ctx->scr_k.p);
+    if (rows) {
+        const int kp_max = ((K + 1) / 2 + G - 1) / G;
+        const size_t lds = (size_t)(p + 1) * screen_rows_slots(kp_max) * 16 + 16;
+        auto kern = k_screen_rows<IR>;
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(timing_begin(ctx));
+        hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const IR*)s->ir,
+                           (const float*)s->xf, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K, G,
+                           (const spkm_blockmap*)ctx->bmap.p, (int)chunk, (float*)ctx->scr_m1.p,
+                           (float*)ctx->scr_m2.p, (int*)ctx->scr_k.p);
+    } else {
+        const size_t lds = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
+        auto kern = k_screen_tile<IR>;
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(timing_begin(ctx));
+        hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const IR*)s->ir,
+                           (const float*)s->xf, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K,
+                           (const spkm_blockmap*)ctx->bmap.p, (int)chunk, (float*)ctx->scr_m1.p,
+                           (float*)ctx->scr_m2.p, (int*)ctx->scr_k.p);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(timing_end(ctx));
     // 2. certification, 3. exact evaluation of the uncertified points
@@ -1113,5 +1155,69 @@ extern "C" int spkm_SparseMatrixColumnNormSq_host(spkm_ctx* ctx, uint64_t n, con
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(nx2, dn.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SPKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense (unsampled) data: two-pass outputs
+// ------------------------------------------------------------------------------------------
+extern "C" int spkm_dense_assign_dev(spkm_ctx* ctx, uint64_t p64, uint64_t n64, const double* d_X, uint64_t K64,
+                                     const double* d_centers, int32_t* d_assign, double* d_dist)
+{
+    if (!ctx || !d_X || !d_centers || !d_assign || !d_dist) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536 || p64 == 0 || p64 > (1u << 24) || n64 > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n64 == 0) return SPKM_OK;
+    const int p = (int)p64, K = (int)K64;
+    const long long n = (long long)n64;
+    int rc;
+    if ((rc = ensure(ctx, ctx->dn_x, (size_t)n * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->dn_c, (size_t)K * 8))) return rc;
+    const int wb = (int)std::min<long long>(4096, (n + 3) / 4);
+    hipLaunchKernelGGL(k_rows_normsq, dim3(wb), dim3(256), 0, ctx->stream, d_X, n, p, (double*)ctx->dn_x.p);
+    hipLaunchKernelGGL(k_rows_normsq, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, d_centers, (long long)K, p,
+                       (double*)ctx->dn_c.p);
+    const size_t lds = (size_t)(DA_PTS + DA_KP) * DA_LD * 8;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_dense_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_dense_assign, dim3((unsigned)((n + DA_PTS - 1) / DA_PTS)), dim3(256), lds, ctx->stream, d_X, n, p,
+                       d_centers, K, (const double*)ctx->dn_x.p, (const double*)ctx->dn_c.p, (int*)d_assign, d_dist);
+    HIP_TRY(hipGetLastError());
+    return SPKM_OK;
+}
+
+extern "C" int spkm_dense_accumulate_dev(spkm_ctx* ctx, uint64_t p64, uint64_t n64, const double* d_X, uint64_t K64,
+                                         const int32_t* d_assign, double* d_sums, double* d_counts)
+{
+    if (!ctx || !d_X || !d_assign || !d_sums || !d_counts) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536 || p64 == 0 || p64 > (1u << 24) || n64 > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n64 == 0) return SPKM_OK;
+    const int p = (int)p64, K = (int)K64;
+    const long long n = (long long)n64;
+    int rc;
+    const int seg = 256;
+    const int max_items = (int)(n / seg) + K + 1;
+    if ((rc = ensure(ctx, ctx->dn_nk, (size_t)K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->perm, (size_t)n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->offs, (size_t)(K + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->dn_nk.p, 0, (size_t)K * 8, ctx->stream));
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
+                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->dn_nk.p);
+    hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->dn_nk.p, K, seg,
+                       (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                       (int*)ctx->nitems.p);
+    const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
+    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+    hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
+                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
+    const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
+    hipLaunchKernelGGL(k_dense_accumulate, dim3(ab), dim3(256), 0, ctx->stream, d_X, p, (const int*)ctx->perm.p,
+                       (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)ctx->nitems.p, d_sums);
+    hipLaunchKernelGGL(k_nk_add_f64, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ctx->dn_nk.p, K, d_counts);
+    HIP_TRY(hipGetLastError());
     return SPKM_OK;
 }

@@ -544,3 +544,243 @@ template __global__ void k_exact_accumulate<unsigned short>(const unsigned short
 template __global__ void k_exact_accumulate<unsigned int>(const unsigned int*, const double*, const int*,
     const long long*, const int4*, const int*, const double*, double, int, int, int, double*, double*, double*,
     double*, double*, long long*);
+
+// ============================================================================================
+// Second screen kernel: lanes <-> stored entries (8 lanes per point, 8 points per wave).
+//
+// The tiled kernels above give each lane a centroid and broadcast the point's entries one by one:
+// 2 of the 4 issue slots per entry go to the DPP broadcasts (x, LDS address).  For the f32 SCREEN the
+// summation order is free, so the roles can be swapped: lane e of a point's 8-lane group takes entries
+// e, e+8, e+16, ... and walks the tile's centroids for each of them -- x and the row offset are
+// lane-local, the centroid values of row r come from LDS with IMMEDIATE offsets (no address math):
+//     q  = LDS[r*RS + 16*c]                  ds_read_b128     (4 centroids)
+//     t  = q + (x, x)                        v_pk_add_f32 x2
+//     acc[.] = t*t + acc[.]                  v_pk_fma_f32 x2
+// i.e. one issue slot per (entry, centroid) instead of two.  At the end the partial sums are all-reduced
+// over the 8 lanes (3 DPP stages).  A tile holds KP centroid PAIRS, 1 <= KP <= 16; the K centroids are
+// split evenly over G = ceil(K/32) tiles (K = 100: 26+26+24+24, no padded slots), every tile gets the
+// same number of workgroups.  Rows are padded to an odd number of 16-B slots so that the 16-B reads of
+// lanes holding different random rows spread over all banks.
+__host__ __device__ constexpr int screen_rows_slots(int kp) { return ((kp + 1) >> 1) | 1; }
+__host__ __device__ inline int screen_rows_pairs(int K, int G, int g, int* k0)
+{
+    const int P = (K + 1) >> 1, base = P / G, rem = P % G;
+    *k0 = 2 * (g * base + (g < rem ? g : rem));
+    return base + (g < rem ? 1 : 0);
+}
+#define SCREEN_ROWS_MAX_STRIDE 36 // floats per row in the global tile buffer (16 pairs + pad)
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// tile g, row r, slot kk: T[(g*(p+1) + r)*36 + kk] = -fl32(C[(k0_g+kk)*p + r] / gamma); row p and padding zero
+__global__ void k_prep_rows_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
+                                float* __restrict__ T, unsigned long long* __restrict__ cmax_bits)
+{
+    const size_t total = (size_t)G * (p + 1) * SCREEN_ROWS_MAX_STRIDE;
+    double mx = 0.0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(t % SCREEN_ROWS_MAX_STRIDE);
+        const size_t rest = t / SCREEN_ROWS_MAX_STRIDE;
+        const int r = (int)(rest % (p + 1));
+        const int g = (int)(rest / (p + 1));
+        int k0;
+        const int kp = screen_rows_pairs(K, G, g, &k0);
+        float v = 0.f;
+        if (r < p && kk < 2 * kp && k0 + kk < K) {
+            double c = C[(size_t)(k0 + kk) * p + r];
+            if (gamma > 0.0) c = c / gamma;
+            mx = fmax(mx, fabs(c));
+            v = -(float)c;
+        }
+        T[t] = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(cmax_bits, __builtin_bit_cast(unsigned long long, mx));
+}
+
+template <int SEL> __device__ __forceinline__ float dpp_f32(float v)
+{
+    const int b = __builtin_bit_cast(int, v);
+    int r;
+    if (SEL == 0) r = __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]: lane ^ 1
+    else if (SEL == 1) r = __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]: lane ^ 2
+    else r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xf, 0xf, false);               // row_half_mirror: i <-> 7-i
+    return __builtin_bit_cast(float, r);
+}
+
+// min over the 8-lane group (3 DPP stages)
+__device__ __forceinline__ float group_min8_f32(float v)
+{
+    asm("s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
+template <int KP, typename IR>
+__device__ __forceinline__ void screen_rows_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
+                                                 int fixed_s, int K, int k0, const spkm_blockmap bm, int chunk_points,
+                                                 float* __restrict__ m1o, float* __restrict__ m2o,
+                                                 int* __restrict__ ko, char* smem, unsigned* ticket)
+{
+    constexpr int PPS = 8; // points per wave step
+    constexpr int RS = screen_rows_slots(KP) * 16;
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 3; // point slot
+    const int e = lane & 7;  // entry lane
+    const int nchunks = (n + chunk_points - 1) / chunk_points;
+    const int R = chunk_points / PPS;
+    const int my_chunks = (nchunks > bm.stream) ? (nchunks - bm.stream + bm.nstreams - 1) / bm.nstreams : 0;
+    const int Tn = my_chunks * R;
+    const int rounds = (fixed_s + 7) >> 3;
+    auto draw = [&]() {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(ticket, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto point_of = [&](int t) { // first point of wave step t (>= n: nothing to do)
+        if (t >= Tn) return n;
+        const int ci = t / R, rr = t - ci * R;
+        const int base = (bm.stream + ci * bm.nstreams) * chunk_points + rr * PPS;
+        return (base < 0 || base > n) ? n : base;
+    };
+    // All entries of a step are loaded at once (RMAX rounds of 8 entries), one step ahead of their use.
+    constexpr int RMAX = 8;
+    float xb[RMAX];
+    int rb[RMAX];
+    auto load_step = [&](int base, float (&xo)[RMAX], int (&ro)[RMAX]) {
+        const int i = base + q;
+        const int ic = i < n ? i : n - 1;
+        const float* xp = xval + (size_t)ic * fixed_s + e;
+        const IR* rp = ir + (size_t)ic * fixed_s + e;
+#pragma unroll
+        for (int rd = 0; rd < RMAX; rd++)
+            if (rd < rounds) { xo[rd] = xp[rd * 8]; ro[rd] = (int)rp[rd * 8]; } // past-the-column reads stay in the slack
+    };
+    int t = draw();
+    int base = point_of(t);
+    if (base < n) load_step(base, xb, rb);
+    while (t < Tn) {
+        const int tn = draw();
+        const int basen = point_of(tn);
+        float xnb[RMAX];
+        int rnb[RMAX];
+        if (basen < n) load_step(basen, xnb, rnb);
+        if (base < n) {
+        const int i = base + q;
+        f2v acc[KP];
+#pragma unroll
+        for (int a = 0; a < KP; a++) acc[a] = f2v{0.f, 0.f};
+#pragma unroll
+        for (int rd = 0; rd < RMAX; rd++) {
+            if (rd < rounds) {
+                const bool ok = rd * 8 + e < fixed_s;
+                const float xv = ok ? xb[rd] : 0.f;
+                const unsigned row = ok ? (unsigned)rb[rd] : (unsigned)p; // zero row: contributes (0 - 0)^2
+                const char* rowp = smem + __umul24(row, (unsigned)RS);
+                const f2v xx = f2v{xv, xv};
+#pragma unroll
+                for (int c = 0; c < KP / 2; c++) {
+                    const f4v qv = *reinterpret_cast<const f4v*>(rowp + 16 * c);
+                    const f2v t0 = f2v{qv.x, qv.y} + xx, t1 = f2v{qv.z, qv.w} + xx;
+                    acc[2 * c] = __builtin_elementwise_fma(t0, t0, acc[2 * c]);
+                    acc[2 * c + 1] = __builtin_elementwise_fma(t1, t1, acc[2 * c + 1]);
+                }
+                if (KP & 1) {
+                    const f2v t0 = *reinterpret_cast<const f2v*>(rowp + 16 * (KP / 2)) + xx;
+                    acc[KP - 1] = __builtin_elementwise_fma(t0, t0, acc[KP - 1]);
+                }
+            }
+        }
+        // all-reduce the sums over the 8 entry lanes
+#pragma unroll
+        for (int a = 0; a < KP; a++) {
+            acc[a].x += dpp_f32<2>(acc[a].x);
+            acc[a].y += dpp_f32<2>(acc[a].y);
+        }
+#pragma unroll
+        for (int a = 0; a < KP; a++) {
+            acc[a].x += dpp_f32<1>(acc[a].x);
+            acc[a].y += dpp_f32<1>(acc[a].y);
+        }
+#pragma unroll
+        for (int a = 0; a < KP; a++) {
+            acc[a].x += dpp_f32<0>(acc[a].x);
+            acc[a].y += dpp_f32<0>(acc[a].y);
+        }
+        // every lane now holds all estimates; lane e looks at centroids e, e+8, ... of the tile, then
+        // min / second-min over the 8 lanes (first index wins ties inside a lane; ties across lanes are
+        // never certified, so which one is reported does not matter)
+        float lo = __builtin_inff(), hi = __builtin_inff();
+        int klo = -1;
+#pragma unroll
+        for (int kk = 0; kk < 2 * KP; kk++) {
+            const float v = (kk & 1) ? acc[kk >> 1].y : acc[kk >> 1].x;
+            const bool mine = (kk & 7) == e && k0 + kk < K;
+            if (mine) {
+                if (v < lo) { hi = lo; lo = v; klo = k0 + kk; }
+                else if (v < hi) hi = v;
+            }
+        }
+        const float m1 = group_min8_f32(lo);
+        const bool win = (lo == m1);
+        const unsigned seg = (unsigned)(__ballot(win) >> (q * 8)) & 0xffu;
+        const int first = seg ? __builtin_ctz(seg) : 0;
+        const float m2 = group_min8_f32((e == first) ? hi : lo);
+        if (e == first && i < n) {
+            const bool none = seg == 0u;
+            m1o[i] = none ? __builtin_inff() : m1;
+            m2o[i] = none ? __builtin_inff() : m2;
+            ko[i] = none ? -1 : klo;
+        }
+        }
+        t = tn;
+        base = basen;
+#pragma unroll
+        for (int rd = 0; rd < RMAX; rd++) { xb[rd] = xnb[rd]; rb[rd] = rnb[rd]; }
+    }
+}
+
+template <typename IR>
+__global__ __launch_bounds__(1024) void k_screen_rows(
+    const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T, int p, int n, int fixed_s,
+    int K, int G, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
+    float* __restrict__ scr_m2, int* __restrict__ scr_k)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const spkm_blockmap bm = bmap[blockIdx.x];
+    if (bm.tile < 0) return;
+    int k0;
+    const int kp = screen_rows_pairs(K, G, bm.tile, &k0);
+    const int slots = screen_rows_slots(kp); // float4 per LDS row
+    const int tid = threadIdx.x;
+    {
+        const float4* src = reinterpret_cast<const float4*>(T + (size_t)bm.tile * (p + 1) * SCREEN_ROWS_MAX_STRIDE);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        const int total = (p + 1) * slots;
+        for (int t = tid; t < total; t += blockDim.x) {
+            const int r = t / slots, c = t - r * slots;
+            dst[t] = src[r * (SCREEN_ROWS_MAX_STRIDE / 4) + c];
+        }
+    }
+    unsigned* ticket = reinterpret_cast<unsigned*>(smem + (size_t)(p + 1) * slots * 16);
+    if (tid == 0) *ticket = 0u;
+    __syncthreads();
+    float* m1o = scr_m1 + (size_t)bm.tile * n;
+    float* m2o = scr_m2 + (size_t)bm.tile * n;
+    int* ko = scr_k + (size_t)bm.tile * n;
+#define SPKM_ROWS_CASE(N) \
+    case N: screen_rows_body<N, IR>(ir, xval, p, n, fixed_s, K, k0, bm, chunk_points, m1o, m2o, ko, smem, ticket); break;
+    switch (kp) {
+        SPKM_ROWS_CASE(1) SPKM_ROWS_CASE(2) SPKM_ROWS_CASE(3) SPKM_ROWS_CASE(4) SPKM_ROWS_CASE(5) SPKM_ROWS_CASE(6)
+        SPKM_ROWS_CASE(7) SPKM_ROWS_CASE(8) SPKM_ROWS_CASE(9) SPKM_ROWS_CASE(10) SPKM_ROWS_CASE(11) SPKM_ROWS_CASE(12)
+        SPKM_ROWS_CASE(13) SPKM_ROWS_CASE(14) SPKM_ROWS_CASE(15) SPKM_ROWS_CASE(16)
+    default: break;
+    }
+#undef SPKM_ROWS_CASE
+}

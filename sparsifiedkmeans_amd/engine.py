@@ -202,6 +202,33 @@ def mix_sample_device(ctx: Context, x: torch.Tensor, p2: int, sign: torch.Tensor
                                               int(col0), _p(ir_out), bits, _p(x_out)), "spkm_mix_sample_dev")
 
 
+def dense_assign_device(ctx: Context, x: torch.Tensor, centers: torch.Tensor):
+    """[assignments, distances] = findClusterAssignments(full(X), centers), dense branch / expanded quadratic
+    (private/findClusterAssignments.m:157-171) for a dense device chunk ``x`` [n, p] and ``centers`` [K, p].
+    Returns (assign int32 0-based [n], dist float64 [n])."""
+    assert x.dtype == torch.float64 and x.is_contiguous() and x.dim() == 2
+    assert centers.dtype == torch.float64 and centers.is_contiguous() and centers.shape[1] == x.shape[1]
+    n, p = x.shape
+    a = torch.empty(n, dtype=torch.int32, device=x.device)
+    d = torch.empty(n, dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib().spkm_dense_assign_dev(ctx.handle, p, n, _p(x), centers.shape[0], _p(centers), _p(a), _p(d)),
+               "spkm_dense_assign_dev")
+    return a, d
+
+
+def dense_accumulate_device(ctx: Context, x: torch.Tensor, assign: torch.Tensor, sums: torch.Tensor,
+                            counts: torch.Tensor):
+    """sums[k] += sum of the rows of ``x`` [n, p] with assign == k, counts[k] += their number: the numerators
+    and denominators of mean(full(XFull(:,ind)),2) (kmeans_sparsified.m:545-550), chunk by chunk."""
+    assert x.dtype == torch.float64 and x.is_contiguous() and x.dim() == 2
+    assert assign.dtype == torch.int32 and assign.is_contiguous() and assign.numel() == x.shape[0]
+    assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.shape[1] == x.shape[1]
+    assert counts.dtype == torch.float64 and counts.numel() == sums.shape[0]
+    n, p = x.shape
+    _lib.check(_lib.lib().spkm_dense_accumulate_dev(ctx.handle, p, n, _p(x), sums.shape[0], _p(assign), _p(sums),
+                                                    _p(counts)), "spkm_dense_accumulate_dev")
+
+
 class StreamingSparsifier:
     """One-pass ingest of a dense dataset that never fits in HBM at once: chunk -> X*(1+2eps) -> mix ->
     sample -> append to the resident sparse shard (private/sampleAndMixFromLargeFile.m:79-129).  Only the

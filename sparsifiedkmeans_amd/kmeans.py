@@ -3,8 +3,8 @@
 the MI355X through libspkm.so.
 
 Scope: the sparsified path -- 'Sparsify',true with the Hadamard sketch or no
-sketch.  What the reference does with MATLAB toolboxes outside that path (dense k-means via
-pdist2, DCT sketch, matfile streaming, two-pass outputs) raises NotImplementedError naming the
+sketch -- including the two-pass outputs (nargout 6..9).  What the reference does with MATLAB toolboxes
+outside that path (dense k-means via pdist2, DCT sketch, matfile) raises NotImplementedError naming the
 option, rather than silently doing something else.
 
 MATLAB's RNG cannot be reproduced here; every random product (sign vector, sampled rows, initial
@@ -31,7 +31,8 @@ import torch
 
 from . import distributed as D_
 from . import synth
-from .engine import LloydEngine, Shard, StreamingSparsifier, mix_device, torch_context
+from .engine import (LloydEngine, Shard, StreamingSparsifier, dense_accumulate_device, dense_assign_device, mix_device,
+                     torch_context)
 
 EPS = np.finfo(np.float64).eps
 
@@ -90,12 +91,20 @@ class _Sketch:
 
 def findClusterAssignments(X, centers, tryBuiltinMex=None, gamma=None, ctx=None):
     """[assignments, distances] = findClusterAssignments(X, centers, tryBuiltinMex, gamma)
-    (private/findClusterAssignments.m) for SPARSE X (p x n scipy matrix): dense centres use the
-    tiled HIP kernel, sparse centres (scipy matrix) the sparse-centres kernel.  assignments are
-    1-based.  The dense-X branch (:124-166) is out of scope."""
+    (private/findClusterAssignments.m).  Sparse X (p x n scipy matrix): dense centres use the tiled HIP
+    kernel, sparse centres (scipy matrix) the sparse-centres kernel.  Dense X (p x n array): the expanded
+    quadratic of :157-165 on the f64 matrix cores (gamma is ignored there, as in the reference).
+    assignments are 1-based."""
     if not sp.issparse(X):
-        raise NotImplementedError("findClusterAssignments: dense X (pdist2 branch, findClusterAssignments.m:124-166) "
-                                  "is outside the sparsified hot path")
+        ctx = ctx or torch_context()
+        Xd = np.asarray(X, np.float64)
+        Cd = np.asarray(centers.toarray() if sp.issparse(centers) else centers, np.float64)
+        if Cd.shape[0] != Xd.shape[0]:
+            raise ValueError("Array of centers not of correct size")  # :55
+        dev = f"cuda:{ctx.device}"
+        a, d = dense_assign_device(ctx, torch.tensor(np.ascontiguousarray(Xd.T), device=dev),
+                                   torch.tensor(np.ascontiguousarray(Cd.T), device=dev))
+        return a.cpu().numpy().astype(np.int64) + 1, d.cpu().numpy()
     ctx = ctx or torch_context()
     p, n = X.shape
     if centers.shape[0] != p:
@@ -122,11 +131,13 @@ def kmeans_sparsified(X, K, **options):
     """[IDX, C, SUMD, D, OUTPUT] = kmeans_sparsified(X, K, 'Name', value, ...)   (kmeans_sparsified.m:1)
 
     X: n x p array (points are rows; 'ColumnSamples',True for p x n).  Returns the tuple
-    (IDX, C, SUMD, D, OUTPUT); IDX is 1-based.  See module docstring for scope."""
+    (IDX, C, SUMD, D, OUTPUT); IDX is 1-based.  With nargout=6..9 the two-pass outputs follow:
+    (..., C_twoPass, IDX_twoPass, D_twoPass, SUMD_twoPass)[:nargout].  See module docstring for scope."""
     t0 = time.time()
     o = _parse(options)
-    if o["nargout"] > 5:
-        raise NotImplementedError("two-pass outputs (kmeans_sparsified.m:522-571) are outside the hot-path scope")
+    nargout = int(o["nargout"])
+    if not 1 <= nargout <= 9:
+        raise ValueError("nargout must be between 1 and 9")
     if isinstance(X, str):
         o["DataFile"], X = X, None                                                # kmeans_sparsified.m:179-183
     LoadFromDisk = o["DataFile"] is not None
@@ -380,12 +391,79 @@ def kmeans_sparsified(X, K, **options):
         torch.distributed.all_reduce(sd, op=torch.distributed.ReduceOp.SUM)
         SUMD = sd.cpu().numpy()
     OUTPUT["TimeOverall_OnePass"] = time.time() - t0
-    Cout = sketch.unmix(best["centers"]).cpu().numpy().T                         # p x K (:523)
+    Cdev = sketch.unmix(best["centers"])                                         # [K, p] (:523)
+    Cout = Cdev.cpu().numpy().T                                                  # p x K
     D = best["dist"]
+    extra = ()
+    if nargout > 5:
+        # ---- two-pass outputs (:525-571): a second pass over the UNSAMPLED data, streamed in MB_limit chunks ----
+        #  centers_twoPass(:,k) = mean(full(XFull(:,ind)),2) over the one-pass assignments (:545-550;
+        #                         DataFile: recalculateAssignmentLargeFile.m:100-113)
+        #  [assignments_twoPass, distances_twoPass] = findClusters(full(XFull), bestCenters)  (:558; dense branch,
+        #                         which ignores gamma) -- for 'DataFile' always computed, as the reference does (:531)
+        #  SUMD_twoPass(k) = sum(distances(:, assignments_twoPass==k).^2) with the ONE-pass distances of the last
+        #                         replicate (:564-568; a reference quirk kept as is)
+        # Reference quirk NOT kept: recalculateAssignmentLargeFile.m:105 overwrites newCenters(:,ki) with each
+        # chunk's sum instead of adding to it, while the counter (:103) and the final division (:111-113) span
+        # all chunks; the sums are accumulated here, which is identical whenever the file fits one chunk.
+        if LoadFromDisk:
+            warnings.warn("Requires a second pass over the dataset")            # :529
+        t1 = time.time()
+        want_assign = LoadFromDisk or nargout > 6
+        sums = torch.zeros((Kb, p), dtype=torch.float64, device=dev)
+        counts = torch.zeros(Kb, dtype=torch.float64, device=dev)
+        a2 = torch.empty(n, dtype=torch.int32, device=dev) if want_assign else None
+        d2 = torch.empty(n, dtype=torch.float64, device=dev) if want_assign else None
+        idx0 = None if not IDX.size else torch.tensor((IDX - 1).astype(np.int32), device=dev)
+        nn = max(1, min(n, int(o["MB_limit"] * 2**20 // (8 * p))))               # recalculateAssignmentLargeFile.m:66
+        t_read = 0.0
+        for c0 in range(0, n, nn):
+            tr = time.time()
+            if LoadFromDisk:
+                blk = Xmm[:, c0:c0 + nn].T if o["ColumnSamples"] else Xmm[c0:c0 + nn, :]
+            else:
+                blk = X[:, c0:c0 + nn].T
+            blk = np.ascontiguousarray(blk, dtype=np.float64)
+            t_read += time.time() - tr
+            xb = torch.tensor(blk, device=dev)
+            if idx0 is not None:
+                dense_accumulate_device(ctx, xb, idx0[c0:c0 + nn].contiguous(), sums, counts)
+            if want_assign:
+                a_, d_ = dense_assign_device(ctx, xb, Cdev)
+                a2[c0:c0 + nn], d2[c0:c0 + nn] = a_, d_
+        if dist_on:
+            torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM)
+            torch.distributed.all_reduce(counts, op=torch.distributed.ReduceOp.SUM)
+        cnt = counts.cpu().numpy()
+        C2 = sums.cpu().numpy().T                                                # p x K
+        if LoadFromDisk:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                C2 = C2 * (1.0 / cnt)[None, :]                                   # bsxfun(@times, newCenters, 1./counter)
+        else:
+            nz = cnt > 0
+            C2[:, nz] = C2[:, nz] / cnt[nz][None, :]                             # mean(...,2); empty clusters stay 0 (:544)
+        torch.cuda.synchronize()
+        OUTPUT["TimeSecondPass_Overall" if LoadFromDisk else "TimeSecondPass_Centers"] = time.time() - t1
+        if LoadFromDisk:
+            OUTPUT["TimeSecondPass_JustRead"] = t_read
+        extra = (C2 if o["ColumnSamples"] else C2.T,)
+        if want_assign:
+            IDX2 = a2.cpu().numpy().astype(np.int64) + 1
+            D2 = d2.cpu().numpy()
+            extra += (IDX2, D2)
+            if nargout >= 9:
+                t1 = time.time()
+                S2 = np.array([np.sum(distances[IDX2 == ki + 1] ** 2) for ki in range(Kb)])
+                if dist_on:
+                    sd = torch.tensor(S2, dtype=torch.float64, device=dev)
+                    torch.distributed.all_reduce(sd, op=torch.distributed.ReduceOp.SUM)
+                    S2 = sd.cpu().numpy()
+                OUTPUT["TimeSecondPass_SUMD"] = time.time() - t1
+                extra += (S2,)
     if not o["ColumnSamples"]:
         Cout = Cout.T                                                            # K x p like MATLAB's kmeans (:586-590)
     OUTPUT["TimeOverall"] = time.time() - t0
-    return IDX, Cout, SUMD, D, OUTPUT
+    return ((IDX, Cout, SUMD, D, OUTPUT) + extra)[:max(nargout, 5)]
 
 
 def _arthur(ctx, shard, column, n, K, gamma, rng, first=0, n_glob=None, dist_on=False):

@@ -132,3 +132,16 @@ def test_golden_regression_fixtures(oracle):
         else:
             raise AssertionError(kind)
         assert np.array_equal(got, z["out"]), f
+
+
+def test_dense_branch_restatement_agrees_with_direct_differences():
+    """findClusterAssignments.m:157-165 (expanded quadratic) against the plain definition sqrt(sum((x-c)^2))."""
+    from oracle import numpy_ref
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((30, 200))
+    C = rng.standard_normal((30, 6))
+    a, d, full = numpy_ref.dense_assign(X, C)
+    direct = np.sqrt(((X[:, None, :] - C[:, :, None]) ** 2).sum(axis=0))
+    assert np.allclose(full, direct, rtol=1e-10, atol=1e-10)
+    assert np.array_equal(a, np.argmin(direct, axis=0))
+    assert np.allclose(numpy_ref.two_pass_centers(X, a, 6)[:, 2], X[:, a == 2].mean(axis=1))
