@@ -33,9 +33,10 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
+    int bmapq_key = -1, bmapq_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     // optional per-launch timing log of the dominant assignment kernel (bench.py)
@@ -58,6 +59,9 @@ struct spkm_shard {
     bool owned = false;
     int fixed_s = 0;   // > 0: every column has exactly this many entries
     uint64_t slack = 0; // entries readable past nnz in ir / x
+    float* xfs = nullptr;  // screen copy for the 4-lanes-per-point kernel: f32 values, columns partitioned by row parity
+    void* irs = nullptr;   // ... and their row ids
+    bool norms_done = false, xf_done = false;
     double* xn1 = nullptr; // per-point sum |x| and sum x^2 (screen error bound), built on first use
     double* xn2 = nullptr;
     float* xf = nullptr;   // f32 copy of x for the screen (with the same slack)
@@ -151,7 +155,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -292,6 +296,8 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xn1) (void)hipFree(s->xn1);
     if (s->xn2) (void)hipFree(s->xn2);
     if (s->xf) (void)hipFree(s->xf);
+    if (s->xfs) (void)hipFree(s->xfs);
+    if (s->irs) (void)hipFree(s->irs);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
     if (s->ev_nlist) (void)hipEventDestroy(s->ev_nlist);
     if (s->owned) {
@@ -364,6 +370,54 @@ static int build_blockmap(spkm_ctx* ctx, int G)
     HIP_TRY(hipMemcpyAsync(ctx->bmap.p, bm.data(), NB * sizeof(spkm_blockmap), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->bmap_G = G; ctx->bmap_blocks = NB; ctx->bmap_streams = nstreams;
+    return SPKM_OK;
+}
+
+// Block map of the 4-lanes-per-point screen.  The last tile may be narrow (pl_last centroid pairs per lane
+// instead of 4) and then costs a fraction of a full tile per point, so the workgroups of each XCD are split
+// over the tiles in proportion to the tiles' cost; all tiles sweep the XCD's chunks (chunk c belongs to XCD
+// c % NX) in the same order, so a chunk is fetched from HBM once and re-read from that XCD's L2.
+//   entry: tile, stream = index among the tile's workgroups on this XCD, nstreams = their number,
+//          pad = NX | xcd << 8 | pairs-per-lane << 16
+static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
+{
+    const int NB = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const int key = G * 64 + pl_last * 8 + 1000003 * rounds + (getenv("SPKM_QUAD_W") ? 7 : 0);
+    if (ctx->bmapq_key == key && ctx->bmapq_blocks == NB) return SPKM_OK;
+    const int NX = (NB % 8 == 0) ? 8 : 1;
+    const int per = NB / NX;
+    if (per < G) return SPKM_ERR_UNSUPPORTED;
+    // issue cycles per 16-point step: rounds * (32 + 32 pl (+12 for the second address)) + overhead
+    auto cost = [&](int pl) { return (double)rounds * (32.0 + 32.0 * pl + (pl == 4 ? 12.0 : 0.0)) + 400.0; };
+    std::vector<double> w(G, cost(4));
+    w[G - 1] = cost(pl_last);
+    if (const char* ev = getenv("SPKM_QUAD_W")) w[G - 1] = cost(4) * atof(ev); // tuning aid
+    // apportionment of the XCD's workgroups, at least one per tile, minimising the makespan
+    std::vector<int> cnt(G, 1);
+    for (int left = per - G; left > 0; left--) {
+        int best = 0;
+        double worst = -1;
+        for (int g = 0; g < G; g++)
+            if (w[g] / cnt[g] > worst) { worst = w[g] / cnt[g]; best = g; }
+        cnt[best]++;
+    }
+    std::vector<spkm_blockmap> bm(NB, spkm_blockmap{-1, 0, 1, 0});
+    for (int x = 0; x < NX; x++) {
+        int i = 0;
+        for (int g = 0; g < G; g++)
+            for (int j = 0; j < cnt[g]; j++, i++) {
+                spkm_blockmap& e = bm[i * NX + x]; // workgroup b runs on XCD b % NX
+                e.tile = g;
+                e.stream = j;
+                e.nstreams = cnt[g];
+                e.pad = NX | (x << 8) | ((g == G - 1 ? pl_last : 4) << 16);
+            }
+    }
+    int rc = ensure(ctx, ctx->bmapq, NB * sizeof(spkm_blockmap));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->bmapq.p, bm.data(), NB * sizeof(spkm_blockmap), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->bmapq_key = key; ctx->bmapq_blocks = NB;
     return SPKM_OK;
 }
 
@@ -686,26 +740,11 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
 // ------------------------------------------------------------------------------------------
 // fused iteration front half: assignment + accumulation (everything before the all-reduce)
 // ------------------------------------------------------------------------------------------
-// Number of tiles for the entry-parallel screen: the smallest G >= ceil(K/32) whose largest tile
-// ((p+1) rows of an odd number of 16-B slots) fits in LDS, as long as a tile still holds >= 16 centroids
-// (or all of them).  0: not usable.
-static int screen_rows_tiles(const spkm_ctx* ctx, uint64_t p, int K)
+// The 4-lanes-per-point screen keeps a point's entries in registers (up to 64); longer columns use the
+// first-generation 16-lanes-per-point kernel.  SPKM_SCREEN_V1 forces the latter (A/B runs).
+static bool screen_use_quad(const spkm_shard* s)
 {
-    const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    const int P = (K + 1) / 2;
-    for (int G = (K + 31) / 32; G <= nb && G <= P; G++) {
-        const int kp = (P + G - 1) / G;
-        if (kp < 8 && G > 1) return 0;
-        if ((p + 1) * (uint64_t)screen_rows_slots(kp) * 16 + 16 <= ctx->lds_max) return G;
-    }
-    return 0;
-}
-
-// The entry-parallel screen holds a point's entries in registers: up to 64 per column.
-static bool screen_use_rows(const spkm_ctx* ctx, const spkm_shard* s, int K)
-{
-    if (!getenv("SPKM_SCREEN_ROWS")) return false; // experimental: slower than the tiled screen (LDS bank conflicts)
-    return s->fixed_s <= 64 && screen_rows_tiles(ctx, s->p, K) > 0;
+    return s->fixed_s <= 64 && !getenv("SPKM_SCREEN_V1");
 }
 
 static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
@@ -713,11 +752,9 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
     if (getenv("SPKM_NO_SCREEN")) return false;
     if (s->fixed_s <= 0 || s->slack < 48 || s->nnz == 0) return false; // the screen reads up to 33 entries past a column
     if (K <= 16) return false; // a single exact tile already streams X once
-    if (!screen_use_rows(ctx, s, K)) { // first-generation tiled screen
-        if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
-        const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
-        if ((K + SCREEN_KT - 1) / SCREEN_KT > nb) return false;
-    }
+    if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
+    const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    if ((K + SCREEN_KT - 1) / SCREEN_KT > nb) return false;
     // phase 2 needs the centroid column + slab + at least 8 staged points per wave
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     if (s->p * 20 + 64 + 16 * 8 * per_pt > ctx->lds_max) return false;
@@ -730,8 +767,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
-    const bool rows = screen_use_rows(ctx, s, K);
-    const int G = rows ? screen_rows_tiles(ctx, s->p, K) : (K + SCREEN_KT - 1) / SCREEN_KT;
+    const bool quad = screen_use_quad(s);
+    const int G = (K + SCREEN_KT - 1) / SCREEN_KT;
     const size_t pk = (size_t)p * K;
     double* sums = d_reduce;
     double* counts = d_reduce + pk;
@@ -742,14 +779,37 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (!sm->xn1) {
         HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
         HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
+    }
+    if (!quad && !sm->xf) {
+        // f32 copy of the values in storage order
         HIP_TRY(hipMalloc((void**)&sm->xf, (size_t)(s->nnz + 48) * 4));
         HIP_TRY(hipMemsetAsync(sm->xf, 0, (size_t)(s->nnz + 48) * 4, ctx->stream));
+    }
+    if (!sm->norms_done || (!quad && !sm->xf_done)) {
         hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256), 0,
                            ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2,
-                           sm->xf);
+                           quad ? (float*)nullptr : sm->xf);
+        sm->norms_done = true;
+        if (!quad) sm->xf_done = true;
     }
-    if ((rc = build_blockmap(ctx, G))) return rc;
-    const size_t tile_floats = (size_t)G * (p + 1) * (rows ? SCREEN_ROWS_MAX_STRIDE : SCREEN_KT);
+    if (quad && !sm->xfs) {
+        // f32 values + row ids, each column partitioned by row parity (k_screen_reorder)
+        const size_t isz = sizeof(IR);
+        HIP_TRY(hipMalloc((void**)&sm->xfs, (size_t)(s->nnz + 48) * 4));
+        HIP_TRY(hipMalloc((void**)&sm->irs, (size_t)(s->nnz + 48) * isz));
+        HIP_TRY(hipMemsetAsync(sm->xfs, 0, (size_t)(s->nnz + 48) * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(sm->irs, 0, (size_t)(s->nnz + 48) * isz, ctx->stream));
+        hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
+                           0, ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, sm->xfs, (IR*)sm->irs);
+    }
+    // narrow last tile (4-lanes-per-point kernel): 1 or 2 centroid pairs per lane instead of 4
+    const int k_last = K - (G - 1) * SCREEN_KT;
+    const int pl_last = !quad ? 4 : (k_last <= 8 ? 1 : (k_last <= 16 ? 2 : 4));
+    const int q_rounds = (s->fixed_s + 3) / 4;
+    if (quad) rc = build_blockmap_quad(ctx, G, pl_last, q_rounds);
+    else rc = build_blockmap(ctx, G);
+    if (rc) return rc;
+    const size_t tile_floats = (size_t)G * (p + 1) * SCREEN_KT;
     if ((rc = ensure(ctx, ctx->t32, tile_floats * 4))) return rc;
     if ((rc = ensure(ctx, ctx->cmax, 64))) return rc;
     if ((rc = ensure(ctx, ctx->scr_m1, (size_t)G * n * 4))) return rc;
@@ -764,40 +824,31 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
-    if (rows)
-        hipLaunchKernelGGL(k_prep_rows_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)),
-                           dim3(256), 0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
-                           (unsigned long long*)ctx->cmax.p);
-    else
-        hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)),
-                           dim3(256), 0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
-                           (unsigned long long*)ctx->cmax.p);
+    hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
+                       0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
+                       (unsigned long long*)ctx->cmax.p, pl_last);
     hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0,
                        ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
     // 1. screen
-    const int sweep = 16 * 8;
-    long long chunk = n / ((long long)ctx->bmap_streams * 8);
+    const int sweep = 16 * 16;
+    long long chunk = n / ((long long)(quad ? ctx->bmapq_blocks / 4 : ctx->bmap_streams) * 8);
     chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
     chunk = (chunk / sweep) * sweep;
-    if (rows) {
-        const int kp_max = ((K + 1) / 2 + G - 1) / G;
-        const size_t lds = (size_t)(p + 1) * screen_rows_slots(kp_max) * 16 + 16;
-        auto kern = k_screen_rows<IR>;
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(timing_begin(ctx));
-        hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const IR*)s->ir,
-                           (const float*)s->xf, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K, G,
-                           (const spkm_blockmap*)ctx->bmap.p, (int)chunk, (float*)ctx->scr_m1.p,
-                           (float*)ctx->scr_m2.p, (int*)ctx->scr_k.p);
-    } else {
+    {
         const size_t lds = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
-        auto kern = k_screen_tile<IR>;
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4) : (const void*)k_screen_tile<IR>;
+        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(timing_begin(ctx));
-        hipLaunchKernelGGL(kern, dim3(ctx->bmap_blocks), dim3(1024), lds, ctx->stream, (const IR*)s->ir,
-                           (const float*)s->xf, (const float*)ctx->t32.p, p, (int)n, s->fixed_s, K,
-                           (const spkm_blockmap*)ctx->bmap.p, (int)chunk, (float*)ctx->scr_m1.p,
-                           (float*)ctx->scr_m2.p, (int*)ctx->scr_k.p);
+        const IR* a_ir = quad ? (const IR*)s->irs : (const IR*)s->ir;
+        const float* a_xf = quad ? (const float*)s->xfs : (const float*)s->xf;
+        const float* a_t = (const float*)ctx->t32.p;
+        int a_p = p, a_n = (int)n, a_s = s->fixed_s, a_K = K, a_chunk = (int)chunk;
+        const spkm_blockmap* a_bm = (const spkm_blockmap*)(quad ? ctx->bmapq.p : ctx->bmap.p);
+        float* a_m1 = (float*)ctx->scr_m1.p;
+        float* a_m2 = (float*)ctx->scr_m2.p;
+        int* a_k = (int*)ctx->scr_k.p;
+        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k};
+        HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(timing_end(ctx));

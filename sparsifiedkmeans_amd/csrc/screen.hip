@@ -31,17 +31,20 @@
 
 #define SCREEN_KT 32 // centroids per tile (two per lane of a 16-lane row)
 
-// T32[g][r][kk] = -fl32(C[(g*32+kk)*p + r] / gamma), row p zero; cmax_bits = max |C/gamma| (f64 bits, atomicMax)
+// T32[g][r][kk] = -fl32(C[(g*32+kk)*p + r] / gamma), row p zero; cmax_bits = max |C/gamma| (f64 bits, atomicMax).
+// pl_last < 4 (4-lanes-per-point kernel only): the last tile holds <= 16 centroids in floats 0..15 of each row
+// and a second copy of them in floats 16..31 (the two point pairs of an LDS phase read different copies).
 __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
-                                 float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits)
+                                 float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits, int pl_last)
 {
     const size_t total = (size_t)G * (p + 1) * SCREEN_KT;
     double mx = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(t % SCREEN_KT);
+        int kk = (int)(t % SCREEN_KT);
         const size_t rest = t / SCREEN_KT;
         const int r = (int)(rest % (p + 1));
         const int g = (int)(rest / (p + 1));
+        if (g == G - 1 && pl_last < 4) kk &= 15;
         const int k = g * SCREEN_KT + kk;
         float v = 0.f;
         if (r < p && k < K) {
@@ -77,11 +80,61 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
                 const double v = x[j];
                 a += fabs(v);
                 b += v * v;
-                xf[j] = (float)v; // the screen's x~ = fl32(x)
+                if (xf) xf[j] = (float)v; // the screen's x~ = fl32(x)
             }
         }
         for (int off = 8; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
         if (i < n && sub == 0) { xn1[i] = a; xn2[i] = b; }
+    }
+}
+
+// The screen's own copy of a fixed-stride shard: values as f32 and, per point, the entries PARTITIONED BY ROW
+// PARITY -- points with an even index list their even rows first, odd points their odd rows first.  The sum
+// of squares the screen estimates does not depend on the order; the order decides which LDS banks the
+// 4-lanes-per-point kernel below hits: the two points that read the same half-row in one 16-lane phase then
+// touch rows of opposite parity (= different 128-B halves of the 64 banks) for all but the few steps around
+// the middle of the column, where one of them has already switched class.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ ir, const double* __restrict__ x,
+                                                        long long n, int fixed_s, float* __restrict__ xfs,
+                                                        IR* __restrict__ irs)
+{
+    const int sub = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
+    const int gsh = lane & 48; // first lane of this 16-lane group
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    const long long rounds = (n + ng - 1) / ng;
+    const int nt = (fixed_s + 15) >> 4;
+    for (long long t = 0; t < rounds; t++) {
+        const long long i = g0 + t * ng;
+        const bool live = i < n;
+        const long long j0 = (live ? i : 0) * fixed_s;
+        const unsigned want = (unsigned)(i & 1);
+        int nfirst = 0;
+        for (int u = 0; u < nt; u++) {
+            const int e = u * 16 + sub;
+            const bool f = live && e < fixed_s && ((unsigned)ir[j0 + e] & 1u) == want;
+            nfirst += __builtin_popcount((unsigned)((__ballot(f) >> gsh) & 0xffffull));
+        }
+        int cf = 0, cs = 0;
+        for (int u = 0; u < nt; u++) {
+            const int e = u * 16 + sub;
+            const bool ok = live && e < fixed_s;
+            const IR r = ok ? ir[j0 + e] : (IR)0;
+            const bool f = ok && ((unsigned)r & 1u) == want;
+            const bool g = ok && !f;
+            const unsigned mf = (unsigned)((__ballot(f) >> gsh) & 0xffffull);
+            const unsigned mg = (unsigned)((__ballot(g) >> gsh) & 0xffffull);
+            const unsigned below = (1u << sub) - 1u;
+            if (ok) {
+                const int pos = f ? cf + __builtin_popcount(mf & below) : nfirst + cs + __builtin_popcount(mg & below);
+                xfs[j0 + pos] = (float)x[j0 + e];
+                irs[j0 + pos] = r;
+            }
+            cf += __builtin_popcount(mf);
+            cs += __builtin_popcount(mg);
+        }
     }
 }
 
@@ -545,242 +598,174 @@ template __global__ void k_exact_accumulate<unsigned int>(const unsigned int*, c
     const long long*, const int4*, const int*, const double*, double, int, int, int, double*, double*, double*,
     double*, double*, long long*);
 
-// ============================================================================================
-// Second screen kernel: lanes <-> stored entries (8 lanes per point, 8 points per wave).
-//
-// The tiled kernels above give each lane a centroid and broadcast the point's entries one by one:
-// 2 of the 4 issue slots per entry go to the DPP broadcasts (x, LDS address).  For the f32 SCREEN the
-// summation order is free, so the roles can be swapped: lane e of a point's 8-lane group takes entries
-// e, e+8, e+16, ... and walks the tile's centroids for each of them -- x and the row offset are
-// lane-local, the centroid values of row r come from LDS with IMMEDIATE offsets (no address math):
-//     q  = LDS[r*RS + 16*c]                  ds_read_b128     (4 centroids)
-//     t  = q + (x, x)                        v_pk_add_f32 x2
-//     acc[.] = t*t + acc[.]                  v_pk_fma_f32 x2
-// i.e. one issue slot per (entry, centroid) instead of two.  At the end the partial sums are all-reduced
-// over the 8 lanes (3 DPP stages).  A tile holds KP centroid PAIRS, 1 <= KP <= 16; the K centroids are
-// split evenly over G = ceil(K/32) tiles (K = 100: 26+26+24+24, no padded slots), every tile gets the
-// same number of workgroups.  Rows are padded to an odd number of 16-B slots so that the 16-B reads of
-// lanes holding different random rows spread over all banks.
-__host__ __device__ constexpr int screen_rows_slots(int kp) { return ((kp + 1) >> 1) | 1; }
-__host__ __device__ inline int screen_rows_pairs(int K, int G, int g, int* k0)
-{
-    const int P = (K + 1) >> 1, base = P / G, rem = P % G;
-    *k0 = 2 * (g * base + (g < rem ? g : rem));
-    return base + (g < rem ? 1 : 0);
-}
-#define SCREEN_ROWS_MAX_STRIDE 36 // floats per row in the global tile buffer (16 pairs + pad)
-
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-// tile g, row r, slot kk: T[(g*(p+1) + r)*36 + kk] = -fl32(C[(k0_g+kk)*p + r] / gamma); row p and padding zero
-__global__ void k_prep_rows_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
-                                float* __restrict__ T, unsigned long long* __restrict__ cmax_bits)
+// ============================================================================================
+// Second screen kernel: 4 lanes per point, 16 points per wave, 8 centroids per lane.
+//
+// Same tile as k_screen_tile (32 centroids, 128-B rows).  Lane (point slot ps, l4) keeps entries l4, l4+4, ...
+// of its point in registers; at step j the owner's value and row offset are broadcast inside the quad
+// (quad_perm DPP, one instruction each) and every lane reads its 2 x 16 B of the row:
+//     xs   = quad_bcast(x)                     v_mov_b32_dpp
+//     addr = quad_bcast(rowoff) + laneoff      v_add_u32_dpp
+//     q0, q1 = LDS[addr], LDS[addr + 64]       ds_read_b128 x2
+//     acc[0..3] += (q + xs)^2                  v_pk_add_f32 x4, v_pk_fma_f32 x4
+// 10 issue slots per entry for 16 points x 32 centroids (the 16-lane layout above: 4 slots for 4 points),
+// no cross-lane reduction of the sums (each lane owns its 8 centroids), a 2-stage quad min for the winner.
+template <int SEL> __device__ __forceinline__ int quad_bcast_i32(int v)
 {
-    const size_t total = (size_t)G * (p + 1) * SCREEN_ROWS_MAX_STRIDE;
-    double mx = 0.0;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(t % SCREEN_ROWS_MAX_STRIDE);
-        const size_t rest = t / SCREEN_ROWS_MAX_STRIDE;
-        const int r = (int)(rest % (p + 1));
-        const int g = (int)(rest / (p + 1));
-        int k0;
-        const int kp = screen_rows_pairs(K, G, g, &k0);
-        float v = 0.f;
-        if (r < p && kk < 2 * kp && k0 + kk < K) {
-            double c = C[(size_t)(k0 + kk) * p + r];
-            if (gamma > 0.0) c = c / gamma;
-            mx = fmax(mx, fabs(c));
-            v = -(float)c;
-        }
-        T[t] = v;
-    }
-    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(cmax_bits, __builtin_bit_cast(unsigned long long, mx));
+    return __builtin_amdgcn_update_dpp(0, v, SEL * 0x55, 0xf, 0xf, false); // quad_perm:[SEL,SEL,SEL,SEL]
 }
-
-template <int SEL> __device__ __forceinline__ float dpp_f32(float v)
-{
-    const int b = __builtin_bit_cast(int, v);
-    int r;
-    if (SEL == 0) r = __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]: lane ^ 1
-    else if (SEL == 1) r = __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]: lane ^ 2
-    else r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xf, 0xf, false);               // row_half_mirror: i <-> 7-i
-    return __builtin_bit_cast(float, r);
-}
-
-// min over the 8-lane group (3 DPP stages)
-__device__ __forceinline__ float group_min8_f32(float v)
+__device__ __forceinline__ float quad_min_f32(float v)
 {
     asm("s_nop 1\n\t"
         "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
         : "+v"(v));
     return v;
 }
 
-template <int KP, typename IR>
-__device__ __forceinline__ void screen_rows_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
-                                                 int fixed_s, int K, int k0, const spkm_blockmap bm, int chunk_points,
+template <int NR, typename IR, int PL>
+__device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
+                                                 int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket)
 {
-    constexpr int PPS = 8; // points per wave step
-    constexpr int RS = screen_rows_slots(KP) * 16;
+    constexpr int RS = SCREEN_KT * 4; // 128-B rows
+    constexpr int PPS = 16;
     const int lane = threadIdx.x & 63;
-    const int q = lane >> 3; // point slot
-    const int e = lane & 7;  // entry lane
+    const int ps = lane >> 2, l4 = lane & 3;
+    const int k0 = bm.tile * SCREEN_KT;
+    // The two point pairs of a 16-lane LDS phase start on opposite halves of their rows (PL = 4), or read
+    // different copies of a narrow tile's row (PL < 4).
+    const bool swp = (ps & 2) != 0;
+    const int off0 = l4 * (PL == 1 ? 8 : 16) + (swp ? 64 : 0), off1 = l4 * 16 + (swp ? 0 : 64);
     const int nchunks = (n + chunk_points - 1) / chunk_points;
     const int R = chunk_points / PPS;
-    const int my_chunks = (nchunks > bm.stream) ? (nchunks - bm.stream + bm.nstreams - 1) / bm.nstreams : 0;
+    // chunk ids of this workgroup: (stream + ci * nstreams) * mul + add   (mul/add: XCD-local numbering)
+    const int mul = bm.pad & 0xff, add = (bm.pad >> 8) & 0xff;
+    const int local_chunks = nchunks > add ? (nchunks - add + mul - 1) / mul : 0;
+    const int my_chunks = (local_chunks > bm.stream) ? (local_chunks - bm.stream + bm.nstreams - 1) / bm.nstreams : 0;
     const int Tn = my_chunks * R;
-    const int rounds = (fixed_s + 7) >> 3;
     auto draw = [&]() {
         unsigned v = 0;
         if (lane == 0) v = atomicAdd(ticket, 1u);
         return (int)__builtin_amdgcn_readfirstlane(v);
     };
-    auto point_of = [&](int t) { // first point of wave step t (>= n: nothing to do)
+    auto point_of = [&](int t) {
         if (t >= Tn) return n;
         const int ci = t / R, rr = t - ci * R;
-        const int base = (bm.stream + ci * bm.nstreams) * chunk_points + rr * PPS;
+        const int base = ((bm.stream + ci * bm.nstreams) * mul + add) * chunk_points + rr * PPS;
         return (base < 0 || base > n) ? n : base;
     };
-    // All entries of a step are loaded at once (RMAX rounds of 8 entries), one step ahead of their use.
-    constexpr int RMAX = 8;
-    float xb[RMAX];
-    int rb[RMAX];
-    auto load_step = [&](int base, float (&xo)[RMAX], int (&ro)[RMAX]) {
-        const int i = base + q;
-        const int ic = i < n ? i : n - 1;
-        const float* xp = xval + (size_t)ic * fixed_s + e;
-        const IR* rp = ir + (size_t)ic * fixed_s + e;
-#pragma unroll
-        for (int rd = 0; rd < RMAX; rd++)
-            if (rd < rounds) { xo[rd] = xp[rd * 8]; ro[rd] = (int)rp[rd * 8]; } // past-the-column reads stay in the slack
-    };
-    int t = draw();
-    int base = point_of(t);
-    if (base < n) load_step(base, xb, rb);
-    while (t < Tn) {
-        const int tn = draw();
-        const int basen = point_of(tn);
-        float xnb[RMAX];
-        int rnb[RMAX];
-        if (basen < n) load_step(basen, xnb, rnb);
+    // a step's entries: NR rounds of 4 (entries past the column become x = 0 on the zero row p).  No software
+    // prefetch across steps: the other three waves of the SIMD cover the load latency.
+    const bool tail_ok = (NR - 1) * 4 + l4 < fixed_s;
+    for (int t = draw(); t < Tn; t = draw()) {
+        const int base = point_of(t);
         if (base < n) {
-        const int i = base + q;
-        f2v acc[KP];
+            const int i = base + ps;
+            const int ic = i < n ? i : n - 1;
+            const float* xp = xval + (size_t)ic * fixed_s + l4;
+            const IR* rp = ir + (size_t)ic * fixed_s + l4;
+            // scalars, not arrays: the compiler turns constant-indexed arrays into 16-wide register tuples and spills them
+#define SPKM_QUAD_LOAD(r)                                                              \
+    float x##r = 0.f;                                                                  \
+    int o##r = 0;                                                                      \
+    if constexpr (NR > r) { x##r = xp[r * 4]; o##r = (int)rp[r * 4]; } // past-the-column reads stay in the slack
+            SPKM_QUAD_LOAD(0) SPKM_QUAD_LOAD(1) SPKM_QUAD_LOAD(2) SPKM_QUAD_LOAD(3) SPKM_QUAD_LOAD(4) SPKM_QUAD_LOAD(5)
+            SPKM_QUAD_LOAD(6) SPKM_QUAD_LOAD(7) SPKM_QUAD_LOAD(8) SPKM_QUAD_LOAD(9) SPKM_QUAD_LOAD(10)
+            SPKM_QUAD_LOAD(11) SPKM_QUAD_LOAD(12) SPKM_QUAD_LOAD(13) SPKM_QUAD_LOAD(14) SPKM_QUAD_LOAD(15)
+#undef SPKM_QUAD_LOAD
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; // two f32 sums each (bit pattern 0 = (0.f, 0.f))
+            constexpr int NVL = 4; // the last round is padded to 4 entries with x = 0 on the zero row
+#define SPKM_QUAD_ROUND(r)                                                                                  \
+    if constexpr (NR > r) {                                                                                 \
+        const bool okr = (r < NR - 1) || tail_ok;                                                           \
+        const int xi = okr ? __builtin_bit_cast(int, x##r) : 0;                                             \
+        const int ro = (int)__umul24((unsigned)(okr ? o##r : p), (unsigned)RS);                             \
+        quad_round<NVL, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);                            \
+    }
+            SPKM_QUAD_ROUND(0) SPKM_QUAD_ROUND(1) SPKM_QUAD_ROUND(2) SPKM_QUAD_ROUND(3) SPKM_QUAD_ROUND(4)
+            SPKM_QUAD_ROUND(5) SPKM_QUAD_ROUND(6) SPKM_QUAD_ROUND(7) SPKM_QUAD_ROUND(8) SPKM_QUAD_ROUND(9)
+            SPKM_QUAD_ROUND(10) SPKM_QUAD_ROUND(11) SPKM_QUAD_ROUND(12) SPKM_QUAD_ROUND(13) SPKM_QUAD_ROUND(14)
+            SPKM_QUAD_ROUND(15)
+#undef SPKM_QUAD_ROUND
+            const f2v acc[4] = {__builtin_bit_cast(f2v, acc0), __builtin_bit_cast(f2v, acc1),
+                                __builtin_bit_cast(f2v, acc2), __builtin_bit_cast(f2v, acc3)};
+            // lane's centroids.  PL = 4: first read -> k0 + off0/4 + 0..3, second read -> k0 + off1/4 + 0..3;
+            // PL < 4: k0 + 2 PL l4 + 0 .. 2 PL - 1 (either copy)
+            // branch-free smallest / second smallest / argmin over the lane's 2 PL values (ascending k, first wins)
+            float lo = __builtin_inff(), hi = __builtin_inff();
+            int klo = -1;
 #pragma unroll
-        for (int a = 0; a < KP; a++) acc[a] = f2v{0.f, 0.f};
+            for (int a = 0; a < PL; a++) {
 #pragma unroll
-        for (int rd = 0; rd < RMAX; rd++) {
-            if (rd < rounds) {
-                const bool ok = rd * 8 + e < fixed_s;
-                const float xv = ok ? xb[rd] : 0.f;
-                const unsigned row = ok ? (unsigned)rb[rd] : (unsigned)p; // zero row: contributes (0 - 0)^2
-                const char* rowp = smem + __umul24(row, (unsigned)RS);
-                const f2v xx = f2v{xv, xv};
-#pragma unroll
-                for (int c = 0; c < KP / 2; c++) {
-                    const f4v qv = *reinterpret_cast<const f4v*>(rowp + 16 * c);
-                    const f2v t0 = f2v{qv.x, qv.y} + xx, t1 = f2v{qv.z, qv.w} + xx;
-                    acc[2 * c] = __builtin_elementwise_fma(t0, t0, acc[2 * c]);
-                    acc[2 * c + 1] = __builtin_elementwise_fma(t1, t1, acc[2 * c + 1]);
-                }
-                if (KP & 1) {
-                    const f2v t0 = *reinterpret_cast<const f2v*>(rowp + 16 * (KP / 2)) + xx;
-                    acc[KP - 1] = __builtin_elementwise_fma(t0, t0, acc[KP - 1]);
+                for (int h = 0; h < 2; h++) {
+                    const int k = PL == 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
+                                          : k0 + 2 * PL * l4 + 2 * a + h;
+                    float v = h ? acc[a].y : acc[a].x;
+                    v = (k < K) ? v : __builtin_inff();
+                    const bool less = v < lo; // false for NaN: a NaN estimate never wins and the point goes to the list
+                    hi = __builtin_fminf(hi, __builtin_fmaxf(lo, v));
+                    klo = less ? k : klo;
+                    lo = less ? v : lo;
                 }
             }
-        }
-        // all-reduce the sums over the 8 entry lanes
-#pragma unroll
-        for (int a = 0; a < KP; a++) {
-            acc[a].x += dpp_f32<2>(acc[a].x);
-            acc[a].y += dpp_f32<2>(acc[a].y);
-        }
-#pragma unroll
-        for (int a = 0; a < KP; a++) {
-            acc[a].x += dpp_f32<1>(acc[a].x);
-            acc[a].y += dpp_f32<1>(acc[a].y);
-        }
-#pragma unroll
-        for (int a = 0; a < KP; a++) {
-            acc[a].x += dpp_f32<0>(acc[a].x);
-            acc[a].y += dpp_f32<0>(acc[a].y);
-        }
-        // every lane now holds all estimates; lane e looks at centroids e, e+8, ... of the tile, then
-        // min / second-min over the 8 lanes (first index wins ties inside a lane; ties across lanes are
-        // never certified, so which one is reported does not matter)
-        float lo = __builtin_inff(), hi = __builtin_inff();
-        int klo = -1;
-#pragma unroll
-        for (int kk = 0; kk < 2 * KP; kk++) {
-            const float v = (kk & 1) ? acc[kk >> 1].y : acc[kk >> 1].x;
-            const bool mine = (kk & 7) == e && k0 + kk < K;
-            if (mine) {
-                if (v < lo) { hi = lo; lo = v; klo = k0 + kk; }
-                else if (v < hi) hi = v;
+            const float m1 = quad_min_f32(lo);
+            const bool win = (lo == m1);
+            const unsigned seg = (unsigned)(__ballot(win) >> (ps * 4)) & 0xfu;
+            const int first = seg ? __builtin_ctz(seg) : 0;
+            const float m2 = quad_min_f32((l4 == first) ? hi : lo);
+            if (l4 == first && i < n) {
+                const bool none = seg == 0u;
+                m1o[i] = none ? __builtin_inff() : m1;
+                m2o[i] = none ? __builtin_inff() : m2;
+                ko[i] = none ? -1 : klo;
             }
         }
-        const float m1 = group_min8_f32(lo);
-        const bool win = (lo == m1);
-        const unsigned seg = (unsigned)(__ballot(win) >> (q * 8)) & 0xffu;
-        const int first = seg ? __builtin_ctz(seg) : 0;
-        const float m2 = group_min8_f32((e == first) ? hi : lo);
-        if (e == first && i < n) {
-            const bool none = seg == 0u;
-            m1o[i] = none ? __builtin_inff() : m1;
-            m2o[i] = none ? __builtin_inff() : m2;
-            ko[i] = none ? -1 : klo;
-        }
-        }
-        t = tn;
-        base = basen;
-#pragma unroll
-        for (int rd = 0; rd < RMAX; rd++) { xb[rd] = xnb[rd]; rb[rd] = rnb[rd]; }
     }
 }
 
-template <typename IR>
-__global__ __launch_bounds__(1024) void k_screen_rows(
-    const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T, int p, int n, int fixed_s,
-    int K, int G, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
+template <int NR, typename IR>
+__global__ __launch_bounds__(1024) void k_screen_quad(
+    const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
+    int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
     if (bm.tile < 0) return;
-    int k0;
-    const int kp = screen_rows_pairs(K, G, bm.tile, &k0);
-    const int slots = screen_rows_slots(kp); // float4 per LDS row
     const int tid = threadIdx.x;
+    const size_t tile_bytes = (size_t)(p + 1) * SCREEN_KT * 4;
     {
-        const float4* src = reinterpret_cast<const float4*>(T + (size_t)bm.tile * (p + 1) * SCREEN_ROWS_MAX_STRIDE);
+        const float4* src = reinterpret_cast<const float4*>(T32 + (size_t)bm.tile * (p + 1) * SCREEN_KT);
         float4* dst = reinterpret_cast<float4*>(smem);
-        const int total = (p + 1) * slots;
-        for (int t = tid; t < total; t += blockDim.x) {
-            const int r = t / slots, c = t - r * slots;
-            dst[t] = src[r * (SCREEN_ROWS_MAX_STRIDE / 4) + c];
-        }
+        for (size_t t = tid; t < tile_bytes / 16; t += blockDim.x) dst[t] = src[t];
     }
-    unsigned* ticket = reinterpret_cast<unsigned*>(smem + (size_t)(p + 1) * slots * 16);
+    unsigned* ticket = reinterpret_cast<unsigned*>(smem + tile_bytes);
     if (tid == 0) *ticket = 0u;
     __syncthreads();
     float* m1o = scr_m1 + (size_t)bm.tile * n;
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
-#define SPKM_ROWS_CASE(N) \
-    case N: screen_rows_body<N, IR>(ir, xval, p, n, fixed_s, K, k0, bm, chunk_points, m1o, m2o, ko, smem, ticket); break;
-    switch (kp) {
-        SPKM_ROWS_CASE(1) SPKM_ROWS_CASE(2) SPKM_ROWS_CASE(3) SPKM_ROWS_CASE(4) SPKM_ROWS_CASE(5) SPKM_ROWS_CASE(6)
-        SPKM_ROWS_CASE(7) SPKM_ROWS_CASE(8) SPKM_ROWS_CASE(9) SPKM_ROWS_CASE(10) SPKM_ROWS_CASE(11) SPKM_ROWS_CASE(12)
-        SPKM_ROWS_CASE(13) SPKM_ROWS_CASE(14) SPKM_ROWS_CASE(15) SPKM_ROWS_CASE(16)
-    default: break;
+    const int pl = (bm.pad >> 16) & 0xff; // centroid pairs per lane in this workgroup's tile
+    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket);
+    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket);
+    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket);
+}
+
+// one kernel per round count (a switch inside one kernel makes the register allocator spill)
+template <typename IR> static const void* screen_quad_kernel(int rounds)
+{
+    switch (rounds) {
+#define SPKM_QUAD_CASE(N) case N: return (const void*)k_screen_quad<N, IR>;
+        SPKM_QUAD_CASE(1) SPKM_QUAD_CASE(2) SPKM_QUAD_CASE(3) SPKM_QUAD_CASE(4) SPKM_QUAD_CASE(5) SPKM_QUAD_CASE(6)
+        SPKM_QUAD_CASE(7) SPKM_QUAD_CASE(8) SPKM_QUAD_CASE(9) SPKM_QUAD_CASE(10) SPKM_QUAD_CASE(11) SPKM_QUAD_CASE(12)
+        SPKM_QUAD_CASE(13) SPKM_QUAD_CASE(14) SPKM_QUAD_CASE(15) SPKM_QUAD_CASE(16)
+#undef SPKM_QUAD_CASE
+    default: return nullptr;
     }
-#undef SPKM_ROWS_CASE
 }
