@@ -674,6 +674,7 @@ extern "C" int spkm_timing_read(spkm_ctx* ctx, double* ms, int cap, int* count)
 // accumulation + finalise
 // ------------------------------------------------------------------------------------------
 static constexpr int SEG_POINTS = 2048;
+static int seg_points() { const char* e = getenv("SPKM_SEG"); return e ? std::max(256, atoi(e)) : SEG_POINTS; }
 
 extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const int32_t* d_assign,
                                    double* d_reduce)
@@ -864,14 +865,14 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // 4. counting sort by cluster
     hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
                        ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p);
-    const int max_items = (int)(n / SEG_POINTS) + K + 1;
+    const int max_items = (int)(n / seg_points()) + K + 1;
     if ((rc = ensure(ctx, ctx->perm, (size_t)n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->offs, (size_t)(K + 1) * 8))) return rc;
     if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
     if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
     hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
-                       SEG_POINTS, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                       seg_points(), (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
                        (int*)ctx->nitems.p);
     const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
@@ -885,10 +886,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     pts = std::max(8, pts & ~7);
     if (const char* ev = getenv("SPKM_PTS")) pts = std::max(8, atoi(ev) & ~7);
     const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
-    auto k2 = k_exact_accumulate<IR>;
-    HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     int per_cu = 1;
     if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
+    auto k2 = k_exact_accumulate<IR, 16, 4>; // 16 points' loads in flight per wave, 4 waves per SIMD
+    HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * per_cu);
     if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;

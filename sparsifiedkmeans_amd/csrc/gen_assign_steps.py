@@ -277,6 +277,10 @@ __device__ __forceinline__ void screen32p<{n}, {irbytes}>(int koff, double rpA, 
 
 
 
+QX = 56   # first literal register of the quad rounds: x broadcasts v[QX:QX+7], read results v[QT:QT+31]
+QT = QX + 8
+
+
 def quad_round_block(nv: int, pl: int) -> str:
     """f32 SCREEN round of the 4-lanes-per-point kernel (screen.hip, k_screen_quad): nv <= 4 consecutive
     entries of a point, owned by lanes 0..nv-1 of its quad; pl = centroid PAIRS per lane (4: full tile of 32
@@ -290,11 +294,11 @@ def quad_round_block(nv: int, pl: int) -> str:
         acc_j = T_j * T_j + acc_j   (j < pl)           v_pk_fma_f32
     All reads of the round are issued first (up to 8 x 16 B per lane in flight), then consumed in order.  The
     128-bit read results and the broadcast x need their halves as separate 64-bit operands, which inline-asm
-    operands cannot express: they live in v[88:127], named literally and declared as clobbers."""
+    operands cannot express: they live in v[QX:QT+31], named literally and declared as clobbers."""
     L = ["s_nop 1"]
     for m in range(nv):
         L.append(f"v_add_u32_dpp %[a{m}], %[ro], %[off0] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
-        T = 96 + 8 * m
+        T = QT + 8 * m
         if pl == 4:
             L.append(f"v_add_u32 %[b{m}], %[a{m}], %[delta]")
             L.append(f"ds_read_b128 v[{T}:{T+3}], %[a{m}]")
@@ -304,13 +308,13 @@ def quad_round_block(nv: int, pl: int) -> str:
         else:
             L.append(f"ds_read_b64 v[{T}:{T+1}], %[a{m}]")
     for m in range(nv):
-        L.append(f"v_mov_b32_dpp v{88 + 2 * m}, %[xi] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
+        L.append(f"v_mov_b32_dpp v{QX + 2 * m}, %[xi] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
     per = 2 if pl == 4 else 1
     nreads = per * nv
     for m in range(nv):
-        X = 88 + 2 * m
+        X = QX + 2 * m
         for h in range(per):
-            T = 96 + 8 * m + 4 * h
+            T = QT + 8 * m + 4 * h
             L.append(f"s_waitcnt lgkmcnt({nreads - 1 - (per * m + h)})")
             L.append(f"v_pk_add_f32 v[{T}:{T+1}], v[{T}:{T+1}], v[{X}:{X+1}] op_sel_hi:[1,0]")
             if pl >= 2:
@@ -330,7 +334,7 @@ def quad_round_func(nv: int, pl: int) -> str:
     ins = ['[xi] "v"(xi)', '[ro] "v"(ro)', '[off0] "v"(off0)']
     if pl == 4:
         ins.append('[delta] "v"(delta)')
-    clob = ", ".join(f'"v{r}"' for r in range(88, 128))
+    clob = ", ".join(f'"v{r}"' for r in range(QX, QT + 32))
     decl = ", ".join([f"a{m}" for m in range(nv)] + ([f"b{m}" for m in range(nv)] if pl == 4 else []))
     return f"""template <>
 __device__ __forceinline__ void quad_round<{nv}, {pl}>(int xi, int ro, int off0, int delta,

@@ -459,8 +459,9 @@ __global__ __launch_bounds__(256) void k_hist(const int* __restrict__ assign, lo
 //      mind[i] = sqrt(acc) is exactly the value the reference's min() returns for this point.
 // LDS: negc f64[p] | ssum f64[p] | scnt u32[p] | per wave: ms f64[PTS*S1]   (S1 = s|1: odd stride, conflict-free)
 // Also per-block partial statistics: sum mind^2, max mind and its first index.
-template <typename IR>
-__global__ __launch_bounds__(1024) void k_exact_accumulate(const IR* __restrict__ ir, const double* __restrict__ x,
+template <typename IR, int U, int WPE>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_exact_accumulate(
+                                                          const IR* __restrict__ ir, const double* __restrict__ x,
                                                           const int* __restrict__ perm,
                                                           const long long* __restrict__ offs,
                                                           const int4* __restrict__ items,
@@ -499,16 +500,22 @@ __global__ __launch_bounds__(1024) void k_exact_accumulate(const IR* __restrict_
             scnt[r] = 0u;
         }
         __syncthreads();
+        // the point ids of a wave's next batch are fetched one batch ahead (takes their latency off the chain)
+        long long my_next = 0;
+        if (wave * pts < len && lane < pts && wave * pts + lane < len) my_next = perm[start + wave * pts + lane];
         for (int qb = wave * pts; qb < len; qb += nwaves * pts) {
             const int have = (len - qb < pts) ? len - qb : pts;
-            long long my_i = 0;
-            if (lane < have) my_i = perm[start + qb + lane];
-            // (a) eight points' loads in flight per lane
-            for (int u = 0; u < have; u += 8) {
-                double xv[8];
-                int rv[8];
+            const long long my_i = my_next;
+            {
+                const int qn = qb + nwaves * pts;
+                if (qn < len && lane < pts && qn + lane < len) my_next = perm[start + qn + lane];
+            }
+            // (a) U points' loads in flight per lane
+            for (int u = 0; u < have; u += U) {
+                double xv[U];
+                int rv[U];
 #pragma unroll
-                for (int v = 0; v < 8; v++) {
+                for (int v = 0; v < U; v++) {
                     const int src = (u + v < have) ? u + v : u;
                     const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, src);
                     const bool ok = (u + v < have) && lane < fixed_s;
@@ -517,12 +524,14 @@ __global__ __launch_bounds__(1024) void k_exact_accumulate(const IR* __restrict_
                     rv[v] = ok ? (int)ir[j] : -1;
                 }
 #pragma unroll
-                for (int v = 0; v < 8; v++) {
+                for (int v = 0; v < U; v++) {
                     if (rv[v] >= 0) {
                         const double d = xv[v] + negc[rv[v]]; // RN(x - c): the reference's subtraction
                         ms[(size_t)(u + v) * S1 + lane] = d * d;
+#ifndef SPKM_EXP_NOATOM
                         unsafeAtomicAdd(&ssum[rv[v]], xv[v]);
                         atomicAdd(&scnt[rv[v]], 1u);
+#endif
                     }
                     if (fixed_s > 64 && u + v < have) { // columns longer than one wave
                         const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, u + v);
@@ -544,7 +553,11 @@ __global__ __launch_bounds__(1024) void k_exact_accumulate(const IR* __restrict_
             if (lane < have) {
                 double acc = 0.0;
                 const double* mq = ms + (size_t)lane * S1;
+#ifdef SPKM_EXP_NOSUM
+                for (int j = 0; j < 2; j++) acc = acc + mq[j];
+#else
                 for (int j = 0; j < fixed_s; j++) acc = acc + mq[j];
+#endif
                 const double dist = sqrt(acc);
                 mind[my_i] = dist;
                 obj2 += dist * dist;
@@ -591,12 +604,6 @@ template __global__ void k_assign_list<unsigned short>(const long long*, const u
     const double*, int, int, const int*, const unsigned int*, int*);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*);
-template __global__ void k_exact_accumulate<unsigned short>(const unsigned short*, const double*, const int*,
-    const long long*, const int4*, const int*, const double*, double, int, int, int, double*, double*, double*,
-    double*, double*, long long*);
-template __global__ void k_exact_accumulate<unsigned int>(const unsigned int*, const double*, const int*,
-    const long long*, const int4*, const int*, const double*, double, int, int, int, double*, double*, double*,
-    double*, double*, long long*);
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -662,7 +669,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     };
     // a step's entries: NR rounds of 4 (entries past the column become x = 0 on the zero row p).  No software
     // prefetch across steps: the other three waves of the SIMD cover the load latency.
-    const bool tail_ok = (NR - 1) * 4 + l4 < fixed_s;
+    const int nvl = fixed_s - 4 * (NR - 1);
     for (int t = draw(); t < Tn; t = draw()) {
         const int base = point_of(t);
         if (base < n) {
@@ -680,13 +687,15 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             SPKM_QUAD_LOAD(11) SPKM_QUAD_LOAD(12) SPKM_QUAD_LOAD(13) SPKM_QUAD_LOAD(14) SPKM_QUAD_LOAD(15)
 #undef SPKM_QUAD_LOAD
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; // two f32 sums each (bit pattern 0 = (0.f, 0.f))
-            constexpr int NVL = 4; // the last round is padded to 4 entries with x = 0 on the zero row
+            // the last round broadcasts only the nvl = fixed_s - 4 (NR - 1) entries the column still has
 #define SPKM_QUAD_ROUND(r)                                                                                  \
     if constexpr (NR > r) {                                                                                 \
-        const bool okr = (r < NR - 1) || tail_ok;                                                           \
-        const int xi = okr ? __builtin_bit_cast(int, x##r) : 0;                                             \
-        const int ro = (int)__umul24((unsigned)(okr ? o##r : p), (unsigned)RS);                             \
-        quad_round<NVL, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);                            \
+        const int xi = __builtin_bit_cast(int, x##r);                                                       \
+        const int ro = (int)__umul24((unsigned)o##r, (unsigned)RS);                                         \
+        if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);   \
+        else if (nvl == 3) quad_round<3, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);            \
+        else if (nvl == 2) quad_round<2, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);            \
+        else quad_round<1, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);                          \
     }
             SPKM_QUAD_ROUND(0) SPKM_QUAD_ROUND(1) SPKM_QUAD_ROUND(2) SPKM_QUAD_ROUND(3) SPKM_QUAD_ROUND(4)
             SPKM_QUAD_ROUND(5) SPKM_QUAD_ROUND(6) SPKM_QUAD_ROUND(7) SPKM_QUAD_ROUND(8) SPKM_QUAD_ROUND(9)
