@@ -158,7 +158,7 @@ def main():
         try:
             with open(pmc) as f:
                 rec = json.load(f)
-            kern = "k_screen_tile" if path == 1 else "k_assign_tile"
+            kern = dominant_kernel(path, s)
             if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
                     and str(rec.get("kernel", "")).startswith(kern)):
                 traffic = rec.get("hbm_bytes_per_launch")
@@ -188,10 +188,11 @@ def main():
                    "uncertified_points_last_iter": listed},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "kernel": "k_screen_tile" if path == 1 else "k_assign_tile", "kernel_ms": k_ms,
+                     "kernel": dominant_kernel(path, s), "kernel_ms": k_ms,
                      "algorithmic_bytes_per_launch": b_iter,
-                     "note": "VALU-issue bound at K=100, not HBM bound: 4 issue slots of 4 cycles per stored entry per "
-                             "32 (screen, f32) or 16 (exact, f64) centroids; see DESIGN.md section 4"},
+                     "note": "VALU-issue / LDS bound at K=100, not HBM bound: the f32 screen spends 10 issue slots of 4 "
+                             "cycles per stored entry for 16 points x 32 centroids (exact f64 tiles: 4 slots per entry "
+                             "for 4 points x 16 centroids); see DESIGN.md section 4"},
         "valu": {"distance_terms_per_s": (nnz_local * K) / (k_ms * 1e-3) if k_ms == k_ms else None,
                  "exact_f64_op_equivalent_Tops": ops / (k_ms * 1e-3) / 1e12 if k_ms == k_ms else None,
                  "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS},
@@ -207,6 +208,14 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def dominant_kernel(path, s):
+    """Name of the kernel the roofline object describes: the f32 screen (4 lanes per point for columns of up to
+    64 entries, 16 lanes per point beyond) or, on the all-exact path, the f64 tile kernel."""
+    if path != 1:
+        return "k_assign_tile"
+    return "k_screen_quad" if s <= 64 else "k_screen_tile"
 
 
 def cpu_baseline(data, centers0, p2, K, gamma, s, n_cpu, n_total):

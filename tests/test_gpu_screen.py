@@ -51,6 +51,44 @@ def test_screen_path_equals_oracle(gpu_ctx, oracle, p, n, K, s):
     assert listed < 0.05 * n                                # random data: almost everything certifies
 
 
+@pytest.mark.parametrize("p,n,K,s", [(256, 4000, 44, 13),    # last tile 12 centroids: 2 pairs per lane
+                                     (256, 4000, 48, 16),    # last tile 16: 2 pairs per lane, rounds of exactly 4
+                                     (128, 3000, 64, 1),     # one entry per point, full tiles only
+                                     (128, 3000, 35, 4),     # one full round
+                                     (128, 3100, 41, 5),     # one full round + 1 entry; last tile 9 centroids
+                                     (512, 2500, 70, 63),    # 16 rounds, 3 entries in the last
+                                     (512, 2500, 20, 62),    # single tile of 20 (4 pairs per lane, padded)
+                                     (256, 2000, 40, 65)])   # 65 entries: the 16-lanes-per-point kernel
+def test_screen_kernel_variants_equal_oracle(gpu_ctx, oracle, p, n, K, s):
+    """Every shape class of the 4-lanes-per-point screen (rounds 1..16, 1..4 entries in the last round, narrow
+    last tiles of 1 / 2 centroid pairs per lane) and the fallback for columns longer than 64 entries."""
+    X = random_csc(p, n, s, seed=3 * p + K + s)
+    Cm = np.random.default_rng(K + s).standard_normal((p, K)) * 0.3
+    eng, path, listed = _run(gpu_ctx, X, Cm, s / p)
+    assert path == 1, "screen path expected"
+    _check(eng, oracle, X, Cm, s / p)
+
+
+def test_screen_with_32bit_row_ids_on_device(gpu_ctx, oracle):
+    """Device-resident shard handed over with int32 row ids (spkm_shard_create_dev, ir_bits = 32)."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    p, n, K, s = 512, 5000, 50, 26
+    X = random_csc(p, n, s, seed=91)
+    Cm = np.random.default_rng(4).standard_normal((p, K)) * 0.3
+    dev = f"cuda:{gpu_ctx.device}"
+    pad = 48
+    jc = torch.tensor(X.indptr.astype(np.int64), device=dev)
+    ir = torch.zeros(X.nnz + pad, dtype=torch.int32, device=dev)
+    xv = torch.zeros(X.nnz + pad, dtype=torch.float64, device=dev)
+    ir[:X.nnz] = torch.tensor(X.indices.astype(np.int32), device=dev)
+    xv[:X.nnz] = torch.tensor(X.data, device=dev)
+    eng = LloydEngine(Shard.from_device(gpu_ctx, p, jc, ir, xv, nnz=X.nnz), K, s / p)
+    eng.assign_accumulate_step(torch.tensor(np.ascontiguousarray(Cm.T), device=dev))
+    torch.cuda.synchronize()
+    assert eng.last_path_info()[0] == 1
+    _check(eng, oracle, X, Cm, s / p)
+
+
 def test_screen_sends_ties_to_the_exact_list(gpu_ctx, oracle):
     """Duplicate centroids (exact ties), near-duplicates (sqrt-collapse band) and empty-ish points
     cannot be certified by any f32 screen: they must take the exact route and still match."""
