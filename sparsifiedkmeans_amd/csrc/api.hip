@@ -835,6 +835,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     long long chunk = n / ((long long)(quad ? ctx->bmapq_blocks / 4 : ctx->bmap_streams) * 8);
     chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
     chunk = (chunk / sweep) * sweep;
+    if (const char* ev = getenv("SPKM_CHUNK")) chunk = std::max<long long>(sweep, (atoll(ev) / sweep) * sweep); // tuning aid
     {
         const size_t lds = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
         const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4) : (const void*)k_screen_tile<IR>;
