@@ -755,7 +755,10 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
     if (K <= 16) return false; // a single exact tile already streams X once
     if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
     const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    if ((K + SCREEN_KT - 1) / SCREEN_KT > nb) return false;
+    const int tiles = (K + SCREEN_KT - 1) / SCREEN_KT;
+    if (tiles > nb) return false;
+    // the 4-lanes-per-point kernel gives every tile at least one workgroup per XCD
+    if (screen_use_quad(s) && tiles > ((nb % 8 == 0) ? nb / 8 : nb)) return false;
     // phase 2 needs the centroid column + slab + at least 8 staged points per wave
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     if (s->p * 20 + 64 + 16 * 8 * per_pt > ctx->lds_max) return false;

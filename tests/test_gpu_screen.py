@@ -69,6 +69,17 @@ def test_screen_kernel_variants_equal_oracle(gpu_ctx, oracle, p, n, K, s):
     _check(eng, oracle, X, Cm, s / p)
 
 
+def test_more_tiles_than_workgroups_per_xcd_takes_the_exact_path(gpu_ctx, oracle):
+    """K = 1100 needs 35 screen tiles; an XCD has 32 workgroups, so the call must fall back to the exact tiles
+    (and still be right) instead of failing."""
+    p, n, K, s = 64, 1500, 1100, 8
+    X = random_csc(p, n, s, seed=12)
+    Cm = np.random.default_rng(12).standard_normal((p, K)) * 0.3
+    eng, path, listed = _run(gpu_ctx, X, Cm, s / p)
+    assert path == 0
+    _check(eng, oracle, X, Cm, s / p)
+
+
 def test_screen_with_32bit_row_ids_on_device(gpu_ctx, oracle):
     """Device-resident shard handed over with int32 row ids (spkm_shard_create_dev, ir_bits = 32)."""
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard

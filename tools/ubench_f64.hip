@@ -96,6 +96,34 @@ __global__ __launch_bounds__(1024) void k(double* out, int iters, double seed)
                 asm volatile("v_mov_b64_dpp %0, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %2, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
                              "v_mov_b64_dpp %4, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %5, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %6, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %7, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
+            } else if (MODE == 15) { // v_pk_fma_f16 x8 independent (32-bit registers)
+                int h0 = addr, h1 = addr + 1, h2 = addr + 2, h3 = addr + 3, h4 = addr + 4, h5 = addr + 5, h6 = addr + 6, h7 = addr + 7;
+                asm volatile("v_pk_fma_f16 %0, %0, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n v_pk_fma_f16 %2, %2, %8, %8\n v_pk_fma_f16 %3, %3, %8, %8\n"
+                             "v_pk_fma_f16 %4, %4, %8, %8\n v_pk_fma_f16 %5, %5, %8, %8\n v_pk_fma_f16 %6, %6, %8, %8\n v_pk_fma_f16 %7, %7, %8, %8"
+                             : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(h6), "+v"(h7) : "v"(addr));
+                addr ^= (h0 ^ h1 ^ h2 ^ h3 ^ h4 ^ h5 ^ h6 ^ h7) & 0;
+            } else if (MODE == 16) { // v_pk_add_f16 x8 independent
+                int h0 = addr, h1 = addr + 1, h2 = addr + 2, h3 = addr + 3, h4 = addr + 4, h5 = addr + 5, h6 = addr + 6, h7 = addr + 7;
+                asm volatile("v_pk_add_f16 %0, %0, %8\n v_pk_add_f16 %1, %1, %8\n v_pk_add_f16 %2, %2, %8\n v_pk_add_f16 %3, %3, %8\n"
+                             "v_pk_add_f16 %4, %4, %8\n v_pk_add_f16 %5, %5, %8\n v_pk_add_f16 %6, %6, %8\n v_pk_add_f16 %7, %7, %8"
+                             : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(h6), "+v"(h7) : "v"(addr));
+                addr ^= (h0 ^ h1 ^ h2 ^ h3 ^ h4 ^ h5 ^ h6 ^ h7) & 0;
+            } else if (MODE == 17) { // v_pk_add_f32 x8 independent
+                asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                             "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one));
+            } else if (MODE == 18) { // v_dot2_f32_f16 x8 (f16 pairs, f32 accumulate)
+                float g0 = 1.f, g1 = 2.f, g2 = 3.f, g3 = 4.f;
+                asm volatile("v_dot2_f32_f16 %0, %4, %4, %0\n v_dot2_f32_f16 %1, %4, %4, %1\n v_dot2_f32_f16 %2, %4, %4, %2\n v_dot2_f32_f16 %3, %4, %4, %3\n"
+                             "v_dot2_f32_f16 %0, %4, %4, %0\n v_dot2_f32_f16 %1, %4, %4, %1\n v_dot2_f32_f16 %2, %4, %4, %2\n v_dot2_f32_f16 %3, %4, %4, %3"
+                             : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3) : "v"(addr));
+                a0 += g0 + g1 + g2 + g3;
+            } else if (MODE == 19) { // ds_read_b128 x4 in flight, 4 lanes per 64-B segment
+                float4 t0, t1, t2, t3;
+                int ad = (threadIdx.x & 3) * 16 + ((threadIdx.x >> 2) & 15) * 128 * 5 + ((threadIdx.x >> 3) & 1) * 64;
+                asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:1024\n ds_read_b128 %2, %4 offset:2048\n ds_read_b128 %3, %4 offset:3072\n s_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ad));
+                a0 += t0.x + t1.x + t2.x + t3.x;
             } else if (MODE == 10) { // v_fma_f32 x8 independent
                 float f = (float)seed;
                 asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n"
@@ -165,6 +193,11 @@ int main()
         run<12>("f32 screen step scalar+dpp (8 instr)", t, 1);
         run<13>("v_pk_fma_f32 independent", t, 1);
         run<14>("v_mov_b64_dpp", t, 1);
+        run<15>("v_pk_fma_f16 independent", t, 1);
+        run<16>("v_pk_add_f16 independent", t, 1);
+        run<17>("v_pk_add_f32 independent", t, 1);
+        run<18>("v_dot2_f32_f16", t, 1);
+        run<19>("ds_read_b128 (4 in flight; counts 8 per REP)", t, 1);
     }
     return 0;
 }
