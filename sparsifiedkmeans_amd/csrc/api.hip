@@ -388,7 +388,8 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
     const int per = NB / NX;
     if (per < G) return SPKM_ERR_UNSUPPORTED;
     // issue cycles per 16-point step: rounds * (32 + 32 pl (+12 for the second address)) + overhead
-    auto cost = [&](int pl) { return (double)rounds * (32.0 + 32.0 * pl + (pl == 4 ? 12.0 : 0.0)) + 400.0; };
+    // (overhead fitted to K = 37 / 100 / 200 timings: a narrow tile costs about half a full one at 13 rounds)
+    auto cost = [&](int pl) { return (double)rounds * (32.0 + 32.0 * pl + (pl == 4 ? 12.0 : 0.0)) + 560.0; };
     std::vector<double> w(G, cost(4));
     w[G - 1] = cost(pl_last);
     if (const char* ev = getenv("SPKM_QUAD_W")) w[G - 1] = cost(4) * atof(ev); // tuning aid
