@@ -389,7 +389,12 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
     if (per < G) return SPKM_ERR_UNSUPPORTED;
     // issue cycles per 16-point step: rounds * (32 + 32 pl (+12 for the second address)) + overhead
     // (overhead fitted to K = 37 / 100 / 200 timings: a narrow tile costs about half a full one at 13 rounds)
-    auto cost = [&](int pl) { return (double)rounds * (32.0 + 32.0 * pl + (pl == 4 ? 12.0 : 0.0)) + 560.0; };
+    auto cost = [&](int pl) {
+        // full tile + one extra centroid per lane: 32 issue cycles per round by count, ~60 measured (its 4-B LDS
+        // reads of 16 random 16-B rows conflict)
+        if (pl == 5) return (double)rounds * (32.0 + 128.0 + 12.0 + 60.0) + 580.0;
+        return (double)rounds * (32.0 + 32.0 * pl + (pl == 4 ? 12.0 : 0.0)) + 560.0;
+    };
     std::vector<double> w(G, cost(4));
     w[G - 1] = cost(pl_last);
     if (const char* ev = getenv("SPKM_QUAD_W")) w[G - 1] = cost(4) * atof(ev); // tuning aid
@@ -807,19 +812,25 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
                            0, ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, sm->xfs, (IR*)sm->irs);
     }
-    // narrow last tile (4-lanes-per-point kernel): 1 or 2 centroid pairs per lane instead of 4
+    // Last tile of the 4-lanes-per-point kernel.  <= 4 centroids: no tile of their own -- the workgroups of the
+    // previous tile carry them as one extra centroid per lane (pl 5; needs (p+1) x 16 B more LDS); <= 16: a
+    // narrow tile with 1 or 2 centroid pairs per lane instead of 4.  Gs = tiles that have workgroups / result slots.
     const int k_last = K - (G - 1) * SCREEN_KT;
-    const int pl_last = !quad ? 4 : (k_last <= 8 ? 1 : (k_last <= 16 ? 2 : 4));
+    int pl_last = !quad ? 4 : (k_last <= 8 ? 1 : (k_last <= 16 ? 2 : 4));
+    if (quad && G >= 2 && k_last <= 4 && !getenv("SPKM_NO_FUSE") &&
+        (size_t)(p + 1) * (SCREEN_KT * 4 + 16) + 16 <= ctx->lds_max)
+        pl_last = 5;
+    const int Gs = pl_last == 5 ? G - 1 : G;
     const int q_rounds = (s->fixed_s + 3) / 4;
-    if (quad) rc = build_blockmap_quad(ctx, G, pl_last, q_rounds);
+    if (quad) rc = build_blockmap_quad(ctx, Gs, pl_last, q_rounds);
     else rc = build_blockmap(ctx, G);
     if (rc) return rc;
     const size_t tile_floats = (size_t)G * (p + 1) * SCREEN_KT;
     if ((rc = ensure(ctx, ctx->t32, tile_floats * 4))) return rc;
     if ((rc = ensure(ctx, ctx->cmax, 64))) return rc;
-    if ((rc = ensure(ctx, ctx->scr_m1, (size_t)G * n * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->scr_m2, (size_t)G * n * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->scr_k, (size_t)G * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->scr_m1, (size_t)Gs * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->scr_m2, (size_t)Gs * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->scr_k, (size_t)Gs * n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->list, (size_t)n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->nlist, 64))) return rc;
     if ((rc = ensure(ctx, ctx->ct, pk * 8))) return rc;
@@ -841,7 +852,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     chunk = (chunk / sweep) * sweep;
     if (const char* ev = getenv("SPKM_CHUNK")) chunk = std::max<long long>(sweep, (atoll(ev) / sweep) * sweep); // tuning aid
     {
-        const size_t lds = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
+        const size_t lds = (size_t)(p + 1) * (SCREEN_KT * 4 + (pl_last == 5 ? 16 : 0)) + 16;
         const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4) : (const void*)k_screen_tile<IR>;
         HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(timing_begin(ctx));
@@ -853,7 +864,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float* a_m1 = (float*)ctx->scr_m1.p;
         float* a_m2 = (float*)ctx->scr_m2.p;
         int* a_k = (int*)ctx->scr_k.p;
-        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k};
+        int a_extra = G - 1; // buffer / centroid block of the carried remainder (pl 5)
+        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -861,7 +873,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // 2. certification, 3. exact evaluation of the uncertified points
     const int cb = (int)std::min<long long>(4096, (n + 255) / 256);
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), 0, ctx->stream, (const float*)ctx->scr_m1.p,
-                       (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, G, (const double*)s->xn1,
+                       (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,

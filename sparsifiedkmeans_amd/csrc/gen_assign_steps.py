@@ -284,36 +284,44 @@ QT = QX + 8
 def quad_round_block(nv: int, pl: int) -> str:
     """f32 SCREEN round of the 4-lanes-per-point kernel (screen.hip, k_screen_quad): nv <= 4 consecutive
     entries of a point, owned by lanes 0..nv-1 of its quad; pl = centroid PAIRS per lane (4: full tile of 32
-    centroids, two 16-B reads; 2: 16 centroids, one 16-B read; 1: 8 centroids, one 8-B read).  Per entry m:
+    centroids, two 16-B reads; 2: 16 centroids, one 16-B read; 1: 8 centroids, one 8-B read; 5: a full tile
+    plus ONE extra centroid per lane held in a second LDS region with 16-B rows).  Per entry m:
         a_m = off0 + ro[quad lane m]                   v_add_u32_dpp quad_perm:[m,m,m,m]
-        b_m = a_m + delta                              v_add_u32            (pl = 4 only: the other half-row,
+        b_m = a_m + delta                              v_add_u32            (pl >= 4: the other half-row,
                                                                              +64 or -64 by point slot)
-        T   = LDS[a_m] (, LDS[b_m])                    ds_read_b128 / b64
+        e_m = (a_m >> 3) + ce                          v_lshrrev_b32, v_add_u32   (pl = 5: row*16 + lane const)
+        T   = LDS[a_m] (, LDS[b_m]) (, LDS[e_m])       ds_read_b128 / b64 (/ b32)
         x_m = xi[quad lane m]                          v_mov_b32_dpp
         T  += (x_m, x_m)   (pl pairs)                  v_pk_add_f32 op_sel_hi:[1,0]
         acc_j = T_j * T_j + acc_j   (j < pl)           v_pk_fma_f32
-    All reads of the round are issued first (up to 8 x 16 B per lane in flight), then consumed in order.  The
-    128-bit read results and the broadcast x need their halves as separate 64-bit operands, which inline-asm
-    operands cannot express: they live in v[QX:QT+31], named literally and declared as clobbers."""
+        E += x_m ; acc4 = E * E + acc4                 v_add_f32, v_fma_f32  (pl = 5)
+    All reads of the round are issued first (up to 8 x 16 B + 4 x 4 B per lane in flight), then consumed in
+    order.  The 128-bit read results and the broadcast x need their halves as separate operands, which
+    inline-asm operands cannot express: they live in v[QX:QT+35], named literally and declared as clobbers."""
     L = ["s_nop 1"]
+    two = pl >= 4
     for m in range(nv):
         L.append(f"v_add_u32_dpp %[a{m}], %[ro], %[off0] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
         T = QT + 8 * m
-        if pl == 4:
+        if two:
             L.append(f"v_add_u32 %[b{m}], %[a{m}], %[delta]")
             L.append(f"ds_read_b128 v[{T}:{T+3}], %[a{m}]")
             L.append(f"ds_read_b128 v[{T+4}:{T+7}], %[b{m}]")
+            if pl == 5:
+                L.append(f"v_lshrrev_b32 %[e{m}], 3, %[a{m}]")
+                L.append(f"v_add_u32 %[e{m}], %[e{m}], %[ce]")
+                L.append(f"ds_read_b32 v{QT + 32 + m}, %[e{m}]")
         elif pl == 2:
             L.append(f"ds_read_b128 v[{T}:{T+3}], %[a{m}]")
         else:
             L.append(f"ds_read_b64 v[{T}:{T+1}], %[a{m}]")
     for m in range(nv):
         L.append(f"v_mov_b32_dpp v{QX + 2 * m}, %[xi] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
-    per = 2 if pl == 4 else 1
+    per = (3 if pl == 5 else 2) if two else 1
     nreads = per * nv
     for m in range(nv):
         X = QX + 2 * m
-        for h in range(per):
+        for h in range(2 if two else 1):
             T = QT + 8 * m + 4 * h
             L.append(f"s_waitcnt lgkmcnt({nreads - 1 - (per * m + h)})")
             L.append(f"v_pk_add_f32 v[{T}:{T+1}], v[{T}:{T+1}], v[{X}:{X+1}] op_sel_hi:[1,0]")
@@ -322,25 +330,40 @@ def quad_round_block(nv: int, pl: int) -> str:
             L.append(f"v_pk_fma_f32 %[acc{2*h}], v[{T}:{T+1}], v[{T}:{T+1}], %[acc{2*h}]")
             if pl >= 2:
                 L.append(f"v_pk_fma_f32 %[acc{2*h+1}], v[{T+2}:{T+3}], v[{T+2}:{T+3}], %[acc{2*h+1}]")
+        if pl == 5:
+            E = QT + 32 + m
+            L.append(f"s_waitcnt lgkmcnt({nreads - 1 - (per * m + 2)})")
+            L.append(f"v_add_f32 v{E}, v{E}, v{X}")
+            L.append(f"v_fma_f32 %[acc4], v{E}, v{E}, %[acc4]")
     return "\\n\\t".join(L)
 
 
 def quad_round_func(nv: int, pl: int) -> str:
     nacc = pl if pl < 4 else 4
     outs = [f'[acc{j}] "+v"(acc{j})' for j in range(nacc)]
+    if pl == 5:
+        outs.append('[acc4] "+v"(acc4)')
     outs += [f'[a{m}] "=&v"(a{m})' for m in range(nv)]
-    if pl == 4:
+    if pl >= 4:
         outs += [f'[b{m}] "=&v"(b{m})' for m in range(nv)]
+    if pl == 5:
+        outs += [f'[e{m}] "=&v"(e{m})' for m in range(nv)]
     ins = ['[xi] "v"(xi)', '[ro] "v"(ro)', '[off0] "v"(off0)']
-    if pl == 4:
+    if pl >= 4:
         ins.append('[delta] "v"(delta)')
-    clob = ", ".join(f'"v{r}"' for r in range(QX, QT + 32))
-    decl = ", ".join([f"a{m}" for m in range(nv)] + ([f"b{m}" for m in range(nv)] if pl == 4 else []))
+    if pl == 5:
+        ins.append('[ce] "v"(ce)')
+    clob = ", ".join(f'"v{r}"' for r in range(QX, QT + 36))
+    names = [f"a{m}" for m in range(nv)]
+    if pl >= 4:
+        names += [f"b{m}" for m in range(nv)]
+    if pl == 5:
+        names += [f"e{m}" for m in range(nv)]
     return f"""template <>
-__device__ __forceinline__ void quad_round<{nv}, {pl}>(int xi, int ro, int off0, int delta,
-    double& acc0, double& acc1, double& acc2, double& acc3)
+__device__ __forceinline__ void quad_round<{nv}, {pl}>(int xi, int ro, int off0, int delta, int ce,
+    double& acc0, double& acc1, double& acc2, double& acc3, float& acc4)
 {{
-    int {decl};
+    int {", ".join(names)};
     asm volatile("{quad_round_block(nv, pl)}"
                  : {", ".join(outs)}
                  : {", ".join(ins)}
@@ -377,8 +400,8 @@ def main():
         out += [screen32_func(n, irb) for n in range(1, 33)]
     out.append("// rounds of the 4-lanes-per-point f32 screen (see gen_assign_steps.py, quad_round_block)\n"
                "template <int NV, int PL>\n__device__ __forceinline__ void quad_round(int xi, int ro, int off0, "
-               "int delta,\n    double& acc0, double& acc1, double& acc2, double& acc3);\n\n")
-    for pl in (1, 2, 4):
+               "int delta, int ce,\n    double& acc0, double& acc1, double& acc2, double& acc3, float& acc4);\n\n")
+    for pl in (1, 2, 4, 5):
         out += [quad_round_func(nv, pl) for nv in range(1, 5)]
     with open(os.path.join(here, "assign_steps.inc"), "w") as f:
         f.write("".join(out))

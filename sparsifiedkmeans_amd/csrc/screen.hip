@@ -32,8 +32,11 @@
 #define SCREEN_KT 32 // centroids per tile (two per lane of a 16-lane row)
 
 // T32[g][r][kk] = -fl32(C[(g*32+kk)*p + r] / gamma), row p zero; cmax_bits = max |C/gamma| (f64 bits, atomicMax).
-// pl_last < 4 (4-lanes-per-point kernel only): the last tile holds <= 16 centroids in floats 0..15 of each row
-// and a second copy of them in floats 16..31 (the two point pairs of an LDS phase read different copies).
+// 4-lanes-per-point kernel only:
+//  * pl_last = 1 / 2: the last tile holds <= 16 centroids in floats 0..15 of each row and a second copy of them
+//    in floats 16..31 (the two point pairs of an LDS phase read different copies);
+//  * pl_last = 5: the last <= 4 centroids are carried by the workgroups of tile G-2; the buffer of "tile" G-1
+//    then holds their (p+1) x 4 table E[r][j] = -fl32(C[(32 (G-1) + j)*p + r] / gamma) (16-B rows).
 __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
                                  float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits, int pl_last)
 {
@@ -42,10 +45,17 @@ __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         int kk = (int)(t % SCREEN_KT);
         const size_t rest = t / SCREEN_KT;
-        const int r = (int)(rest % (p + 1));
+        int r = (int)(rest % (p + 1));
         const int g = (int)(rest / (p + 1));
-        if (g == G - 1 && pl_last < 4) kk &= 15;
-        const int k = g * SCREEN_KT + kk;
+        int k = g * SCREEN_KT + kk;
+        if (g == G - 1 && pl_last == 5) {
+            const size_t local = t - (size_t)g * (p + 1) * SCREEN_KT; // compact (p+1) x 4 table first, rest unused
+            r = (int)(local >> 2);
+            k = local < (size_t)(p + 1) * 4 ? g * SCREEN_KT + (int)(local & 3) : K;
+        } else if (g == G - 1 && pl_last < 4) {
+            kk &= 15;
+            k = g * SCREEN_KT + kk;
+        }
         float v = 0.f;
         if (r < p && k < K) {
             double c = C[(size_t)k * p + r];
@@ -638,7 +648,8 @@ template <int NR, typename IR, int PL>
 __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
                                                  int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
-                                                 int* __restrict__ ko, char* smem, unsigned* ticket)
+                                                 int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
+                                                 int extra_k0)
 {
     constexpr int RS = SCREEN_KT * 4; // 128-B rows
     constexpr int PPS = 16;
@@ -649,6 +660,9 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     // different copies of a narrow tile's row (PL < 4).
     const bool swp = (ps & 2) != 0;
     const int off0 = l4 * (PL == 1 ? 8 : 16) + (swp ? 64 : 0), off1 = l4 * 16 + (swp ? 0 : 64);
+    // PL = 5: the lane's extra centroid extra_k0 + l4 sits in a table of 16-B rows at extra_base:
+    // its address is (a >> 3) + ce for a = row * 128 + off0
+    const int ce = extra_base + l4 * 4 - (off0 >> 3);
     const int nchunks = (n + chunk_points - 1) / chunk_points;
     const int R = chunk_points / PPS;
     // chunk ids of this workgroup: (stream + ci * nstreams) * mul + add   (mul/add: XCD-local numbering)
@@ -687,15 +701,16 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             SPKM_QUAD_LOAD(11) SPKM_QUAD_LOAD(12) SPKM_QUAD_LOAD(13) SPKM_QUAD_LOAD(14) SPKM_QUAD_LOAD(15)
 #undef SPKM_QUAD_LOAD
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; // two f32 sums each (bit pattern 0 = (0.f, 0.f))
+            float acc4 = 0.f;                                       // PL = 5: the lane's extra centroid
             // the last round broadcasts only the nvl = fixed_s - 4 (NR - 1) entries the column still has
 #define SPKM_QUAD_ROUND(r)                                                                                  \
     if constexpr (NR > r) {                                                                                 \
         const int xi = __builtin_bit_cast(int, x##r);                                                       \
         const int ro = (int)__umul24((unsigned)o##r, (unsigned)RS);                                         \
-        if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);   \
-        else if (nvl == 3) quad_round<3, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);            \
-        else if (nvl == 2) quad_round<2, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);            \
-        else quad_round<1, PL>(xi, ro, off0, off1 - off0, acc0, acc1, acc2, acc3);                          \
+        if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);   \
+        else if (nvl == 3) quad_round<3, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);            \
+        else if (nvl == 2) quad_round<2, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);            \
+        else quad_round<1, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);                          \
     }
             SPKM_QUAD_ROUND(0) SPKM_QUAD_ROUND(1) SPKM_QUAD_ROUND(2) SPKM_QUAD_ROUND(3) SPKM_QUAD_ROUND(4)
             SPKM_QUAD_ROUND(5) SPKM_QUAD_ROUND(6) SPKM_QUAD_ROUND(7) SPKM_QUAD_ROUND(8) SPKM_QUAD_ROUND(9)
@@ -709,11 +724,12 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             // branch-free smallest / second smallest / argmin over the lane's 2 PL values (ascending k, first wins)
             float lo = __builtin_inff(), hi = __builtin_inff();
             int klo = -1;
+            constexpr int NPAIR = PL == 5 ? 4 : PL;
 #pragma unroll
-            for (int a = 0; a < PL; a++) {
+            for (int a = 0; a < NPAIR; a++) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const int k = PL == 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
+                    const int k = PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
                                           : k0 + 2 * PL * l4 + 2 * a + h;
                     float v = h ? acc[a].y : acc[a].x;
                     v = (k < K) ? v : __builtin_inff();
@@ -722,6 +738,14 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                     klo = less ? k : klo;
                     lo = less ? v : lo;
                 }
+            }
+            if (PL == 5) {
+                const int k = extra_k0 + l4;
+                const float v = (k < K) ? acc4 : __builtin_inff();
+                const bool less = v < lo;
+                hi = __builtin_fminf(hi, __builtin_fmaxf(lo, v));
+                klo = less ? k : klo;
+                lo = less ? v : lo;
             }
             const float m1 = quad_min_f32(lo);
             const bool win = (lo == m1);
@@ -742,28 +766,36 @@ template <int NR, typename IR>
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
-    float* __restrict__ scr_m2, int* __restrict__ scr_k)
+    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
     if (bm.tile < 0) return;
     const int tid = threadIdx.x;
+    const int pl = (bm.pad >> 16) & 0xff; // centroid pairs per lane in this workgroup's tile (5: 4 + one extra centroid)
     const size_t tile_bytes = (size_t)(p + 1) * SCREEN_KT * 4;
+    const size_t extra_bytes = pl == 5 ? (size_t)(p + 1) * 16 : 0;
     {
         const float4* src = reinterpret_cast<const float4*>(T32 + (size_t)bm.tile * (p + 1) * SCREEN_KT);
         float4* dst = reinterpret_cast<float4*>(smem);
         for (size_t t = tid; t < tile_bytes / 16; t += blockDim.x) dst[t] = src[t];
+        if (pl == 5) {
+            const float4* esrc = reinterpret_cast<const float4*>(T32 + (size_t)extra_tile * (p + 1) * SCREEN_KT);
+            float4* edst = reinterpret_cast<float4*>(smem + tile_bytes);
+            for (size_t t = tid; t < extra_bytes / 16; t += blockDim.x) edst[t] = esrc[t];
+        }
     }
-    unsigned* ticket = reinterpret_cast<unsigned*>(smem + tile_bytes);
+    unsigned* ticket = reinterpret_cast<unsigned*>(smem + tile_bytes + extra_bytes);
     if (tid == 0) *ticket = 0u;
     __syncthreads();
     float* m1o = scr_m1 + (size_t)bm.tile * n;
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
-    const int pl = (bm.pad >> 16) & 0xff; // centroid pairs per lane in this workgroup's tile
-    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket);
-    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket);
-    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket);
+    const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
+    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
+    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
+    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
+    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
