@@ -153,6 +153,7 @@ def main():
     achieved = b_iter / (k_ms * 1e-3) / 1e9 if k_ms == k_ms else None
     ops = 3.0 * nnz_local * K
     traffic = None
+    valu_pmc = {}
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
@@ -162,6 +163,8 @@ def main():
             if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
                     and str(rec.get("kernel", "")).startswith(kern)):
                 traffic = rec.get("hbm_bytes_per_launch")
+                valu_pmc = {"issue_utilization_pmc": rec.get("valu_issue_utilization"),
+                            "effective_clock_ghz_pmc": rec.get("effective_clock_ghz")}
         except Exception:
             traffic = None
 
@@ -195,7 +198,7 @@ def main():
                              "for 4 points x 16 centroids); see DESIGN.md section 4"},
         "valu": {"distance_terms_per_s": (nnz_local * K) / (k_ms * 1e-3) if k_ms == k_ms else None,
                  "exact_f64_op_equivalent_Tops": ops / (k_ms * 1e-3) / 1e12 if k_ms == k_ms else None,
-                 "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS},
+                 "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS, **valu_pmc},
         "whole_iter_gbs": b_iter / (elapsed / args.steps) / 1e9,
         "fwht": fw,
     }
