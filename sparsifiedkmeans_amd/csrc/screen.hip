@@ -454,8 +454,16 @@ __global__ __launch_bounds__(256) void k_hist(const int* __restrict__ assign, lo
     for (int k = threadIdx.x; k < K; k += blockDim.x) hist[k] = 0;
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x)
-        atomicAdd(&hist[assign[i]], 1u);
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = assign[i];
+        const unsigned long long act = __ballot(1);
+        const int k0 = __builtin_amdgcn_readfirstlane(k);
+        if (__ballot(k == k0) == act) { // the whole wave holds one cluster: one atomic for all lanes
+            if (__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u)) == 0)
+                atomicAdd(&hist[k0], (unsigned)__builtin_popcountll(act));
+        } else
+            atomicAdd(&hist[k], 1u);
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += blockDim.x)
         if (hist[k]) atomicAdd(&nk[k], (unsigned long long)hist[k]);

@@ -204,7 +204,19 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
     const long long hi = (lo + per < n) ? lo + per : n;
     for (int k = tid; k < K; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
-    for (long long i = lo + tid; i < hi; i += blockDim.x) atomicAdd(&cnt[assign[i]], 1u);
+    // Neighbouring points very often share a cluster (any dataset stored roughly by class, and every dataset once
+    // the counting sort of the previous iteration is reflected in its order): when all active lanes of a wave
+    // hold the same k, one lane adds the wave's population and the lanes take consecutive ranks.
+    for (long long i = lo + tid; i < hi; i += blockDim.x) {
+        const int k = assign[i];
+        const unsigned long long act = __ballot(1);
+        const int k0 = __builtin_amdgcn_readfirstlane(k);
+        if (__ballot(k == k0) == act) {
+            if (__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u)) == 0)
+                atomicAdd(&cnt[k0], (unsigned)__builtin_popcountll(act));
+        } else
+            atomicAdd(&cnt[k], 1u);
+    }
     __syncthreads();
     for (int k = tid; k < K; k += blockDim.x) {
         base[k] = cnt[k] ? atomicAdd(&cursor[k], (unsigned long long)cnt[k]) : 0ull;
@@ -213,7 +225,16 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
     __syncthreads();
     for (long long i = lo + tid; i < hi; i += blockDim.x) {
         const int k = assign[i];
-        const unsigned int r = atomicAdd(&cnt[k], 1u);
+        const unsigned long long act = __ballot(1);
+        const int k0 = __builtin_amdgcn_readfirstlane(k);
+        unsigned int r;
+        if (__ballot(k == k0) == act) {
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+            unsigned first = 0;
+            if (rank == 0) first = atomicAdd(&cnt[k0], (unsigned)__builtin_popcountll(act));
+            r = (unsigned)__builtin_amdgcn_readfirstlane((int)first) + rank;
+        } else
+            r = atomicAdd(&cnt[k], 1u);
         perm[base[k] + r] = (int)i;
     }
 }
