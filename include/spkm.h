@@ -92,14 +92,16 @@ int spkm_hadamard_pthreads_host(spkm_ctx *ctx, uint64_t m, uint64_t n, const dou
  * ------------------------------------------------------------------------------------------ */
 
 /* Upload a CSC block of n points (columns) of dimension p; indices are validated and narrowed
- * (row ids to 16 bit when p <= 65536).  Rows must ascend within a column (MATLAB invariant). */
+ * (row ids to 16 bit when p <= 65536).  Rows must ascend within a column (MATLAB invariant).
+ * A shard holds at most 0x7ff00000 (~2.1e9) points: SPKM_ERR_UNSUPPORTED beyond (shard the data). */
 int spkm_shard_create_host(spkm_ctx *ctx, uint64_t p, uint64_t n, const uint64_t *jc, const uint64_t *ir,
                            const double *x, spkm_shard **out);
 /* Adopt device arrays without copying (caller keeps them alive): d_jc int64[n+1],
  * d_ir uint32 (ir_bits=32) or uint16 (ir_bits=16), d_x double; both hold nnz entries inside
  * allocations of `capacity` >= nnz entries.  With capacity >= nnz + 16 and a fixed number of
- * entries per column the fastest kernel variant is used (it reads, and ignores, up to 15
- * entries past a column's end).  Rows must ascend within a column; not re-validated here. */
+ * entries per column the fastest exact kernel variant is used (it reads, and ignores, up to 15
+ * entries past a column's end); capacity >= nnz + 48 also unlocks the certified f32 screen for K > 16.
+ * Rows must ascend within a column; not re-validated here. */
 int spkm_shard_create_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t nnz, const int64_t *d_jc,
                           const void *d_ir, int ir_bits, const double *d_x, uint64_t capacity,
                           spkm_shard **out);

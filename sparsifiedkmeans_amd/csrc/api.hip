@@ -202,7 +202,7 @@ extern "C" int spkm_shard_create_host(spkm_ctx* ctx, uint64_t p, uint64_t n, con
 {
     if (!ctx || !out || !jc || (!ir && jc[n]) || (!x && jc[n])) return SPKM_ERR_NULL_ARG;
     *out = nullptr;
-    if (p == 0 || p > 0x7fffffffull || n > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
+    if (p == 0 || p > 0x7fffffffull || n > 0x7ff00000ull) return SPKM_ERR_UNSUPPORTED; // kernels index points with int (+ a step of slack)
     int rc = validate_csc(p, n, jc, ir);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -261,7 +261,7 @@ extern "C" int spkm_shard_create_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint
 {
     if (!ctx || !out || !d_jc || (nnz && (!d_ir || !d_x))) return SPKM_ERR_NULL_ARG;
     *out = nullptr;
-    if (p == 0 || p > 0x7fffffffull || n > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
+    if (p == 0 || p > 0x7fffffffull || n > 0x7ff00000ull) return SPKM_ERR_UNSUPPORTED; // kernels index points with int (+ a step of slack)
     if (ir_bits != 16 && ir_bits != 32) return SPKM_ERR_BAD_VALUE;
     if (ir_bits == 16 && p > 65536) return SPKM_ERR_BAD_VALUE;
     if (capacity < nnz) return SPKM_ERR_BAD_VALUE;
