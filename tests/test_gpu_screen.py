@@ -136,9 +136,20 @@ def test_exact_path_is_used_when_not_eligible(gpu_ctx, oracle):
     eng, path, listed = _run(gpu_ctx, X, Cm, 0.05)
     assert path == 0
     _check(eng, oracle, X, Cm, 0.05)
-    X2 = random_csc(512, 4000, 26, seed=9)                   # K <= 16: single exact tile
-    eng, path, _ = _run(gpu_ctx, X2, Cm[:, :10], 0.05)
+    X2 = random_csc(512, 4000, 26, seed=9)                   # K = 1: nothing to screen
+    eng, path, _ = _run(gpu_ctx, X2, Cm[:, :1], 0.05)
     assert path == 0
+    _check(eng, oracle, X2, Cm[:, :1], 0.05)
+
+
+@pytest.mark.parametrize("K", [2, 3, 5, 8, 9, 10, 16])
+def test_small_k_takes_the_screen_and_equals_oracle(gpu_ctx, oracle, K):
+    """K <= 16: a single (narrow) screen tile + exact confirmation."""
+    X = random_csc(512, 4000, 26, seed=40 + K)
+    Cm = np.random.default_rng(K).standard_normal((512, K)) * 0.3
+    eng, path, listed = _run(gpu_ctx, X, Cm, 0.05)
+    assert path == 1
+    _check(eng, oracle, X, Cm, 0.05)
 
 
 def test_full_lloyd_with_screen_matches_oracle_loop(gpu_ctx, oracle):
