@@ -69,6 +69,18 @@ def test_screen_kernel_variants_equal_oracle(gpu_ctx, oracle, p, n, K, s):
     _check(eng, oracle, X, Cm, s / p)
 
 
+@pytest.mark.parametrize("p,n,K,s", [(1024, 6000, 100, 51), (512, 5000, 37, 26), (256, 3000, 64, 80)])
+def test_sixteen_lane_screen_kernel_equals_oracle(gpu_ctx, oracle, p, n, K, s, monkeypatch):
+    """The first-generation screen kernel (16 lanes per point; what columns longer than 64 entries use),
+    forced for ordinary shapes too."""
+    monkeypatch.setenv("SPKM_SCREEN_V1", "1")
+    X = random_csc(p, n, s, seed=p + K + 1)
+    Cm = np.random.default_rng(K + 1).standard_normal((p, K)) * 0.2
+    eng, path, listed = _run(gpu_ctx, X, Cm, s / p)
+    assert path == 1
+    _check(eng, oracle, X, Cm, s / p)
+
+
 def test_more_tiles_than_workgroups_per_xcd_takes_the_exact_path(gpu_ctx, oracle):
     """K = 1100 needs 35 screen tiles; an XCD has 32 workgroups, so the call must fall back to the exact tiles
     (and still be right) instead of failing."""
