@@ -638,6 +638,18 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //     acc[0..3] += (q + xs)^2                  v_pk_add_f32 x4, v_pk_fma_f32 x4
 // 10 issue slots per entry for 16 points x 32 centroids (the 16-lane layout above: 4 slots for 4 points),
 // no cross-lane reduction of the sums (each lane owns its 8 centroids), a 2-stage quad min for the winner.
+__device__ __forceinline__ float raw_min_f32(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float raw_max_f32(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int SEL> __device__ __forceinline__ int quad_bcast_i32(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, SEL * 0x55, 0xf, 0xf, false); // quad_perm:[SEL,SEL,SEL,SEL]
@@ -668,6 +680,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     // different copies of a narrow tile's row (PL < 4).
     const bool swp = (ps & 2) != 0;
     const int off0 = l4 * (PL == 1 ? 8 : 16) + (swp ? 64 : 0), off1 = l4 * 16 + (swp ? 0 : 64);
+    const bool tile_full = (PL >= 4 ? k0 + SCREEN_KT <= K : k0 + 8 * PL <= K) && (PL != 5 || extra_k0 + 4 <= K);
     // PL = 5: the lane's extra centroid extra_k0 + l4 sits in a table of 16-B rows at extra_base:
     // its address is (a >> 3) + ce for a = row * 128 + off0
     const int ce = extra_base + l4 * 4 - (off0 >> 3);
@@ -729,31 +742,42 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                 __builtin_bit_cast(f2v, acc2), __builtin_bit_cast(f2v, acc3)};
             // lane's centroids.  PL = 4: first read -> k0 + off0/4 + 0..3, second read -> k0 + off1/4 + 0..3;
             // PL < 4: k0 + 2 PL l4 + 0 .. 2 PL - 1 (either copy)
-            // branch-free smallest / second smallest / argmin over the lane's 2 PL values (ascending k, first wins)
+            // branch-free smallest / second smallest / argmin over the lane's values (ascending k, first wins).
+            // Raw v_min / v_max: the compiler's fminf / fmaxf add a canonicalising v_max per operand.  A NaN
+            // estimate never wins (v < lo is false) and drags `hi` down to `lo`: the point goes to the list.
             float lo = __builtin_inff(), hi = __builtin_inff();
             int klo = -1;
             constexpr int NPAIR = PL == 5 ? 4 : PL;
-#pragma unroll
-            for (int a = 0; a < NPAIR; a++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int k = PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
-                                          : k0 + 2 * PL * l4 + 2 * a + h;
-                    float v = h ? acc[a].y : acc[a].x;
-                    v = (k < K) ? v : __builtin_inff();
-                    const bool less = v < lo; // false for NaN: a NaN estimate never wins and the point goes to the list
-                    hi = __builtin_fminf(hi, __builtin_fmaxf(lo, v));
-                    klo = less ? k : klo;
-                    lo = less ? v : lo;
-                }
-            }
-            if (PL == 5) {
-                const int k = extra_k0 + l4;
-                const float v = (k < K) ? acc4 : __builtin_inff();
+            auto consider = [&](float v, int k) {
                 const bool less = v < lo;
-                hi = __builtin_fminf(hi, __builtin_fmaxf(lo, v));
+                hi = raw_min_f32(hi, raw_max_f32(lo, v));
                 klo = less ? k : klo;
                 lo = less ? v : lo;
+            };
+            if (tile_full) { // every slot of this tile is a real centroid (uniform): no masking
+#pragma unroll
+                for (int a = 0; a < NPAIR; a++) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+                        consider(h ? acc[a].y : acc[a].x, PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
+                                                                  : k0 + 2 * PL * l4 + 2 * a + h);
+                }
+                if (PL == 5) consider(acc4, extra_k0 + l4);
+            } else {
+#pragma unroll
+                for (int a = 0; a < NPAIR; a++) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int k = PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
+                                              : k0 + 2 * PL * l4 + 2 * a + h;
+                        const float v = h ? acc[a].y : acc[a].x;
+                        consider((k < K) ? v : __builtin_inff(), k);
+                    }
+                }
+                if (PL == 5) {
+                    const int k = extra_k0 + l4;
+                    consider((k < K) ? acc4 : __builtin_inff(), k);
+                }
             }
             const float m1 = quad_min_f32(lo);
             const bool win = (lo == m1);
