@@ -6,6 +6,7 @@
  * resident (spkm_lloyd('release') frees it).  NOT COMPILED HERE (needs MATLAB's mex.h and the HIP runtime
  * headers for the two small copies).  INTEGRATION.md shows the six-line patch to kmeans_sparsified.m.
  */
+#include <math.h>
 #include <string.h>
 #include <hip/hip_runtime_api.h>
 #include "mex.h"
