@@ -42,8 +42,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     double *dout = (double *)dmalloc(16);
     int32_t *dassign = (int32_t *)dmalloc((n + 1) * 4);
     hipMemcpy(dC, mxGetPr(C), pk * 8, hipMemcpyHostToDevice);
-    st = spkm_assign_dev(ctx, g_shard, K, dC, gamma, dassign, dmind, NULL, NULL);
-    if (st == SPKM_OK) st = spkm_accumulate_dev(ctx, g_shard, K, dassign, dred);
+    /* assignment + accumulation in one call: the certified f32 screen with exact f64 confirmation where the
+     * shard qualifies (every column the same length, as randsample_fixedNumberEntries produces), the exact
+     * kernels otherwise -- same outputs either way */
+    st = spkm_assign_accumulate_dev(ctx, g_shard, K, dC, gamma, dassign, dmind, NULL, NULL, dred);
     if (st == SPKM_OK) st = spkm_finalize_dev(ctx, p, K, dred, gamma, dC, dout);
     if (st == SPKM_OK) st = spkm_ctx_sync(ctx);
     if (st != SPKM_OK) mexErrMsgTxt(spkm_strerror(st));
