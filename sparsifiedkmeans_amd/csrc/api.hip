@@ -769,7 +769,7 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
     if (screen_use_quad(s) && tiles > ((nb % 8 == 0) ? nb / 8 : nb)) return false;
     // phase 2 needs the centroid column + slab + at least 8 staged points per wave
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
-    if (s->p * 20 + 64 + 16 * 8 * per_pt > ctx->lds_max) return false;
+    if (s->p * 20 + 1024 + 16 * 8 * per_pt > ctx->lds_max) return false;
     return true;
 }
 
@@ -901,7 +901,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const int threads = 1024, nw = threads / 64;
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     const size_t fixed_lds = (size_t)p * 20 + 16;
-    int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 64) / nw / per_pt);
+    // 1 KB headroom: the kernel also has 384 B of static LDS (per-wave partial statistics)
+    int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 1024) / nw / per_pt);
     pts = std::max(8, pts & ~7);
     if (const char* ev = getenv("SPKM_PTS")) pts = std::max(8, atoi(ev) & ~7);
     const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;

@@ -81,6 +81,25 @@ def test_sixteen_lane_screen_kernel_equals_oracle(gpu_ctx, oracle, p, n, K, s, m
     _check(eng, oracle, X, Cm, s / p)
 
 
+@pytest.mark.parametrize("seed", range(72))
+def test_random_shapes_equal_oracle(gpu_ctx, oracle, seed, monkeypatch):
+    """Seeded sweep over (p, n, K, s): whatever path the library picks, the outputs are the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.choice([64, 100, 128, 200, 256, 500, 512, 784, 1000, 1024]))
+    s = int(rng.integers(1, min(64, p) + 1))
+    K = int(rng.integers(2, 141))
+    n = int(rng.integers(500, 4001))
+    X = random_csc(p, n, s, seed=seed)
+    scale = float(rng.choice([1e-3, 0.3, 1.0, 50.0]))
+    Cm = rng.standard_normal((p, K)) * scale
+    if seed % 4 == 0:
+        Cm[:, K // 2] = Cm[:, 0]                                # an exact tie -> exact list
+    if seed % 3 == 2:
+        monkeypatch.setenv("SPKM_NO_SCREEN", "1")               # the all-exact kernels on the same shapes
+    eng, path, listed = _run(gpu_ctx, X, Cm, s / p)
+    _check(eng, oracle, X, Cm, s / p)
+
+
 def test_more_tiles_than_workgroups_per_xcd_takes_the_exact_path(gpu_ctx, oracle):
     """K = 1100 needs 35 screen tiles; an XCD has 32 workgroups, so the call must fall back to the exact tiles
     (and still be right) instead of failing."""
