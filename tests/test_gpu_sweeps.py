@@ -194,3 +194,48 @@ def test_driver_random_options(gpu_ctx, seed):
             direct = np.sqrt(((X[:, None, :] - Cp[:, :, None]) ** 2).sum(axis=0))      # Kb x n
             assert np.allclose(D2, direct.min(axis=0), rtol=1e-6, atol=1e-6)
             assert np.allclose(direct[IDX2 - 1, np.arange(n)], direct.min(axis=0), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_screen_equals_exact_kernels_midsize(gpu_ctx, seed, monkeypatch):
+    """1e5 .. 6e5 points (many chunks per workgroup, ragged last chunk, every tile / round variant by chance):
+    the screen path against the all-exact kernels, every point, bit for bit.  No CPU oracle at this size."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    rng = np.random.default_rng(9000 + seed)
+    p = int(rng.choice([64, 128, 256, 512, 1000, 1024]))
+    s = int(rng.integers(1, min(64, p) + 1))
+    K = int(rng.integers(2, 200))
+    n = int(rng.integers(100_000, 600_001))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    # fixed-stride CSC on the device: s distinct ascending rows per column
+    keys = torch.rand((n, p), generator=g, device="cuda")
+    rows = torch.topk(keys, s, dim=1, largest=False).indices.sort(dim=1).values.to(torch.int16)
+    del keys
+    lab = torch.randint(0, K, (n,), generator=g, device="cuda")
+    C = torch.randn((K, p), generator=g, device="cuda", dtype=torch.float64)
+    vals = C[lab[:, None], rows.long()] * (p / s) + 0.5 * torch.randn((n, s), generator=g, device="cuda", dtype=torch.float64)
+    pad = 48
+    ir = torch.zeros(n * s + pad, dtype=torch.int16, device="cuda")
+    xv = torch.zeros(n * s + pad, dtype=torch.float64, device="cuda")
+    ir[: n * s] = rows.reshape(-1)
+    xv[: n * s] = vals.reshape(-1)
+    jc = torch.arange(0, (n + 1) * s, s, dtype=torch.int64, device="cuda")
+    shard = Shard.from_device(gpu_ctx, p, jc, ir, xv, nnz=n * s)
+    gamma = s / p
+    centers = (C * gamma * (p / s)).contiguous()               # centres / gamma is comparable to the values
+    e1 = LloydEngine(shard, K, gamma)
+    e1.assign_accumulate_step(centers)
+    torch.cuda.synchronize()
+    assert e1.last_path_info()[0] == 1
+    monkeypatch.setenv("SPKM_NO_SCREEN", "1")
+    e0 = LloydEngine(shard, K, gamma)
+    e0.assign_accumulate_step(centers)
+    torch.cuda.synchronize()
+    assert e0.last_path_info()[0] == 0
+    assert torch.equal(e1.assign, e0.assign)
+    assert torch.equal(e1.mind, e0.mind)
+    pk = p * K
+    assert torch.equal(e1.reduce[pk:2 * pk + K], e0.reduce[pk:2 * pk + K])
+    scale = float(e0.reduce[:pk].abs().max().item())
+    assert float((e1.reduce[:pk] - e0.reduce[:pk]).abs().max().item()) <= 1e-11 * max(scale, 1e-300)
