@@ -138,6 +138,7 @@ def main():
         elapsed = float(t.item())
 
     path, listed = eng.last_path_info()
+    rounds_all, rounds = eng.last_screen_rounds()
     # dominant kernel (tiled assignment) durations of exactly the timed launches, HIP events on our stream
     buf = (C.c_double * max(args.steps, 1))()
     cnt = C.c_int()
@@ -188,7 +189,10 @@ def main():
                    "datagen_s": round(t_gen, 1), "final_obj": float(np.sqrt(out[1])),
                    "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "
                                   "bit-identical to the all-exact kernels)" if path == 1 else "exact f64 tiles",
-                   "uncertified_points_last_iter": listed},
+                   "uncertified_points_last_iter": listed,
+                   # rounds (of 4 stored entries) evaluated for all centroids / per column in the last iteration:
+                   # equal = plain screen; fewer = the two-phase screen switched itself on (converged, separated data)
+                   "screen_rounds_last_iter": [rounds_all, rounds]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel": dominant_kernel(path, s), "kernel_ms": k_ms,

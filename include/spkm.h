@@ -149,6 +149,13 @@ int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, c
 /* info[0] = path taken by the last spkm_assign_accumulate_dev (0 = exact tiles, 1 = screen + exact
  * confirmation), info[1] = points the screen could not certify.  Blocks on the stream. */
 int spkm_last_path_info(spkm_ctx *ctx, int64_t info[2]);
+/* After a screen call on the 4-lanes-per-point kernel: info[1] = rounds (of 4 stored entries) per column,
+ * info[0] = rounds evaluated for ALL centroids.  info[0] < info[1]: the two-phase screen was used -- partial
+ * sums (lower bounds) for every centroid, the remaining entries only for each tile's leader; the library
+ * switches it on by itself when the previous call found almost no point with a runner-up within 2x of the
+ * winner, and off again when it certifies poorly.  SPKM_NO_PRUNE=1 disables it; outputs never change.
+ * Both 0 after any other path. */
+int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
 
 /* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
  * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;

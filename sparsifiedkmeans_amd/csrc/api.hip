@@ -46,6 +46,7 @@ struct spkm_ctx {
     int assign_KT = 0, assign_G = 0; // of the last assign call
     int last_path = 0;               // 0 = exact tiled/generic, 1 = f32 screen + exact confirmation
     unsigned last_listed = 0;        // points sent to the exact list by the last screen (read lazily)
+    int last_rounds_all = 0, last_rounds = 0; // rounds for all centroids / total rounds of the last 4-lane screen call
     char errmsg[256] = {0};
 };
 
@@ -70,6 +71,9 @@ struct spkm_shard {
     hipEvent_t ev_nlist = nullptr;
     bool nlist_pending = false;
     int exact_cooldown = 0;      // calls left on the all-exact kernels after a poorly certifying screen
+    // two-phase screen (screen.hip, phase B): rounds evaluated for ALL centroids in the call whose counters are
+    // pending / in the next call (0 = all rounds, the plain screen), and calls left before pruning is retried
+    int prune_pending_a = 0, prune_next_a = 0, prune_cooldown = 0;
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -775,7 +779,7 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
 
 template <typename IR>
 static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d_centers, double gamma,
-                      int32_t* d_assign, double* d_mind, double* d_reduce)
+                      int32_t* d_assign, double* d_mind, double* d_reduce, int prune_a)
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
@@ -839,7 +843,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
@@ -867,7 +871,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float* a_m2 = (float*)ctx->scr_m2.p;
         int* a_k = (int*)ctx->scr_k.p;
         int a_extra = G - 1; // buffer / centroid block of the carried remainder (pl 5)
-        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra};
+        int a_rounds = (quad && prune_a > 0) ? std::min(q_rounds, prune_a) : q_rounds;
+        if (const char* ev = getenv("SPKM_SCREEN_A")) a_rounds = std::max(1, std::min(q_rounds, atoi(ev)));
+        ctx->last_rounds_all = quad ? a_rounds : 0;
+        ctx->last_rounds = quad ? q_rounds : 0;
+        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra, &a_rounds};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -937,29 +945,41 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
     spkm_shard* sm = const_cast<spkm_shard*>(s);
-    // The screen pays K-fold exact work for every point it cannot certify.  Its count is copied back
-    // asynchronously and looked at one call later (no host sync on the hot path): if more than 5 % of the
-    // points needed the exact list, the next 8 calls use the all-exact kernels, then the screen is retried.
+    // The screen pays K-fold exact work for every point it cannot certify.  Its counters are copied back
+    // asynchronously and looked at one call later (no host sync on the hot path):
+    //  * more than 5 % of the points on the exact list: the next 8 calls use the all-exact kernels;
+    //  * two-phase screen (partial sums for all centroids, only each tile's leader finished -- screen.hip):
+    //    switched on when a plain screen found < 0.2 % of the points with a runner-up within 2x of the winner
+    //    (converged iterations on separated data), switched off for 16 calls when it listed > 0.5 %.
     if (sm->nlist_pending && hipEventQuery(sm->ev_nlist) == hipSuccess) {
         sm->nlist_pending = false;
-        ctx->last_listed = *sm->h_nlist;
-        if ((double)ctx->last_listed > 0.05 * (double)s->n) sm->exact_cooldown = 8;
+        ctx->last_listed = sm->h_nlist[0];
+        const double listed = (double)sm->h_nlist[0], ambig = (double)sm->h_nlist[1], nn = (double)s->n;
+        if (listed > 0.05 * nn) sm->exact_cooldown = 8;
+        const int nr = (s->fixed_s + 3) / 4;
+        const int a_prune = std::max(2, (nr + 2) / 3); // K = 100, s = 51: 5 of 13 rounds
+        if (sm->prune_pending_a == 0)
+            sm->prune_next_a = (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) ? a_prune : 0;
+        else if (listed > 0.005 * nn) { sm->prune_next_a = 0; sm->prune_cooldown = 16; }
     }
+    if (sm->prune_cooldown > 0) sm->prune_cooldown--;
     const bool cooling = sm->exact_cooldown > 0;
     if (cooling) sm->exact_cooldown--;
     if (s->n > 0 && !cooling && screen_eligible(ctx, s, (int)K64)) {
         ctx->ev_valid = false;
-        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce)
-                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce);
+        const int prune_a = getenv("SPKM_NO_PRUNE") ? 0 : sm->prune_next_a;
+        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a)
+                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a);
         if (rc) return rc;
         if (!sm->h_nlist) {
             HIP_TRY(hipHostMalloc((void**)&sm->h_nlist, 64, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
         }
         if (!sm->nlist_pending) {
-            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
             sm->nlist_pending = true;
+            sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
         }
         if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -969,6 +989,14 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     rc = spkm_assign_dev(ctx, s, K64, d_centers, gamma, d_assign, d_mind, d_stats, d_nk_u64);
     if (rc) return rc;
     return spkm_accumulate_dev(ctx, s, K64, d_assign, d_reduce);
+}
+
+extern "C" int spkm_last_screen_rounds(spkm_ctx* ctx, int64_t info[2])
+{
+    if (!ctx || !info) return SPKM_ERR_NULL_ARG;
+    info[0] = ctx->last_path == 1 ? ctx->last_rounds_all : 0;
+    info[1] = ctx->last_path == 1 ? ctx->last_rounds : 0;
+    return SPKM_OK;
 }
 
 // [0] = path of the last spkm_assign_accumulate_dev (0 exact tiles, 1 f32 screen + exact confirmation),

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     const double eu = (2.0 * u + u * u) * (1.0 + 1e-9);
     const double gacc = (double)(fixed_s + 1) * u * (1.0 + 1e-4);
     const double nu = 0x1p-45;
+    unsigned nambig = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         float b1 = __builtin_inff(), b2 = __builtin_inff();
@@ -393,8 +394,12 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         for (int g = 0; g < G; g++) {
             const float m1 = scr_m1[(size_t)g * n + i], m2 = scr_m2[(size_t)g * n + i];
             const int k = scr_k[(size_t)g * n + i];
-            if (m1 < b1) { b2 = fminf(b1, m2); b1 = m1; bk = k; }
+            // m1 = estimate of the tile's leader, m2 = a LOWER bound of every other centroid of the tile (the
+            // second smallest estimate, or with the two-phase screen the second smallest partial sum -- which
+            // can lie below m1): every m2 and every m1 but the best one bound the competition from below
+            if (m1 < b1) { b2 = fminf(b2, b1); b1 = m1; bk = k; }
             else { b2 = fminf(b2, m1); }
+            b2 = fminf(b2, m2);
         }
         const double W = (xn2[i] + 2.0 * cmax * xn1[i] + (double)fixed_s * cmax * cmax) * (1.0 + 1e-9);
         const double E = eu * sqrt(W) * (1.0 + 1e-9);
@@ -406,7 +411,12 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
             const unsigned at = atomicAdd(nlist, 1u);
             list[at] = (int)i;
         }
+        // nlist[1]: points whose runner-up is within 2x of the winner -- the ones a partial-sum lower bound
+        // could not separate; the host decides from this count whether the next call may use the two-phase screen
+        if (!(r2 >= 2.0 * r1)) nambig++;
     }
+    for (int off = 32; off > 0; off >>= 1) nambig += __shfl_down(nambig, off);
+    if ((threadIdx.x & 63) == 0 && nambig) atomicAdd(nlist + 1, nambig);
 }
 
 // Listed points: exact reference arithmetic over all K centroids (row-major scaled centres Cs in
@@ -650,6 +660,18 @@ __device__ __forceinline__ float raw_max_f32(float a, float b)
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ int quad_min_i32(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false)); // quad_perm:[1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false)); // quad_perm:[2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float quad_sum_f32(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    return v;
+}
 template <int SEL> __device__ __forceinline__ int quad_bcast_i32(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, SEL * 0x55, 0xf, 0xf, false); // quad_perm:[SEL,SEL,SEL,SEL]
@@ -669,7 +691,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
-                                                 int extra_k0)
+                                                 int extra_k0, int a_rounds)
 {
     constexpr int RS = SCREEN_KT * 4; // 128-B rows
     constexpr int PPS = 16;
@@ -725,7 +747,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             float acc4 = 0.f;                                       // PL = 5: the lane's extra centroid
             // the last round broadcasts only the nvl = fixed_s - 4 (NR - 1) entries the column still has
 #define SPKM_QUAD_ROUND(r)                                                                                  \
-    if constexpr (NR > r) {                                                                                 \
+    if constexpr (NR > r) if (r < a_rounds) {                                                               \
         const int xi = __builtin_bit_cast(int, x##r);                                                       \
         const int ro = (int)__umul24((unsigned)o##r, (unsigned)RS);                                         \
         if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);   \
@@ -784,9 +806,35 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             const unsigned seg = (unsigned)(__ballot(win) >> (ps * 4)) & 0xfu;
             const int first = seg ? __builtin_ctz(seg) : 0;
             const float m2 = quad_min_f32((l4 == first) ? hi : lo);
+            // Phase B (a_rounds < NR): the sums above cover only the first 4 a_rounds entries of each column.  They are
+            // LOWER bounds of the full sums (every term is >= 0 and f32 addition is monotone), which is all the
+            // certificate needs for the centroids that lose; only the tile's leader by partial sum is finished:
+            // each lane adds ITS OWN remaining entries (no broadcast) for that one centroid, the quad adds up.
+            //   m1 = full estimate of the leader, m2 = smallest partial sum among the others (<= their full sums)
+            float full = m1;
+            if (a_rounds < NR) {
+                const int kwin = quad_min_i32((l4 == first && seg != 0u) ? klo : 0x7fffffff);
+                const bool is_extra = PL == 5 && kwin >= extra_k0;
+                const int cbase = is_extra ? extra_base + (kwin - extra_k0) * 4 : (kwin - k0) * 4;
+                const int rshift = is_extra ? 4 : 7; // 16-B rows of the extra table, 128-B rows of the tile
+                float accb = 0.f;
+#define SPKM_QUAD_FINISH(r)                                                                                 \
+    if constexpr (NR > r) if (r >= a_rounds) {                                                              \
+        const bool okr = (r < NR - 1) || l4 < nvl;                                                          \
+        const float cv = *reinterpret_cast<const float*>(smem + (o##r << rshift) + cbase);                  \
+        const float tv = okr ? cv + x##r : 0.f;                                                             \
+        accb = __builtin_fmaf(tv, tv, accb);                                                                \
+    }
+                SPKM_QUAD_FINISH(0) SPKM_QUAD_FINISH(1) SPKM_QUAD_FINISH(2) SPKM_QUAD_FINISH(3) SPKM_QUAD_FINISH(4)
+                SPKM_QUAD_FINISH(5) SPKM_QUAD_FINISH(6) SPKM_QUAD_FINISH(7) SPKM_QUAD_FINISH(8) SPKM_QUAD_FINISH(9)
+                SPKM_QUAD_FINISH(10) SPKM_QUAD_FINISH(11) SPKM_QUAD_FINISH(12) SPKM_QUAD_FINISH(13)
+                SPKM_QUAD_FINISH(14) SPKM_QUAD_FINISH(15)
+#undef SPKM_QUAD_FINISH
+                full = m1 + quad_sum_f32(kwin == 0x7fffffff ? 0.f : accb);
+            }
             if (l4 == first && i < n) {
                 const bool none = seg == 0u;
-                m1o[i] = none ? __builtin_inff() : m1;
+                m1o[i] = none ? __builtin_inff() : full;
                 m2o[i] = none ? __builtin_inff() : m2;
                 ko[i] = none ? -1 : klo;
             }
@@ -798,7 +846,7 @@ template <int NR, typename IR>
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
-    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile)
+    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int a_rounds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -824,10 +872,10 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
-    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
-    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
-    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
-    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek);
+    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
+    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
+    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
+    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)

@@ -150,6 +150,13 @@ class LloydEngine:
         _lib.check(_lib.lib().spkm_last_path_info(self.ctx.handle, a))
         return int(a[0]), int(a[1])
 
+    def last_screen_rounds(self) -> tuple[int, int]:
+        """(rounds evaluated for all centroids, rounds per column) of the last screen call; the first is smaller
+        when the two-phase screen was used (spkm_last_screen_rounds)."""
+        a = (C.c_int64 * 2)()
+        _lib.check(_lib.lib().spkm_last_screen_rounds(self.ctx.handle, a))
+        return int(a[0]), int(a[1])
+
     def iterate(self, centers: torch.Tensor):
         """One full Lloyd iteration in place on ``centers``; returns the device tensor
         [dff^2, obj^2] (no host sync)."""

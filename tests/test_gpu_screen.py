@@ -229,3 +229,40 @@ def test_poorly_certifying_screen_backs_off_to_exact_kernels(gpu_ctx, oracle):
         paths.append(eng.last_path_info()[0])
         _check(eng, oracle, X, Cm, 9 / 128)
     assert paths[0] == 1 and 0 in paths[1:]
+
+
+def test_two_phase_screen_switches_itself_on_and_off(gpu_ctx, oracle):
+    """Separated clusters with one centre each: after a plain screen has seen that no point has a runner-up within
+    2x of the winner, the next call evaluates only a third of the rounds for all centroids and finishes the tile
+    leaders (spkm_last_screen_rounds) -- with the oracle's outputs.  Ambiguous data (random centres) keeps or
+    brings back the plain screen."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    data = synth.sparsified_gmm_host(p=256, n=6000, K=40, gamma=0.2, seed=5, fwht=oracle.fwht)
+    Y, p2, gam = data["Y"], data["p2"], data["gamma"]
+    true_c = np.zeros((p2, 40))
+    for k in range(40):                                 # the ML-corrected centre of each planted cluster
+        Yk = Y[:, data["labels"] == k]
+        S = np.asarray(Yk.sum(axis=1)).ravel()
+        Cnt = np.asarray((Yk != 0).sum(axis=1)).ravel()
+        true_c[:, k] = gam * S / (Cnt + 1e-16)          # kmeans_sparsified.m:448
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, Y), 40, gam)
+    good = torch.tensor(np.ascontiguousarray(true_c.T), device="cuda")
+    seen = []
+    for it in range(4):
+        eng.assign_accumulate_step(good)
+        torch.cuda.synchronize()
+        seen.append(eng.last_screen_rounds())
+        ra, rd = oracle.assign(p2, 6000, *parts(Y), true_c, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)
+    nr = seen[0][1]
+    assert seen[0] == (nr, nr)                      # first call: plain screen
+    assert any(a < r for a, r in seen[1:])          # then the two-phase screen
+    bad = torch.tensor(np.random.default_rng(0).standard_normal((40, p2)) * 0.01, device="cuda")   # every centre ~ equally far
+    for it in range(4):
+        eng.assign_accumulate_step(bad)
+        torch.cuda.synchronize()
+        last = eng.last_screen_rounds()
+        ra, rd = oracle.assign(p2, 6000, *parts(Y), bad.cpu().numpy().T, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)
+    assert last[0] == last[1] or eng.last_path_info()[0] == 0    # back on the plain screen (or the exact kernels)
