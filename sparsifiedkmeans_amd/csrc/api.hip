@@ -826,6 +826,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (quad && G >= 2 && k_last <= 4 && !getenv("SPKM_NO_FUSE") &&
         (size_t)(p + 1) * (SCREEN_KT * 4 + 16) + 16 <= ctx->lds_max)
         pl_last = 5;
+    if (quad && getenv("SPKM_QUAD_EQUAL")) pl_last = 4; // A/B aid: every tile full width, equal workgroup counts (lock-step)
     const int Gs = pl_last == 5 ? G - 1 : G;
     const int q_rounds = (s->fixed_s + 3) / 4;
     if (quad) rc = build_blockmap_quad(ctx, Gs, pl_last, q_rounds);
