@@ -239,10 +239,26 @@ def cpu_baseline(data, centers0, p2, K, gamma, s, n_cpu, n_total):
     t0 = time.perf_counter()
     O.lloyd(p2, n_cpu, jc, ir, x, C0, gamma, maxiter=1, tol=0.0)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / (dt * n_total / n_cpu), "unit": "Lloyd iters/sec", "cores": 1, "kind": "port",
-            "sample": f"1 Lloyd iteration of oracle/orc_sparse.c orc_lloyd (gcc -O, single thread) on the first "
-                      f"{n_cpu} points of the same dataset in {dt:.2f} s, scaled linearly to N={n_total}",
-            "host_cpus": os.cpu_count()}
+    out = {"value": 1.0 / (dt * n_total / n_cpu), "unit": "Lloyd iters/sec", "cores": 1, "kind": "port",
+           "sample": f"1 Lloyd iteration of oracle/orc_sparse.c orc_lloyd (gcc -O, single thread) on the first "
+                     f"{n_cpu} points of the same dataset in {dt:.2f} s, scaled linearly to N={n_total}",
+           "host_cpus": os.cpu_count()}
+    # the preconditioner's CPU path: the reference's one multi-threaded mex (private/hadamard_pthreads.c, static
+    # column partition over NTHREADS = maxNumCompThreads(), setup_kmeans.m:45), restated in oracle/orc_fwht.c
+    try:
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        cols = 32768
+        xin = np.random.default_rng(0).standard_normal(cols * p2)
+        yout = np.zeros_like(xin)
+        O.lib().orc_fwht_threads(p2, cols, xin, yout, threads)          # warm-up (thread creation, page faults)
+        t0 = time.perf_counter()
+        O.lib().orc_fwht_threads(p2, cols, xin, yout, threads)
+        dt = time.perf_counter() - t0
+        out["fwht"] = {"columns_per_s": cols / dt, "threads": threads, "m": p2,
+                       "sample": f"{cols} columns of length {p2}, oracle/orc_fwht.c orc_fwht_threads"}
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        out["fwht"] = {"error": str(e)}
+    return out
 
 
 if __name__ == "__main__":
