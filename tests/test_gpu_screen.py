@@ -8,6 +8,10 @@ from util import parts, random_csc
 
 pytestmark = pytest.mark.gpu
 
+# SPKM_SWEEP=n multiplies the number of seeds of the random-shape sweeps (bug hunting; default 1)
+import os as _os
+_SW = max(1, int(_os.environ.get("SPKM_SWEEP", "1")))
+
 
 def _run(ctx, X, Cm, gamma):
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
@@ -81,7 +85,7 @@ def test_sixteen_lane_screen_kernel_equals_oracle(gpu_ctx, oracle, p, n, K, s, m
     _check(eng, oracle, X, Cm, s / p)
 
 
-@pytest.mark.parametrize("seed", range(72))
+@pytest.mark.parametrize("seed", range(72 * _SW))
 def test_random_shapes_equal_oracle(gpu_ctx, oracle, seed, monkeypatch):
     """Seeded sweep over (p, n, K, s): whatever path the library picks, the outputs are the oracle's."""
     rng = np.random.default_rng(1000 + seed)

@@ -10,8 +10,12 @@ from util import parts, random_csc, sample_rows_reference
 
 pytestmark = pytest.mark.gpu
 
+# SPKM_SWEEP=n multiplies the number of seeds of the random-shape sweeps (bug hunting; default 1)
+import os as _os
+_SW = max(1, int(_os.environ.get("SPKM_SWEEP", "1")))
 
-@pytest.mark.parametrize("seed", range(24))
+
+@pytest.mark.parametrize("seed", range(24 * _SW))
 def test_assign_step_random_shapes(gpu_ctx, oracle, seed):
     """spkm_assign_dev (exact kernels): ragged or fixed columns, any K, gamma present or empty."""
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
@@ -40,7 +44,7 @@ def test_assign_step_random_shapes(gpu_ctx, oracle, seed):
     assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-12 * max(np.abs(S).max(), 1e-300)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SW))
 def test_sparse_centres_random_shapes(gpu_ctx, oracle, seed):
     """spkm_assign_sparse_centers_dev (findClusterAssignments.m:63-75) against the oracle."""
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
@@ -64,7 +68,7 @@ def test_sparse_centres_random_shapes(gpu_ctx, oracle, seed):
     assert np.array_equal(eng.mind.cpu().numpy(), d)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SW))
 def test_mex_operators_random_shapes(gpu_ctx, oracle, seed):
     """The stand-alone operators through their host entry points, ragged inputs."""
     from sparsifiedkmeans_amd import ops
@@ -86,7 +90,7 @@ def test_mex_operators_random_shapes(gpu_ctx, oracle, seed):
                           oracle.dist_csc_beta(n, *parts(X), Cm[:, 0], beta), equal_nan=True)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SW))
 def test_sparsifier_random_shapes(gpu_ctx, oracle, seed):
     """spkm_mix_sample_dev: any p (zero-padded to p2), any s <= p2, any column offset."""
     from sparsifiedkmeans_amd.engine import mix_sample_device
@@ -111,7 +115,7 @@ def test_sparsifier_random_shapes(gpu_ctx, oracle, seed):
     assert np.array_equal(xv[: n * s].cpu().numpy().reshape(n, s), want)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * _SW))
 def test_fwht_random_shapes(gpu_ctx, oracle, seed):
     from sparsifiedkmeans_amd import ops
     rng = np.random.default_rng(6000 + seed)
@@ -121,7 +125,7 @@ def test_fwht_random_shapes(gpu_ctx, oracle, seed):
     assert np.array_equal(ops.hadamard(x, ctx=gpu_ctx), oracle.fwht(x))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * _SW))
 def test_dense_assign_random_shapes(gpu_ctx, seed):
     """spkm_dense_assign_dev / spkm_dense_accumulate_dev on drawn shapes (tails of the 64 x 128 x 64 MFMA tiling)."""
     import os
@@ -153,7 +157,7 @@ def test_dense_assign_random_shapes(gpu_ctx, seed):
     assert np.allclose(sums.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * _SW))
 def test_driver_random_options(gpu_ctx, seed):
     """kmeans_sparsified with drawn options: the outputs are mutually consistent whatever the combination."""
     import warnings
@@ -196,7 +200,7 @@ def test_driver_random_options(gpu_ctx, seed):
             assert np.allclose(direct[IDX2 - 1, np.arange(n)], direct.min(axis=0), rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * _SW))
 def test_screen_equals_exact_kernels_midsize(gpu_ctx, seed, monkeypatch):
     """1e5 .. 6e5 points (many chunks per workgroup, ragged last chunk, every tile / round variant by chance):
     the screen path against the all-exact kernels, every point, bit for bit.  No CPU oracle at this size."""
