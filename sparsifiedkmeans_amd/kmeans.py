@@ -5,7 +5,8 @@ the MI355X through libspkm.so.
 Scope: the sparsified path -- 'Sparsify',true with the Hadamard sketch or no
 sketch -- including the two-pass outputs (nargout 6..9).  What the reference does with MATLAB toolboxes
 outside that path (dense k-means via pdist2, DCT sketch, matfile) raises NotImplementedError naming the
-option, rather than silently doing something else.
+option, rather than silently doing something else.  'MLcorrection',false (plain means of the sparse columns,
+kmeans_sparsified.m:449-451) runs on the same accumulation with a different final division.
 
 MATLAB's RNG cannot be reproduced here; every random product (sign vector, sampled rows, initial
 centres) comes from ``rng`` (a numpy Generator or seed), so runs are reproducible per seed but
@@ -145,9 +146,6 @@ def kmeans_sparsified(X, K, **options):
         raise NotImplementedError("'Sparsify',false is the dense k-means path (pdist2 / expanded quadratic, "
                                   "findClusterAssignments.m:124-166): outside the sparsified hot path")
     MLcorrection = bool(o["MLcorrection"]) and bool(o["Sparsify"])   # :171
-    if not MLcorrection:
-        raise NotImplementedError("'MLcorrection',false densifies every cluster (kmeans_sparsified.m:449-451): "
-                                  "outside the sparsified hot path")
     rng = o["rng"] if isinstance(o["rng"], np.random.Generator) else np.random.default_rng(o["rng"])
     ctx = torch_context(o["device"])
     dev = f"cuda:{ctx.device}"
@@ -329,7 +327,14 @@ def kmeans_sparsified(X, K, **options):
             old = centers.clone()
             eng.accumulate_step()
             eng.allreduce_step()
-            eng.finalize_step(centers)                                           # :447-448
+            if MLcorrection:
+                eng.finalize_step(centers)                                       # gamma*S./(Cnt+1e-16)  (:447-448)
+            else:
+                # centers(:,ki) = mean(full(X(:,ind)),2) (:449-451): plain mean of the sparse columns, zeros included
+                pk_ = p2 * Kc
+                nk_ = eng.reduce[2 * pk_: 2 * pk_ + Kc]
+                nz_ = nk_ > 0
+                centers[nz_] = eng.reduce[:pk_].view(Kc, p2)[nz_] / nk_[nz_, None]
             nk = eng.global_nk().cpu().numpy()
             empty = np.flatnonzero(nk == 0)
             dropped = False

@@ -168,3 +168,21 @@ def test_kmeanspp_running_minimum_equals_full_recompute(gpu_ctx, oracle):
         Cd = X[:, picks[: t + 1]].toarray()
         _, full = oracle.assign(p, n, *parts(X), Cd, 13 / 256)      # what the reference recomputes
         assert np.array_equal(run.cpu().numpy(), full)
+
+
+def test_mlcorrection_false_takes_plain_means(gpu_ctx):
+    """'MLcorrection',false: centers(:,k) = mean(full(X(:,ind)),2) (kmeans_sparsified.m:449-451).  With
+    SparsityLevel = 1 nothing is dropped, so the centres are the plain cluster means of X*(1+2eps) after unmix."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+    p, n, K = 64, 1500, 4
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=8)
+    start = (centres + 0.05 * np.random.default_rng(2).standard_normal(centres.shape)).T
+    IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, Sparsify=True, SparsityLevel=1.0, SketchType="Hadamard",
+                                             MLcorrection=False, Start=start, rng=3, MaxIter=20)
+    assert np.array_equal(np.bincount(IDX - 1, minlength=K), np.bincount(labels, minlength=K))   # planted clusters recovered
+    want = np.stack([X[:, IDX == k + 1].mean(axis=1) for k in range(K)], axis=0) * (1.0 + 2.0 * np.finfo(float).eps)
+    assert np.allclose(C, want, rtol=1e-10, atol=1e-12)
+    # and it differs from the ML-corrected estimate only through the count normalisation: identical at SparsityLevel 1
+    C_ml = kmeans_sparsified(X.T, K, Sparsify=True, SparsityLevel=1.0, SketchType="Hadamard", Start=start, rng=3, MaxIter=20)[1]
+    assert np.allclose(C, C_ml, rtol=1e-9, atol=1e-10)
