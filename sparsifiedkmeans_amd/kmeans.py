@@ -4,8 +4,9 @@ the MI355X through libspkm.so.
 
 Scope: the sparsified path -- 'Sparsify',true with the Hadamard sketch or no
 sketch -- including the two-pass outputs (nargout 6..9).  What the reference does with MATLAB toolboxes
-outside that path (dense k-means via pdist2, DCT sketch, matfile) raises NotImplementedError naming the
-option, rather than silently doing something else.  'MLcorrection',false (plain means of the sparse columns,
+outside that path (DCT sketch, matfile) raises NotImplementedError naming the option, rather than silently
+doing something else.  'Sparsify',false -- the reference's default -- runs plain Lloyd on the dense data with the
+dense kernels of the two-pass outputs (one GPU, data resident in HBM).  'MLcorrection',false (plain means of the sparse columns,
 kmeans_sparsified.m:449-451) runs on the same accumulation with a different final division.
 
 MATLAB's RNG cannot be reproduced here; every random product (sign vector, sampled rows, initial
@@ -143,8 +144,7 @@ def kmeans_sparsified(X, K, **options):
         o["DataFile"], X = X, None                                                # kmeans_sparsified.m:179-183
     LoadFromDisk = o["DataFile"] is not None
     if not o["Sparsify"]:
-        raise NotImplementedError("'Sparsify',false is the dense k-means path (pdist2 / expanded quadratic, "
-                                  "findClusterAssignments.m:124-166): outside the sparsified hot path")
+        return _kmeans_dense(X, K, o, nargout, t0)
     MLcorrection = bool(o["MLcorrection"]) and bool(o["Sparsify"])   # :171
     rng = o["rng"] if isinstance(o["rng"], np.random.Generator) else np.random.default_rng(o["rng"])
     ctx = torch_context(o["device"])
@@ -469,6 +469,136 @@ def kmeans_sparsified(X, K, **options):
         Cout = Cout.T                                                            # K x p like MATLAB's kmeans (:586-590)
     OUTPUT["TimeOverall"] = time.time() - t0
     return ((IDX, Cout, SUMD, D, OUTPUT) + extra)[:max(nargout, 5)]
+
+
+def _kmeans_dense(X, K, o, nargout, t0):
+    """'Sparsify',false -- the reference's DEFAULT: plain Lloyd on the dense data, no sketch, no sampling
+    (kmeans_sparsified.m:362-364,378-486 with findClusterAssignments.m:124-171 and the plain mean of :449-451).
+    Assignment = spkm_dense_assign_dev (expanded quadratic on the f64 matrix cores), centres = per-cluster means
+    from spkm_dense_accumulate_dev.  The data must fit in HBM as one n x p float64 tensor; 'DataFile' is not
+    offered on this branch (neither does the reference's code path load it)."""
+    if o["DataFile"] is not None:
+        raise NotImplementedError("'DataFile' needs 'Sparsify',true (kmeans_sparsified.m:298-307 only loads it there)")
+    if D_.is_distributed():
+        raise NotImplementedError("'Sparsify',false runs on one GPU")
+    rng = o["rng"] if isinstance(o["rng"], np.random.Generator) else np.random.default_rng(o["rng"])
+    ctx = torch_context(o["device"])
+    dev = f"cuda:{ctx.device}"
+    X = np.asarray(X, np.float64)
+    if np.iscomplexobj(X):
+        raise ValueError("Code and distance computations require real data")
+    if o["ColumnSamples"]:
+        X = X.T                                                                   # here: points as rows [n, p]
+    n, p = X.shape
+    if n < K:
+        raise ValueError("X must have more samples than the number of clusters.")  # :219-221
+    free, _ = torch.cuda.mem_get_info()
+    if n * p * 8 > 0.8 * free:
+        raise NotImplementedError("'Sparsify',false keeps the dense data on the GPU; it does not fit")
+    Xd = torch.tensor(np.ascontiguousarray(X), device=dev)
+    Display = o["Display"] if isinstance(o["Display"], str) else "off"
+    Replicates = int(o["Replicates"])
+    OUTPUT = dict(LoadFromDisk=False, Options=dict(o), Sparsify=False, iterations=np.zeros(Replicates, int),
+                  stoppingDiff=np.zeros(Replicates), objectives=np.zeros(Replicates), replicateTimes=np.zeros(Replicates),
+                  replicateTimesJustInitialization=np.zeros(Replicates))
+    start = o["Start"]
+    best = dict(obj=np.inf)
+    distances = None
+    for trial in range(Replicates):
+        t1 = time.time()
+        if isinstance(start, str):
+            sl = start.lower()
+            if sl == "sample":
+                centers = Xd[torch.tensor(rng.choice(n, K, replace=False), device=dev)].clone()       # :387
+            elif sl == "uniform":
+                mn, mx = float(Xd.min().item()), float(Xd.max().item())
+                centers = torch.tensor((mx - mn) * rng.random((K, p)) - mn, device=dev)   # :390 (subtracts mn)
+            elif sl in ("arthur", "++", "kmeans++", "k-means++", "k-means-++"):
+                chosen = [int(rng.integers(n))]                                   # Arthur_initialization.m:35
+                dist = None
+                for k in range(1, K):
+                    _, dnew = dense_assign_device(ctx, Xd, Xd[chosen[-1]][None, :].contiguous())
+                    dist = dnew if dist is None else torch.minimum(dist, dnew)    # same dist vector as :39
+                    cum = torch.cumsum(dist * dist, 0)
+                    tot = float(cum[-1].item())
+
+                    def draw():
+                        if tot <= 0.0:
+                            return int(rng.integers(n))
+                        t = torch.tensor([rng.random() * tot], dtype=torch.float64, device=dev)
+                        return int(min(torch.searchsorted(cum, t, right=True).item(), n - 1))
+                    i, counter = draw(), 1
+                    while i in chosen and counter < 400:                          # :54-61
+                        i, counter = draw(), counter + 1
+                    if i in chosen:
+                        raise RuntimeError("Cannot sample with replacement with this distribution")
+                    chosen.append(i)
+                centers = Xd[torch.tensor(chosen, device=dev)].clone()
+            else:
+                raise ValueError('cannot handle other types of "Start" values')  # :398
+        else:
+            S = np.asarray(start, np.float64)
+            if o["ColumnSamples"]:
+                S = S.T
+            if S.shape != (K, p):
+                raise ValueError("Start matrix must be K x p (or p x K with ColumnSamples)")
+            centers = torch.tensor(np.ascontiguousarray(S), device=dev)
+            if Replicates > 1:
+                warnings.warn("initialization is specified, so running more than 1 replicate is not helpful")
+        OUTPUT["replicateTimesJustInitialization"][trial] = time.time() - t1
+        Kc = K
+        its, dff, obj, assign, dmin, dropped = 0, np.nan, np.nan, None, None, False
+        for its in range(1, int(o["MaxIter"]) + 1):
+            assign, dmin = dense_assign_device(ctx, Xd, centers.contiguous())     # findClusterAssignments.m:124-171
+            old = centers.clone()
+            sums = torch.zeros((Kc, p), dtype=torch.float64, device=dev)
+            cnt = torch.zeros(Kc, dtype=torch.float64, device=dev)
+            dense_accumulate_device(ctx, Xd, assign, sums, cnt)
+            nz = cnt > 0
+            centers[nz] = sums[nz] / cnt[nz, None]                                # mean(full(X(:,ind)),2) (:449-451)
+            empty = torch.nonzero(~nz).flatten().cpu().numpy()
+            dropped = False
+            if empty.size:
+                warnings.warn("cluster has lost all its members")                # :433
+                act = str(o["EmptyAction"]).lower()
+                if act == "error":
+                    raise RuntimeError("One cluster lost all its members")      # :439
+                if act == "singleton":
+                    centers[torch.tensor(empty, device=dev)] = Xd[int(torch.argmax(dmin).item())]   # :436-437
+                else:                                                            # 'drop' (:441,454-459)
+                    keep = torch.nonzero(nz).flatten()
+                    centers, old, Kc, dropped = centers[keep].contiguous(), old[keep].contiguous(), int(keep.numel()), True
+            dff = float(torch.linalg.norm(old - centers).item())                 # :470
+            obj = float(torch.sqrt((dmin * dmin).sum()).item())                  # :471
+            if Display == "iter" and its % int(o["PrintEvery"]) == 0:
+                print(f"Iter: {its:3d}; change in cluster centers: {dff:.2e}; objective: {obj:.2e}")
+            if dff < o["Tol"]:
+                break
+            if bool(torch.isnan(centers).any().item()):
+                raise RuntimeError("Found NaN in centers")
+        OUTPUT["replicateTimes"][trial] = time.time() - t1
+        OUTPUT["stoppingDiff"][trial], OUTPUT["objectives"][trial], OUTPUT["iterations"][trial] = dff, obj, its
+        distances = dmin.cpu().numpy()
+        if obj < best["obj"]:
+            best = dict(obj=obj, K=Kc, centers=centers.clone(), dist=distances.copy(),
+                        assign=None if dropped else assign.cpu().numpy().astype(np.int64) + 1)
+        if Display == "iter" or (Display == "final" and best["obj"] == obj):
+            print(f"Trial {trial + 1:3d} of {Replicates:3d} total, objective {obj:.2e}")
+    OUTPUT["TimeInitialization"] = float(OUTPUT["replicateTimesJustInitialization"].sum())
+    OUTPUT["TimeAlgo_wo_initialization"] = float(OUTPUT["replicateTimes"].sum()) - OUTPUT["TimeInitialization"]
+    Kb = best["K"]
+    IDX = best["assign"] if best["assign"] is not None else np.zeros(0, np.int64)
+    SUMD = np.array([np.sum(distances[IDX == ki + 1] ** 2) if IDX.size else 0.0 for ki in range(Kb)])   # :514-518
+    OUTPUT["TimeOverall_OnePass"] = time.time() - t0
+    Cout = best["centers"].cpu().numpy()                                          # K x p
+    extra = ()
+    if nargout > 5:
+        warnings.warn("There is no sparsification, so the twoPass variables are the same")   # :575-576
+        extra = (Cout.T if o["ColumnSamples"] else Cout, IDX, best["dist"], SUMD)             # :577-582
+    if o["ColumnSamples"]:
+        Cout = Cout.T
+    OUTPUT["TimeOverall"] = time.time() - t0
+    return ((IDX, Cout, SUMD, best["dist"], OUTPUT) + extra)[:max(nargout, 5)]
 
 
 def _arthur(ctx, shard, column, n, K, gamma, rng, first=0, n_glob=None, dist_on=False):

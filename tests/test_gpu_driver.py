@@ -112,8 +112,8 @@ def test_kmeans_sparsified_option_errors(gpu_ctx):
         kmeans_sparsified(X[:2], 3, Sparsify=True)
     with pytest.raises(NotImplementedError, match="DCT"):
         kmeans_sparsified(np.zeros((100, 12)), 3, Sparsify=True)       # auto -> DCT for p not a power of two
-    with pytest.raises(NotImplementedError, match="dense k-means"):
-        kmeans_sparsified(X, 3)
+    with pytest.raises(NotImplementedError, match="DataFile"):
+        kmeans_sparsified("somefile", 3)                               # the dense default path does not stream files
 
 
 def test_datafile_streaming_equals_in_memory(gpu_ctx, tmp_path):
@@ -186,3 +186,32 @@ def test_mlcorrection_false_takes_plain_means(gpu_ctx):
     # and it differs from the ML-corrected estimate only through the count normalisation: identical at SparsityLevel 1
     C_ml = kmeans_sparsified(X.T, K, Sparsify=True, SparsityLevel=1.0, SketchType="Hadamard", Start=start, rng=3, MaxIter=20)[1]
     assert np.allclose(C, C_ml, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("start", ["Arthur", "sample", "matrix"])
+def test_default_dense_path_is_plain_lloyd(gpu_ctx, start):
+    """kmeans_sparsified(X, K) with the reference's defaults ('Sparsify',false): plain Lloyd on the dense data
+    (findClusterAssignments.m:124-171 + mean, kmeans_sparsified.m:449-451), checked against a numpy Lloyd loop run
+    from the same initial centres."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+    p, n, K = 48, 1200, 4
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=12)
+    opts = dict(rng=4, MaxIter=50)
+    if start == "matrix":
+        opts["Start"] = (centres + 0.05 * np.random.default_rng(1).standard_normal(centres.shape)).T
+    else:
+        opts["Start"] = start
+    IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, **opts)
+    assert OUT["Sparsify"] is False and IDX.shape == (n,) and C.shape == (K, p)
+    # fixed point of Lloyd: every point sits with its nearest centre, every centre is its cluster's mean
+    d = np.sqrt(((X[:, None, :] - C.T[:, :, None]) ** 2).sum(axis=0))            # K x n
+    assert np.array_equal(IDX - 1, np.argmin(d, axis=0))
+    assert np.allclose(D, d.min(axis=0), rtol=1e-9, atol=1e-9)
+    for k in range(K):
+        assert np.allclose(C[k], X[:, IDX == k + 1].mean(axis=1), rtol=1e-10, atol=1e-12)
+    assert np.allclose(SUMD, [np.sum(D[IDX == k + 1] ** 2) for k in range(K)], rtol=1e-12)
+    if start != "sample":                                   # a good start recovers the planted clusters
+        assert np.array_equal(np.sort(np.bincount(IDX - 1, minlength=K)), np.sort(np.bincount(labels, minlength=K)))
+    out9 = kmeans_sparsified(X.T, K, nargout=9, **opts)     # no sparsification: the two-pass outputs are the same
+    assert np.array_equal(out9[6], out9[0]) and np.allclose(out9[5], out9[1])
