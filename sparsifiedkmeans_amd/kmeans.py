@@ -4,8 +4,9 @@ the MI355X through libspkm.so.
 
 Scope: the sparsified path -- 'Sparsify',true with the Hadamard sketch or no
 sketch -- including the two-pass outputs (nargout 6..9).  What the reference does with MATLAB toolboxes
-outside that path (DCT sketch, matfile) raises NotImplementedError naming the option, rather than silently
-doing something else.  'Sparsify',false -- the reference's default -- runs plain Lloyd on the dense data with the
+outside that path (matfile containers, function-handle sketches) raises NotImplementedError naming the option,
+rather than silently doing something else.  The DCT sketch ('auto' picks it when p is not a power of two) is a
+p x p orthonormal matrix applied with a library GEMM.  'Sparsify',false -- the reference's default -- runs plain Lloyd on the dense data with the
 dense kernels of the two-pass outputs (one GPU, data resident in HBM).  'MLcorrection',false (plain means of the sparse columns,
 kmeans_sparsified.m:449-451) runs on the same accumulation with a different final division.
 
@@ -76,16 +77,31 @@ class _Sketch:
         self.ctx, self.kind, self.p = ctx, kind, p
         self.p2 = _nextpow2(p) if kind == "hadamard" else p
         self.sign = None if sign is None else torch.tensor(sign, dtype=torch.float64, device=f"cuda:{ctx.device}")
+        if kind == "dct":
+            # orthonormal DCT-II as MATLAB's dct(): y(k) = w(k) sum_n x(n) cos(pi (2n-1)(k-1) / (2N)), w(1) = 1/sqrt(N),
+            # w(k>1) = sqrt(2/N); idct is its transpose (kmeans_sparsified.m:256-258).  A p x p matrix applied with a
+            # library GEMM: one pass over the data, and the reference's own dct is a toolbox FFT whose rounding is
+            # not specified either (tolerance parity).
+            k = torch.arange(p, dtype=torch.float64, device=f"cuda:{ctx.device}")[:, None]
+            nn_ = torch.arange(p, dtype=torch.float64, device=f"cuda:{ctx.device}")[None, :]
+            M = torch.cos(np.pi * (2.0 * nn_ + 1.0) * k / (2.0 * p)) * np.sqrt(2.0 / p)
+            M[0] = M[0] / np.sqrt(2.0)
+            self.M = M                                                            # [p, p]: y = M x
 
     def mix(self, x: torch.Tensor, premul: float = 1.0) -> torch.Tensor:
         if self.kind == "none":
             return x * premul if premul != 1.0 else x
+        if self.kind == "dct":
+            xs = x * self.sign if premul == 1.0 else (x * premul) * self.sign     # DD*X (:283-291), rows = points
+            return (xs @ self.M.T).contiguous()
         # H(DD*upsample(x)) with H(x) = hadamard(x)/sqrt(p2)   (:241-248,286-295)
         return mix_device(self.ctx, x.contiguous(), self.p2, self.sign, premul, float(np.sqrt(np.float64(self.p2))))
 
     def unmix(self, y: torch.Tensor) -> torch.Tensor:
         if self.kind == "none":
             return y
+        if self.kind == "dct":
+            return ((y @ self.M) * self.sign).contiguous()                        # DD*idct(Y) (:296)
         # downsample(DD*Ht(y)), Ht = H (:255,296)
         z = mix_device(self.ctx, y.contiguous(), self.p2, None, 1.0, float(np.sqrt(np.float64(self.p2))))
         return (z * self.sign)[:, : self.p].contiguous()
@@ -190,9 +206,12 @@ def kmeans_sparsified(X, K, **options):
         sk = "hadamard" if p == _nextpow2(p) else "dct"                          # :226-231
         OUTPUT["SketchType"] = "Hadamard" if sk == "hadamard" else "DCT"
     if sk == "dct":
-        raise NotImplementedError("the DCT sketch uses the Signal Processing Toolbox (kmeans_sparsified.m:256-258); "
-                                  "pass 'SketchType','Hadamard' (zero-pads to a power of two) or 'none'")
-    if sk in ("nothing", "none"):
+        d = np.sign(rng.random(p)) if o["FORCE_BUG"] else np.sign(rng.standard_normal(p))   # :283-287 (p2 = p here)
+        d[d == 0] = 1.0
+        if p > 16384:
+            raise NotImplementedError("the DCT sketch is applied as a p x p matrix; p is too large for that")
+        sketch = _Sketch(ctx, "dct", p, d)
+    elif sk in ("nothing", "none"):
         sketch = _Sketch(ctx, "none", p, None)
     elif sk == "hadamard":
         p2 = _nextpow2(p)

@@ -110,8 +110,8 @@ def test_kmeans_sparsified_option_errors(gpu_ctx):
         kmeans_sparsified(X, 3, Sparsify=True, Bogus=1)
     with pytest.raises(ValueError, match="more samples"):
         kmeans_sparsified(X[:2], 3, Sparsify=True)
-    with pytest.raises(NotImplementedError, match="DCT"):
-        kmeans_sparsified(np.zeros((100, 12)), 3, Sparsify=True)       # auto -> DCT for p not a power of two
+    with pytest.raises(NotImplementedError, match="function-handle"):
+        kmeans_sparsified(X, 3, Sparsify=True, SketchType=[abs, abs])  # {H, Ht} handles exist only inside MATLAB
     with pytest.raises(NotImplementedError, match="DataFile"):
         kmeans_sparsified("somefile", 3)                               # the dense default path does not stream files
 
@@ -215,3 +215,27 @@ def test_default_dense_path_is_plain_lloyd(gpu_ctx, start):
         assert np.array_equal(np.sort(np.bincount(IDX - 1, minlength=K)), np.sort(np.bincount(labels, minlength=K)))
     out9 = kmeans_sparsified(X.T, K, nargout=9, **opts)     # no sparsification: the two-pass outputs are the same
     assert np.array_equal(out9[6], out9[0]) and np.allclose(out9[5], out9[1])
+
+
+def test_dct_sketch_auto_for_non_power_of_two(gpu_ctx):
+    """'SketchType','auto' picks the DCT when p is not a power of two (kmeans_sparsified.m:226-231,256-258): the
+    mix is MATLAB's orthonormal dct() of DD*X, unmix its transpose."""
+    import scipy.fft
+    import torch
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import torch_context
+    from sparsifiedkmeans_amd.kmeans import _Sketch, kmeans_sparsified
+    p, n, K = 100, 2500, 4
+    rng = np.random.default_rng(0)
+    d = np.sign(rng.standard_normal(p))
+    sk = _Sketch(torch_context(), "dct", p, d)
+    x = rng.standard_normal((37, p))
+    xm = sk.mix(torch.tensor(x, device="cuda")).cpu().numpy()
+    assert np.allclose(xm, scipy.fft.dct(x * d, type=2, norm="ortho", axis=1), rtol=1e-12, atol=1e-13)
+    assert np.allclose(sk.unmix(torch.tensor(xm, device="cuda")).cpu().numpy(), x, rtol=1e-12, atol=1e-13)
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=21)
+    start = (centres + 0.05 * rng.standard_normal(centres.shape)).T
+    IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, Sparsify=True, SparsityLevel=0.3, Start=start, rng=5)
+    assert OUT["SketchType"] == "DCT"
+    assert np.array_equal(np.bincount(IDX - 1, minlength=K), np.bincount(labels, minlength=K))
+    assert np.abs(C - centres.T).max() < 0.1                # centres come back in the original coordinates
