@@ -246,16 +246,28 @@ def kmeans_sparsified(X, K, **options):
         OUTPUT["TimeToSketch"] = OUTPUT["TimeToSample"] = time.time() - t1       # fused: one number for both
         nnz = n * small_p
     else:
-        if LoadFromDisk:
-            raise NotImplementedError("'DataFile' needs the Hadamard sketch (fused device sparsifier)")
-        t1 = time.time()
-        Xdev = torch.tensor(np.ascontiguousarray(X.T), device=dev)               # [n, p]
-        Xmixed = sketch.mix(Xdev, premul=1.0 + 2.0 * EPS)                        # :292,295 (X*(1+2eps) then mix)
-        torch.cuda.synchronize()
-        OUTPUT["TimeToSketch"] = time.time() - t1
-        t1 = time.time()
-        Y = synth.sparsify_dense(Xmixed.cpu().numpy().T, small_p, np.random.default_rng(sample_seed))  # :334
-        OUTPUT["TimeToSample"] = time.time() - t1
+        # DCT / no sketch: mix on the device (a GEMM or nothing), sample on the host (randsample_fixedNumberEntries,
+        # :334), MB_limit columns at a time -- the same generator runs through all chunks, so a 'DataFile' run
+        # draws exactly the samples of the in-memory run (sampleAndMixFromLargeFile.m:100-129)
+        nn = max(1, min(n, int(o["MB_limit"] * 2**20 // (8 * p)))) if LoadFromDisk else n
+        srng = np.random.default_rng(sample_seed)
+        t_mix = t_smp = 0.0
+        parts_ = []
+        for c0 in range(0, n, nn):
+            if LoadFromDisk:
+                blk = Xmm[:, c0:c0 + nn].T if o["ColumnSamples"] else Xmm[c0:c0 + nn, :]
+            else:
+                blk = X[:, c0:c0 + nn].T
+            t1 = time.time()
+            Xmixed = sketch.mix(torch.tensor(np.ascontiguousarray(blk, dtype=np.float64), device=dev),
+                                premul=1.0 + 2.0 * EPS)                          # :292,295 (X*(1+2eps) then mix)
+            torch.cuda.synchronize()
+            t_mix += time.time() - t1
+            t1 = time.time()
+            parts_.append(synth.sparsify_dense(Xmixed.cpu().numpy().T, small_p, srng))
+            t_smp += time.time() - t1
+        OUTPUT["TimeToSketch"], OUTPUT["TimeToSample"] = t_mix, t_smp
+        Y = parts_[0] if len(parts_) == 1 else sp.hstack(parts_, format="csc")
         shard = Shard.from_scipy(ctx, Y)
         nnz = Y.nnz
     if Display in ("iter", "final"):

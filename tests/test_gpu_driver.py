@@ -239,3 +239,18 @@ def test_dct_sketch_auto_for_non_power_of_two(gpu_ctx):
     assert OUT["SketchType"] == "DCT"
     assert np.array_equal(np.bincount(IDX - 1, minlength=K), np.bincount(labels, minlength=K))
     assert np.abs(C - centres.T).max() < 0.1                # centres come back in the original coordinates
+
+
+@pytest.mark.parametrize("sketch", ["none", "DCT"])
+def test_datafile_with_host_sampler_equals_in_memory(gpu_ctx, tmp_path, sketch):
+    """'DataFile' with the sketches that use the host sampler: chunked reading draws the same samples."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+    X, centres, labels = synth.gmm_dense(100, 1800, 3, seed=14)
+    fn = str(tmp_path / "d.npy")
+    np.save(fn, X.T)
+    S = X[:, [0, 700, 1400]].T
+    a = kmeans_sparsified(X.T, 3, Sparsify=True, SparsityLevel=0.2, SketchType=sketch, Start=S, rng=9)
+    b = kmeans_sparsified(fn, 3, Sparsify=True, SparsityLevel=0.2, SketchType=sketch, Start=S, rng=9, MB_limit=0.2)
+    assert np.array_equal(a[0], b[0]) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-12)
+    assert np.allclose(a[3], b[3], rtol=1e-9, atol=1e-12)
