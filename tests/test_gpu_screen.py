@@ -104,6 +104,21 @@ def test_random_shapes_equal_oracle(gpu_ctx, oracle, seed, monkeypatch):
     _check(eng, oracle, X, Cm, s / p)
 
 
+@pytest.mark.parametrize("seed", range(24 * _SW))
+def test_random_wide_shapes_equal_oracle(gpu_ctx, oracle, seed):
+    """Shapes around the eligibility limits of the screen: rows beyond what an LDS tile holds, columns longer
+    than 64 entries, many hundreds of centroids.  Whatever path is taken, the outputs are the oracle's."""
+    rng = np.random.default_rng(11000 + seed)
+    p = int(rng.choice([1024, 1100, 1136, 1137, 1278, 1279, 1500, 2048, 3000]))
+    s = int(rng.integers(1, 101))
+    K = int(rng.choice([2, 17, 33, 100, 129, 300, 600, 1025]))
+    n = int(rng.integers(200, 1500))
+    X = random_csc(p, n, s, seed=seed + 3)
+    Cm = rng.standard_normal((p, K)) * 0.3
+    eng, path, listed = _run(gpu_ctx, X, Cm, s / p)
+    _check(eng, oracle, X, Cm, s / p)
+
+
 def test_more_tiles_than_workgroups_per_xcd_takes_the_exact_path(gpu_ctx, oracle):
     """K = 1100 needs 35 screen tiles; an XCD has 32 workgroups, so the call must fall back to the exact tiles
     (and still be right) instead of failing."""
