@@ -1,10 +1,14 @@
 // Certified f32 screen + exact f64 confirmation: the fast path of the fused Lloyd iteration
-// for K > 16 (gfx950).  RESULTS ARE IDENTICAL to the exact kernel of assign.hip -- assignments
+// for K >= 2 (gfx950).  RESULTS ARE IDENTICAL to the exact kernel of assign.hip -- assignments
 // bit-for-bit, min-distances bit-for-bit -- because nothing computed in f32 is ever output:
 //
-//   1. k_screen_tile     for every point and centroid, an f32 estimate of the squared distance
-//                        (2 centroids per lane, 32 per DPP row: twice the rate of the f64 chain);
-//                        per (point, tile): smallest estimate, its centroid, second smallest.
+//   1. k_screen_quad     (columns of up to 64 entries; k_screen_tile, the 16-lanes-per-point kernel, beyond)
+//                        for every point and centroid, an f32 estimate of the squared distance, 32 centroids
+//                        per LDS tile; per (point, tile): the leader's estimate m1, its centroid, and m2, a
+//                        LOWER BOUND of the estimate of every other centroid of the tile (the second smallest
+//                        estimate -- or, in the two-phase form, the second smallest partial sum: partial sums
+//                        of the non-negative terms bound the full sums from below because f32 addition is
+//                        monotone, and only the leader by partial sum is summed to the end).
 //   2. k_combine_screen  best / second-best over the tiles and a RIGOROUS bound on
 //                        |sqrt(estimate) - true distance| (below).  If best + bound < second - bound
 //                        the reference's argmin is certified (uniquely: no tie can occur inside the
@@ -23,8 +27,9 @@
 // The f32 FMA accumulation of s terms gives a~ in ||t~||^2 (1 +- g), g = (s+1)u(1+1e-4), hence
 // |sqrt(a~) - ||t~||| <= g sqrt(a~).  Together |sqrt(a~_k) - D_k| <= eps_k := E + g sqrt(a~_k) + 1e-20
 // (the last term covers f32 subnormal products).  dist_k itself is within D_k (1 +- 2^-45).
-// Certified iff (r1 + eps_1)(1+2^-45) < (r2 - eps_2)(1-2^-45) with r = sqrt(a~) of the best and second best:
-// every other centroid has r_k >= r2 and r_k - eps_k is increasing in r_k, so dist_1 < dist_k for all k.
+// Certified iff (r1 + eps_1)(1+2^-45) < (r2 - eps_2)(1-2^-45) with r1 = sqrt(a~) of the best leader and r2 = sqrt of
+// the smallest of: the other tiles' leaders, every tile's m2.  Every other centroid has sqrt(a~_k) >= r2 (its
+// full sum is at least any lower bound of it) and r - eps(r) is increasing in r, so dist_1 < dist_k for all k.
 // Overflow makes a~ = inf and fails the test (-> list).  Empty / duplicate columns fail it (-> list).
 #include "common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
