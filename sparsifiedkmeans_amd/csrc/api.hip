@@ -958,7 +958,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         const double listed = (double)sm->h_nlist[0], ambig = (double)sm->h_nlist[1], nn = (double)s->n;
         if (listed > 0.05 * nn) sm->exact_cooldown = 8;
         const int nr = (s->fixed_s + 3) / 4;
-        const int a_prune = std::max(2, (nr + 2) / 3); // K = 100, s = 51: 5 of 13 rounds
+        const int a_prune = std::max(2, (3 * nr + 9) / 10); // ~30 % of the rounds (s = 51: 4 of 13): a runner-up 2x away clears it
         if (sm->prune_pending_a == 0)
             sm->prune_next_a = (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) ? a_prune : 0;
         else if (listed > 0.005 * nn) { sm->prune_next_a = 0; sm->prune_cooldown = 16; }
