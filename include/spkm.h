@@ -105,6 +105,11 @@ int spkm_shard_create_host(spkm_ctx *ctx, uint64_t p, uint64_t n, const uint64_t
 int spkm_shard_create_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t nnz, const int64_t *d_jc,
                           const void *d_ir, int ir_bits, const double *d_x, uint64_t capacity,
                           spkm_shard **out);
+/* Forget what earlier calls learned about how well the screen certifies on this shard (the choice between the
+ * exact kernels, the plain screen and the two-phase screen adapts from call to call).  Hosts call it when the
+ * centres are about to jump -- a new replicate, a new start -- so that the first call does not run in a mode
+ * tuned for the previous, converged centres.  Outputs never depend on it. */
+int spkm_shard_reset_policy(spkm_shard *s);
 void spkm_shard_destroy(spkm_shard *s);
 int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
 

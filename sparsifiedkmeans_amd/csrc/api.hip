@@ -312,6 +312,16 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     delete s;
 }
 
+extern "C" int spkm_shard_reset_policy(spkm_shard* s)
+{
+    if (!s) return SPKM_ERR_NULL_ARG;
+    s->exact_cooldown = 0;
+    s->prune_next_a = 0;
+    s->prune_cooldown = 0;
+    s->prune_pending_a = 0;
+    return SPKM_OK;
+}
+
 extern "C" int spkm_shard_info(const spkm_shard* s, uint64_t* p, uint64_t* n, uint64_t* nnz, int* ir_bits)
 {
     if (!s) return SPKM_ERR_NULL_ARG;

@@ -60,6 +60,10 @@ class Shard:
                                                     C.byref(h)), "spkm_shard_create_dev")
         return cls(ctx, h, keep=(jc, ir, x))
 
+    def reset_policy(self):
+        """New start / new replicate: drop the adaptive state of the fused call (spkm_shard_reset_policy)."""
+        _lib.check(_lib.lib().spkm_shard_reset_policy(self.handle), "spkm_shard_reset_policy")
+
     def close(self):
         if self.handle:
             _lib.lib().spkm_shard_destroy(self.handle)

@@ -344,6 +344,7 @@ def kmeans_sparsified(X, K, **options):
             sparse_mask = None                                                   # centers = full(centers) (:412-414)
         OUTPUT["replicateTimesJustInitialization"][trial] = time.time() - t1
 
+        shard.reset_policy()                                                     # new start: nothing learned carries over
         eng = LloydEngine(shard, Kc, gamma, unbiased=unbiased)
         centers = torch.tensor(np.ascontiguousarray(centers_np.T), device=dev)   # [K, p2]
         mask_t = None if sparse_mask is None else torch.tensor(np.ascontiguousarray(sparse_mask.T), device=dev)
