@@ -243,3 +243,44 @@ def test_screen_equals_exact_kernels_midsize(gpu_ctx, seed, monkeypatch):
     assert torch.equal(e1.reduce[pk:2 * pk + K], e0.reduce[pk:2 * pk + K])
     scale = float(e0.reduce[:pk].abs().max().item())
     assert float((e1.reduce[:pk] - e0.reduce[:pk]).abs().max().item()) <= 1e-11 * max(scale, 1e-300)
+
+
+def test_adaptive_policy_soak(gpu_ctx, monkeypatch):
+    """60 consecutive fused calls on one shard while the centres wander between converged, slightly perturbed and
+    scrambled states: the library moves between the two-phase screen, the plain screen and the exact kernels on its
+    own; every call's assignments and min-distances equal those of the all-exact kernels on the same centres."""
+    import os
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_device
+    n, p, K = 300_000, 512, 60
+    d = synth.sparsified_gmm_device(gpu_ctx, p, n, n, 0, K, 0.1, seed=77)
+    shard = Shard.from_device(gpu_ctx, d["p2"], d["jc"], d["ir"], d["x"], nnz=d["nnz"])
+    planted = mix_device(gpu_ctx, d["means"].contiguous(), d["p2"], d["sign"], 1.0, float(np.sqrt(np.float64(d["p2"]))))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    eng = LloydEngine(shard, K, d["gamma"])
+    ref = LloydEngine(shard, K, d["gamma"])
+    modes = set()
+    for it in range(60):
+        phase = (it // 6) % 4
+        if phase in (0, 1):
+            c = planted + 0.01 * torch.randn(planted.shape, generator=g, device="cuda", dtype=torch.float64)
+        elif phase == 2:
+            c = planted[torch.randint(0, K, (K,), generator=g, device="cuda")] + 0.05 * torch.randn(
+                planted.shape, generator=g, device="cuda", dtype=torch.float64)       # duplicates, uncovered clusters
+        else:
+            c = torch.randn(planted.shape, generator=g, device="cuda", dtype=torch.float64) * 0.05   # everything ambiguous
+        c = c.contiguous()
+        os.environ.pop("SPKM_NO_SCREEN", None)
+        eng.assign_accumulate_step(c)
+        torch.cuda.synchronize()
+        path, listed = eng.last_path_info()
+        ra, rn = eng.last_screen_rounds()
+        modes.add("exact" if path == 0 else ("two-phase" if ra < rn else "plain"))
+        os.environ["SPKM_NO_SCREEN"] = "1"
+        ref.assign_accumulate_step(c)
+        torch.cuda.synchronize()
+        os.environ.pop("SPKM_NO_SCREEN", None)
+        assert torch.equal(eng.assign, ref.assign), f"call {it}"
+        assert torch.equal(eng.mind, ref.mind), f"call {it}"
+    assert "two-phase" in modes and "plain" in modes           # the policy really moved between modes
