@@ -696,7 +696,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
-                                                 int extra_k0, int a_rounds)
+                                                 int extra_k0, int a_rounds, int share)
 {
     constexpr int RS = SCREEN_KT * 4; // 128-B rows
     constexpr int PPS = 16;
@@ -736,6 +736,9 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
         const int base = point_of(t);
         if (base < n) {
             const int i = base + ps;
+            // PL = 5 with share > 1: the extra centroids are carried by all `share` tiles in turn -- this tile takes
+            // them for every share-th step (uniform per step), so that all tiles cost the same per chunk
+            const bool with_extra = PL == 5 && (share <= 1 || ((unsigned)(base >> 4) % (unsigned)share) == (unsigned)bm.tile);
             const int ic = i < n ? i : n - 1;
             const float* xp = xval + (size_t)ic * fixed_s + l4;
             const IR* rp = ir + (size_t)ic * fixed_s + l4;
@@ -755,7 +758,12 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     if constexpr (NR > r) if (r < a_rounds) {                                                               \
         const int xi = __builtin_bit_cast(int, x##r);                                                       \
         const int ro = (int)__umul24((unsigned)o##r, (unsigned)RS);                                         \
-        if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);   \
+        if (PL == 5 && !with_extra) {                                                                       \
+            if (r < NR - 1 || nvl == 4) quad_round<4, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);    \
+            else if (nvl == 3) quad_round<3, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);             \
+            else if (nvl == 2) quad_round<2, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);             \
+            else quad_round<1, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);                           \
+        } else if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);   \
         else if (nvl == 3) quad_round<3, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);            \
         else if (nvl == 2) quad_round<2, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);            \
         else quad_round<1, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);                          \
@@ -789,7 +797,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                         consider(h ? acc[a].y : acc[a].x, PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
                                                                   : k0 + 2 * PL * l4 + 2 * a + h);
                 }
-                if (PL == 5) consider(acc4, extra_k0 + l4);
+                if (PL == 5 && with_extra) consider(acc4, extra_k0 + l4);
             } else {
 #pragma unroll
                 for (int a = 0; a < NPAIR; a++) {
@@ -801,7 +809,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                         consider((k < K) ? v : __builtin_inff(), k);
                     }
                 }
-                if (PL == 5) {
+                if (PL == 5 && with_extra) {
                     const int k = extra_k0 + l4;
                     consider((k < K) ? acc4 : __builtin_inff(), k);
                 }
@@ -851,7 +859,7 @@ template <int NR, typename IR>
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
-    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int a_rounds)
+    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int a_rounds, int share)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -877,10 +885,10 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
-    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
-    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
-    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
-    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds);
+    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
+    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
+    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
+    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
