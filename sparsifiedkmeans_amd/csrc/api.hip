@@ -531,6 +531,48 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
         if (d_nk_u64) HIP_TRY(hipMemsetAsync(d_nk_u64, 0, (size_t)K * 8, ctx->stream));
         return SPKM_OK;
     }
+    // K = 1 on a fixed-stride shard (the k-means++ rounds): a plain stream over X, no tiles, no partials
+    if (K == 1 && s->fixed_s > 0 && s->nnz > 0 && !getenv("SPKM_NO_DIST1")) {
+        const int threads = 1024, nw = threads / 64;
+        const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
+        const size_t fixed_lds = (size_t)p * 8;
+        if (fixed_lds + 1024 + (size_t)nw * 16 * per_pt <= ctx->lds_max) {
+            int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 1024) / nw / per_pt);
+            pts = std::max(16, pts & ~15);
+            const size_t lds1 = fixed_lds + (size_t)nw * pts * per_pt;
+            const int nb = (int)std::min<long long>(std::max(1, ctx->num_cus), (n + (long long)nw * pts - 1) / ((long long)nw * pts));
+            if ((rc = ensure(ctx, ctx->blk_obj, (size_t)nb * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->blk_max, (size_t)nb * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->blk_imax, (size_t)nb * 8))) return rc;
+            ctx->ev_valid = false;
+            HIP_TRY(timing_begin(ctx));
+            if (s->ir_bits == 16) {
+                auto k1 = k_exact_dist1<unsigned short, 8>;
+                HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+                hipLaunchKernelGGL(k1, dim3(nb), dim3(threads), lds1, ctx->stream, (const unsigned short*)s->ir,
+                                   (const double*)s->x, d_centers, gamma, p, n, s->fixed_s, pts, (int*)d_assign, d_mind,
+                                   (double*)ctx->blk_obj.p, (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p);
+            } else {
+                auto k1 = k_exact_dist1<unsigned int, 8>;
+                HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+                hipLaunchKernelGGL(k1, dim3(nb), dim3(threads), lds1, ctx->stream, (const unsigned int*)s->ir,
+                                   (const double*)s->x, d_centers, gamma, p, n, s->fixed_s, pts, (int*)d_assign, d_mind,
+                                   (double*)ctx->blk_obj.p, (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(timing_end(ctx));
+            hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
+                               (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, nb, (double*)ctx->stats.p);
+            hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long*)ctx->nk.p,
+                               (unsigned long long)n);
+            HIP_TRY(hipGetLastError());
+            ctx->assign_KT = 0;
+            ctx->assign_G = 1;
+            if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
+            return SPKM_OK;
+        }
+    }
     const int KT = (s->nnz > 0) ? pick_kt(ctx, s->p, K64) : 0;
     int G = 1;
     ctx->ev_valid = false;

@@ -903,3 +903,100 @@ template <typename IR> static const void* screen_quad_kernel(int rounds)
     default: return nullptr;
     }
 }
+
+// ============================================================================================
+// K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through
+// SparseMatrixMinusCluster.c:133-141).  Nothing to minimise over, so the work is a stream over X: the same
+// lanes <-> entries load + LDS transposition as k_exact_accumulate (separately rounded subtract and multiply,
+// squared terms added in storage order), without the counting sort and the accumulation slabs.  HBM bound.
+// LDS: negc f64[p] | per wave ms f64[pts * S1]
+template <typename IR, int U>
+__global__ __launch_bounds__(1024) void k_exact_dist1(const IR* __restrict__ ir, const double* __restrict__ x,
+                                                      const double* __restrict__ C, double gamma, int p, long long n,
+                                                      int fixed_s, int pts, int* __restrict__ assign,
+                                                      double* __restrict__ mind, double* __restrict__ blk_obj2,
+                                                      double* __restrict__ blk_max, long long* __restrict__ blk_imax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* negc = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int S1 = fixed_s | 1;
+    double* ms = negc + p + (size_t)wave * pts * S1;
+    __shared__ double s_obj[16], s_max[16];
+    __shared__ long long s_imax[16];
+    for (int r = tid; r < p; r += blockDim.x) {
+        double c = C[r];
+        if (gamma > 0.0) c = c / gamma;
+        negc[r] = -c;
+    }
+    __syncthreads();
+    double obj2 = 0.0, dmax = -1.0;
+    long long imax = 0x7fffffffffffffffLL;
+    const long long stride = (long long)gridDim.x * nwaves * pts;
+    for (long long b0 = ((long long)blockIdx.x * nwaves + wave) * pts; b0 < n; b0 += stride) {
+        const int have = (n - b0 < pts) ? (int)(n - b0) : pts;
+        // uniform base pointers + 32-bit lane offsets; loads are unconditional (clamped), validity is applied to
+        // the staging store only -- no divergent control flow around the loads
+        const double* xb = x + b0 * fixed_s;
+        const IR* rb = ir + b0 * fixed_s;
+        const int lanec = lane < fixed_s ? lane : fixed_s - 1;
+        for (int u = 0; u < have; u += U) {
+            double xv[U];
+            int rv[U];
+#pragma unroll
+            for (int v = 0; v < U; v++) {
+                const int pc = (u + v < have) ? u + v : have - 1;
+                const int off = pc * fixed_s + lanec;
+                xv[v] = xb[off];
+                rv[v] = (int)rb[off];
+            }
+#pragma unroll
+            for (int v = 0; v < U; v++) {
+                const double d = xv[v] + negc[rv[v]]; // RN(x - c): the reference's subtraction
+                if (u + v < have && lane < fixed_s) ms[(size_t)(u + v) * S1 + lane] = d * d;
+                if (fixed_s > 64 && u + v < have) { // columns longer than one wave
+                    for (int e = 64 + lane; e < fixed_s; e += 64) {
+                        const double de = xb[(u + v) * fixed_s + e] + negc[(int)rb[(u + v) * fixed_s + e]];
+                        ms[(size_t)(u + v) * S1 + e] = de * de;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < have) {
+            double acc = 0.0;
+            const double* mq = ms + (size_t)lane * S1;
+            for (int j = 0; j < fixed_s; j++) acc = acc + mq[j];
+            const double dist = sqrt(acc);
+            const long long i = b0 + lane;
+            mind[i] = dist;
+            assign[i] = 0;
+            obj2 += dist * dist;
+            if (dist > dmax || (dist == dmax && i < imax)) { dmax = dist; imax = i; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        obj2 += __shfl_down(obj2, off);
+        const double om = __shfl_down(dmax, off);
+        const long long oi = __shfl_down(imax, off);
+        if (om > dmax || (om == dmax && oi < imax)) { dmax = om; imax = oi; }
+    }
+    if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, m = -1.0;
+        long long im = 0x7fffffffffffffffLL;
+        for (int w = 0; w < nwaves; w++) {
+            o += s_obj[w];
+            if (s_max[w] > m || (s_max[w] == m && s_imax[w] < im)) { m = s_max[w]; im = s_imax[w]; }
+        }
+        blk_obj2[blockIdx.x] = o;
+        blk_max[blockIdx.x] = m;
+        blk_imax[blockIdx.x] = im;
+    }
+}
+
+__global__ void k_set_u64(unsigned long long* __restrict__ dst, unsigned long long v) { dst[0] = v; }
