@@ -544,17 +544,22 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 if (qn < len && lane < pts && qn + lane < len) my_next = perm[start + qn + lane];
             }
             // (a) U points' loads in flight per lane
+            const int lanec = lane < fixed_s ? lane : fixed_s - 1;
             for (int u = 0; u < have; u += U) {
                 double xv[U];
                 int rv[U];
 #pragma unroll
                 for (int v = 0; v < U; v++) {
+                    // unconditional loads through a uniform per-point base + a clamped 32-bit lane offset (no
+                    // divergent control flow around the loads); validity is applied to the row id afterwards
                     const int src = (u + v < have) ? u + v : u;
                     const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, src);
                     const bool ok = (u + v < have) && lane < fixed_s;
-                    const long long j = i * fixed_s + lane;
-                    xv[v] = ok ? x[j] : 0.0;
-                    rv[v] = ok ? (int)ir[j] : -1;
+                    const double* xb = x + i * fixed_s;
+                    const IR* rb = ir + i * fixed_s;
+                    xv[v] = xb[lanec];
+                    const int r = (int)rb[lanec];
+                    rv[v] = ok ? r : -1;
                 }
 #pragma unroll
                 for (int v = 0; v < U; v++) {
