@@ -861,7 +861,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         HIP_TRY(hipMalloc((void**)&sm->xf, (size_t)(s->nnz + 48) * 4));
         HIP_TRY(hipMemsetAsync(sm->xf, 0, (size_t)(s->nnz + 48) * 4, ctx->stream));
     }
-    if (!sm->norms_done || (!quad && !sm->xf_done)) {
+    if ((!sm->norms_done && !(quad && !sm->xfs)) || (!quad && !sm->xf_done)) { // (with the 4-lane screen the reorder pass below computes the norms)
         hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256), 0,
                            ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2,
                            quad ? (float*)nullptr : sm->xf);
@@ -876,7 +876,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         HIP_TRY(hipMemsetAsync(sm->xfs, 0, (size_t)(s->nnz + 48) * 4, ctx->stream));
         HIP_TRY(hipMemsetAsync(sm->irs, 0, (size_t)(s->nnz + 48) * isz, ctx->stream));
         hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
-                           0, ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, sm->xfs, (IR*)sm->irs);
+                           0, ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, sm->xfs, (IR*)sm->irs,
+                           sm->norms_done ? (double*)nullptr : sm->xn1, sm->norms_done ? (double*)nullptr : sm->xn2);
+        sm->norms_done = true;
     }
     // Last tile of the 4-lanes-per-point kernel.  <= 4 centroids: no tile of their own -- the workgroups of the
     // previous tile carry them as one extra centroid per lane (pl 5; needs (p+1) x 16 B more LDS); <= 16: a

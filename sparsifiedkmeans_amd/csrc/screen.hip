@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
 template <typename IR>
 __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ ir, const double* __restrict__ x,
                                                         long long n, int fixed_s, float* __restrict__ xfs,
-                                                        IR* __restrict__ irs)
+                                                        IR* __restrict__ irs, double* __restrict__ xn1,
+                                                        double* __restrict__ xn2)
 {
     const int sub = threadIdx.x & 15;
     const int lane = threadIdx.x & 63;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
             nfirst += __builtin_popcount((unsigned)((__ballot(f) >> gsh) & 0xffffull));
         }
         int cf = 0, cs = 0;
+        double na = 0.0, nb = 0.0;
         for (int u = 0; u < nt; u++) {
             const int e = u * 16 + sub;
             const bool ok = live && e < fixed_s;
@@ -144,12 +146,18 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
             const unsigned below = (1u << sub) - 1u;
             if (ok) {
                 const int pos = f ? cf + __builtin_popcount(mf & below) : nfirst + cs + __builtin_popcount(mg & below);
-                xfs[j0 + pos] = (float)x[j0 + e];
+                const double v = x[j0 + e];
+                na += fabs(v);
+                nb += v * v;
+                xfs[j0 + pos] = (float)v;
                 irs[j0 + pos] = r;
             }
             cf += __builtin_popcount(mf);
             cs += __builtin_popcount(mg);
         }
+        // the certificate's per-point norms (sum |x|, sum x^2; any order) ride on the same pass over x
+        for (int off = 8; off > 0; off >>= 1) { na += __shfl_xor(na, off); nb += __shfl_xor(nb, off); }
+        if (live && sub == 0 && xn1) { xn1[i] = na; xn2[i] = nb; }
     }
 }
 
