@@ -115,46 +115,67 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
                                                         IR* __restrict__ irs, double* __restrict__ xn1,
                                                         double* __restrict__ xn2)
 {
+    // 16 lanes per point, up to 4 rounds of 16 entries (fixed_s <= 64) held in registers; the partitioned
+    // column is staged in LDS so that both the reads and the writes are contiguous per point
+    __shared__ float s_x[16][64];
+    __shared__ IR s_r[16][64];
     const int sub = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;
     const int lane = threadIdx.x & 63;
     const int gsh = lane & 48; // first lane of this 16-lane group
     const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
     const long long rounds = (n + ng - 1) / ng;
-    const int nt = (fixed_s + 15) >> 4;
+    const unsigned below = (1u << sub) - 1u;
     for (long long t = 0; t < rounds; t++) {
         const long long i = g0 + t * ng;
         const bool live = i < n;
         const long long j0 = (live ? i : 0) * fixed_s;
         const unsigned want = (unsigned)(i & 1);
+        double xv[4];
+        IR rv[4];
+        unsigned mf[4], mg[4];
         int nfirst = 0;
-        for (int u = 0; u < nt; u++) {
-            const int e = u * 16 + sub;
-            const bool f = live && e < fixed_s && ((unsigned)ir[j0 + e] & 1u) == want;
-            nfirst += __builtin_popcount((unsigned)((__ballot(f) >> gsh) & 0xffffull));
-        }
-        int cf = 0, cs = 0;
         double na = 0.0, nb = 0.0;
-        for (int u = 0; u < nt; u++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
             const bool ok = live && e < fixed_s;
-            const IR r = ok ? ir[j0 + e] : (IR)0;
-            const bool f = ok && ((unsigned)r & 1u) == want;
-            const bool g = ok && !f;
-            const unsigned mf = (unsigned)((__ballot(f) >> gsh) & 0xffffull);
-            const unsigned mg = (unsigned)((__ballot(g) >> gsh) & 0xffffull);
-            const unsigned below = (1u << sub) - 1u;
-            if (ok) {
-                const int pos = f ? cf + __builtin_popcount(mf & below) : nfirst + cs + __builtin_popcount(mg & below);
-                const double v = x[j0 + e];
-                na += fabs(v);
-                nb += v * v;
-                xfs[j0 + pos] = (float)v;
-                irs[j0 + pos] = r;
-            }
-            cf += __builtin_popcount(mf);
-            cs += __builtin_popcount(mg);
+            xv[u] = ok ? x[j0 + e] : 0.0;
+            rv[u] = ok ? ir[j0 + e] : (IR)0;
+            const bool f = ok && ((unsigned)rv[u] & 1u) == want;
+            mf[u] = (unsigned)((__ballot(f) >> gsh) & 0xffffull);
+            mg[u] = (unsigned)((__ballot(ok && !f) >> gsh) & 0xffffull);
+            nfirst += __builtin_popcount(mf[u]);
+            na += fabs(xv[u]);
+            nb += xv[u] * xv[u];
         }
+        int cf = 0, cs = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = u * 16 + sub;
+            if (live && e < fixed_s) {
+                const bool f = (mf[u] >> sub) & 1u;
+                const int pos = f ? cf + __builtin_popcount(mf[u] & below) : nfirst + cs + __builtin_popcount(mg[u] & below);
+                s_x[grp][pos] = (float)xv[u];
+                s_r[grp][pos] = rv[u];
+            }
+            cf += __builtin_popcount(mf[u]);
+            cs += __builtin_popcount(mg[u]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the group's 16 lanes belong to one wave
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = u * 16 + sub;
+                if (e < fixed_s) {
+                    xfs[j0 + e] = s_x[grp][e];
+                    irs[j0 + e] = s_r[grp][e];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         // the certificate's per-point norms (sum |x|, sum x^2; any order) ride on the same pass over x
         for (int off = 8; off > 0; off >>= 1) { na += __shfl_xor(na, off); nb += __shfl_xor(nb, off); }
         if (live && sub == 0 && xn1) { xn1[i] = na; xn2[i] = nb; }
