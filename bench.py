@@ -145,6 +145,7 @@ def main():
 
     path, listed = eng.last_path_info()
     rounds_all, rounds = eng.last_screen_rounds()
+    mode = eng.last_screen_mode()
     # dominant kernel (tiled assignment) durations of exactly the timed launches, HIP events on our stream
     buf = (C.c_double * max(args.steps, 1))()
     cnt = C.c_int()
@@ -198,7 +199,13 @@ def main():
                    "uncertified_points_last_iter": listed,
                    # rounds (of 4 stored entries) evaluated for all centroids / per column in the last iteration:
                    # equal = plain screen; fewer = the two-phase screen switched itself on (converged, separated data)
-                   "screen_rounds_last_iter": [rounds_all, rounds]},
+                   "screen_rounds_last_iter": [rounds_all, rounds],
+                   # form of the last screen call (plain / two-phase / hinted: the previous iteration's
+                   # min-distances let 16-point steps stop after rounds_all rounds) and the number of
+                   # (16-point step, centroid tile) pairs it finished early
+                   "screen_form_last_iter": {0: "plain", 1: "two-phase", 2: "hinted"}.get(mode[0], "none"),
+                   "early_finished_steps": mode[3] if mode[0] == 2 else None,
+                   "steps_per_centroid_tile": (n_local + 15) // 16},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel": dominant_kernel(path, s), "kernel_ms": k_ms,

@@ -147,7 +147,13 @@ int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const in
  * fast path: a certified f32 screen over all centroids, exact reference arithmetic for every point the
  * screen cannot certify, and the exact distance of every point to its assigned centroid fused into the
  * accumulation pass (csrc/screen.hip).  Nothing computed in f32 reaches an output.  The environment
- * variable SPKM_NO_SCREEN=1 forces the all-exact kernels. */
+ * variable SPKM_NO_SCREEN=1 forces the all-exact kernels.
+ * Hints: when a shard is called again with the SAME d_mind pointer as in its previous call, the buffer's
+ * contents on entry (that call's min-distances, if the caller left them alone) steer the screen: a group of
+ * 16 points stops after ~30 % of its entries once every other centroid of a tile is already more than twice
+ * the hinted distance away.  Hints only choose how much work is done -- every shortcut keeps a certified
+ * lower bound, a stale or overwritten buffer costs time (and switches the hints off), never correctness.
+ * SPKM_NO_HINT=1 disables them. */
 int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers,
                                double gamma, int32_t *d_assign, double *d_mind, double *d_stats,
                                uint64_t *d_nk_u64, double *d_reduce);
@@ -161,6 +167,11 @@ int spkm_last_path_info(spkm_ctx *ctx, int64_t info[2]);
  * winner, and off again when it certifies poorly.  SPKM_NO_PRUNE=1 disables it; outputs never change.
  * Both 0 after any other path. */
 int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
+/* info[0] = form of the last screen call: 0 plain, 1 two-phase, 2 hinted two-phase (-1: no screen);
+ * info[1..3] = that call's counters: points listed for exact evaluation, points with a runner-up within 2x
+ * (a bound: over-counts in the two-phase forms), (16-point step, centroid tile) pairs finished early by the
+ * hinted form.  Blocks on the stream. */
+int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[4]);
 
 /* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
  * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;

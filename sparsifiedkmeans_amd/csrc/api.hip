@@ -47,6 +47,7 @@ struct spkm_ctx {
     int last_path = 0;               // 0 = exact tiled/generic, 1 = f32 screen + exact confirmation
     unsigned last_listed = 0;        // points sent to the exact list by the last screen (read lazily)
     int last_rounds_all = 0, last_rounds = 0; // rounds for all centroids / total rounds of the last 4-lane screen call
+    int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     char errmsg[256] = {0};
 };
 
@@ -74,6 +75,11 @@ struct spkm_shard {
     // two-phase screen (screen.hip, phase B): rounds evaluated for ALL centroids in the call whose counters are
     // pending / in the next call (0 = all rounds, the plain screen), and calls left before pruning is retried
     int prune_pending_a = 0, prune_next_a = 0, prune_cooldown = 0;
+    // hinted two-phase screen: the d_mind buffer the previous fused call wrote (its contents are that call's
+    // min-distances as long as the caller reuses the buffer), whether the pending call used it, calls to wait
+    const double* hint_ptr = nullptr;
+    bool hint_pending = false;
+    int hint_cooldown = 0;
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -319,6 +325,8 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->prune_next_a = 0;
     s->prune_cooldown = 0;
     s->prune_pending_a = 0;
+    s->hint_ptr = nullptr;
+    s->hint_cooldown = 0;
     return SPKM_OK;
 }
 
@@ -839,7 +847,7 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
 
 template <typename IR>
 static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d_centers, double gamma,
-                      int32_t* d_assign, double* d_mind, double* d_reduce, int prune_a)
+                      int32_t* d_assign, double* d_mind, double* d_reduce, int prune_a, const double* hint)
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
@@ -907,7 +915,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 12, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
@@ -940,7 +948,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         ctx->last_rounds_all = quad ? a_rounds : 0;
         ctx->last_rounds = quad ? q_rounds : 0;
         int a_share = share_extra ? Gs : 1;
-        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra, &a_rounds, &a_share};
+        const double* a_hint = (quad && a_rounds < q_rounds) ? hint : nullptr; // nullptr: every step is finished for the leaders only
+        float a_hc = 4.0f; // the other centroids of a tile must be > 2x the previous min-distance away (squared: 4x)
+        unsigned* a_cnt = (unsigned*)ctx->nlist.p;
+        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra, &a_rounds, &a_share,
+                        &a_hint, &a_hc, &a_cnt};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -1023,28 +1035,50 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         if (listed > 0.05 * nn) sm->exact_cooldown = 8;
         const int nr = (s->fixed_s + 3) / 4;
         const int a_prune = std::max(2, (3 * nr + 9) / 10); // ~30 % of the rounds (s = 51: 4 of 13): a runner-up 2x away clears it
-        if (sm->prune_pending_a == 0)
+        if (sm->hint_pending) {
+            // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only
+            // while the hints do not mislead (stale buffer: many listed points)
+            const double steps = (nn / 16.0) * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
+            if (listed > 0.005 * nn || (double)sm->h_nlist[2] < 0.05 * steps) sm->hint_cooldown = 16;
+            // runner-up bounds of early-finished steps are partial sums, so `ambig` over-counts: still small
+            // means the unconditional form (no hint loads, no second evaluation) is safe to try
+            else if (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) sm->prune_next_a = a_prune;
+        } else if (sm->prune_pending_a == 0)
             sm->prune_next_a = (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) ? a_prune : 0;
         else if (listed > 0.005 * nn) { sm->prune_next_a = 0; sm->prune_cooldown = 16; }
     }
     if (sm->prune_cooldown > 0) sm->prune_cooldown--;
+    if (sm->hint_cooldown > 0) sm->hint_cooldown--;
     const bool cooling = sm->exact_cooldown > 0;
     if (cooling) sm->exact_cooldown--;
     if (s->n > 0 && !cooling && screen_eligible(ctx, s, (int)K64)) {
         ctx->ev_valid = false;
-        const int prune_a = getenv("SPKM_NO_PRUNE") ? 0 : sm->prune_next_a;
-        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a)
-                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a);
+        int prune_a = getenv("SPKM_NO_PRUNE") ? 0 : sm->prune_next_a;
+        // Hinted two-phase screen: the caller hands in the same d_mind buffer as last time, so it still holds the
+        // previous call's min-distances -- used as per-point hints for how far the competition has to be before a
+        // step may stop early (screen.hip).  Chosen when the unconditional two-phase form is not, and not cooling.
+        const double* hint = nullptr;
+        if (prune_a == 0 && !getenv("SPKM_NO_PRUNE") && !getenv("SPKM_NO_HINT") && sm->hint_ptr == d_mind &&
+            sm->hint_cooldown == 0 && screen_use_quad(s)) {
+            const int nr = (s->fixed_s + 3) / 4;
+            const int a_h = std::max(2, (3 * nr + 9) / 10);
+            if (a_h < nr) { hint = d_mind; prune_a = a_h; }
+        }
+        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, hint)
+                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, hint);
         if (rc) return rc;
+        sm->hint_ptr = d_mind;
+        ctx->last_mode = hint ? 2 : (ctx->last_rounds_all < ctx->last_rounds ? 1 : 0);
         if (!sm->h_nlist) {
             HIP_TRY(hipHostMalloc((void**)&sm->h_nlist, 64, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
         }
         if (!sm->nlist_pending) {
-            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 12, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
             sm->nlist_pending = true;
             sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
+            sm->hint_pending = hint != nullptr;
         }
         if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1061,6 +1095,23 @@ extern "C" int spkm_last_screen_rounds(spkm_ctx* ctx, int64_t info[2])
     if (!ctx || !info) return SPKM_ERR_NULL_ARG;
     info[0] = ctx->last_path == 1 ? ctx->last_rounds_all : 0;
     info[1] = ctx->last_path == 1 ? ctx->last_rounds : 0;
+    return SPKM_OK;
+}
+
+// Form and counters of the last screen call.  Blocks on the stream (diagnostics, not the hot path).
+extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[4])
+{
+    if (!ctx || !info) return SPKM_ERR_NULL_ARG;
+    info[0] = -1;
+    info[1] = info[2] = info[3] = 0;
+    if (ctx->last_path == 1 && ctx->nlist.p) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned v[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpy(v, ctx->nlist.p, 12, hipMemcpyDeviceToHost));
+        info[0] = ctx->last_mode;
+        for (int j = 0; j < 3; j++) info[1 + j] = v[j];
+    }
     return SPKM_OK;
 }
 

@@ -730,7 +730,9 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
-                                                 int extra_k0, int a_rounds, int share)
+                                                 int extra_k0, int a_rounds, int share,
+                                                 const double* __restrict__ hint, float hint_c,
+                                                 unsigned* __restrict__ counters)
 {
     constexpr int RS = SCREEN_KT * 4; // 128-B rows
     constexpr int PPS = 16;
@@ -766,6 +768,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     // a step's entries: NR rounds of 4 (entries past the column become x = 0 on the zero row p).  No software
     // prefetch across steps: the other three waves of the SIMD cover the load latency.
     const int nvl = fixed_s - 4 * (NR - 1);
+    unsigned npruned = 0; // steps this wave finished in the hinted two-phase form
     for (int t = draw(); t < Tn; t = draw()) {
         const int base = point_of(t);
         if (base < n) {
@@ -788,8 +791,10 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; // two f32 sums each (bit pattern 0 = (0.f, 0.f))
             float acc4 = 0.f;                                       // PL = 5: the lane's extra centroid
             // the last round broadcasts only the nvl = fixed_s - 4 (NR - 1) entries the column still has
-#define SPKM_QUAD_ROUND(r)                                                                                  \
-    if constexpr (NR > r) if (r < a_rounds) {                                                               \
+#define SPKM_GUARD_A(r) ((r) < a_rounds)
+#define SPKM_GUARD_B(r) ((r) >= a_rounds)
+#define SPKM_QUAD_ROUND_G(r, COND)                                                                          \
+    if constexpr (NR > r) if (COND(r)) {                                                                    \
         const int xi = __builtin_bit_cast(int, x##r);                                                       \
         const int ro = (int)__umul24((unsigned)o##r, (unsigned)RS);                                         \
         if (PL == 5 && !with_extra) {                                                                       \
@@ -802,64 +807,87 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
         else if (nvl == 2) quad_round<2, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);            \
         else quad_round<1, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);                          \
     }
-            SPKM_QUAD_ROUND(0) SPKM_QUAD_ROUND(1) SPKM_QUAD_ROUND(2) SPKM_QUAD_ROUND(3) SPKM_QUAD_ROUND(4)
-            SPKM_QUAD_ROUND(5) SPKM_QUAD_ROUND(6) SPKM_QUAD_ROUND(7) SPKM_QUAD_ROUND(8) SPKM_QUAD_ROUND(9)
-            SPKM_QUAD_ROUND(10) SPKM_QUAD_ROUND(11) SPKM_QUAD_ROUND(12) SPKM_QUAD_ROUND(13) SPKM_QUAD_ROUND(14)
-            SPKM_QUAD_ROUND(15)
-#undef SPKM_QUAD_ROUND
-            const f2v acc[4] = {__builtin_bit_cast(f2v, acc0), __builtin_bit_cast(f2v, acc1),
-                                __builtin_bit_cast(f2v, acc2), __builtin_bit_cast(f2v, acc3)};
+#define SPKM_QUAD_ROUNDS(COND)                                                                              \
+    SPKM_QUAD_ROUND_G(0, COND) SPKM_QUAD_ROUND_G(1, COND) SPKM_QUAD_ROUND_G(2, COND) SPKM_QUAD_ROUND_G(3, COND)   \
+    SPKM_QUAD_ROUND_G(4, COND) SPKM_QUAD_ROUND_G(5, COND) SPKM_QUAD_ROUND_G(6, COND) SPKM_QUAD_ROUND_G(7, COND)   \
+    SPKM_QUAD_ROUND_G(8, COND) SPKM_QUAD_ROUND_G(9, COND) SPKM_QUAD_ROUND_G(10, COND) SPKM_QUAD_ROUND_G(11, COND) \
+    SPKM_QUAD_ROUND_G(12, COND) SPKM_QUAD_ROUND_G(13, COND) SPKM_QUAD_ROUND_G(14, COND) SPKM_QUAD_ROUND_G(15, COND)
+            SPKM_QUAD_ROUNDS(SPKM_GUARD_A)
             // lane's centroids.  PL = 4: first read -> k0 + off0/4 + 0..3, second read -> k0 + off1/4 + 0..3;
             // PL < 4: k0 + 2 PL l4 + 0 .. 2 PL - 1 (either copy)
             // branch-free smallest / second smallest / argmin over the lane's values (ascending k, first wins).
             // Raw v_min / v_max: the compiler's fminf / fmaxf add a canonicalising v_max per operand.  A NaN
             // estimate never wins (v < lo is false) and drags `hi` down to `lo`: the point goes to the list.
-            float lo = __builtin_inff(), hi = __builtin_inff();
-            int klo = -1;
+            float lo, hi, m1, m2;
+            int klo, first;
+            unsigned seg;
             constexpr int NPAIR = PL == 5 ? 4 : PL;
-            auto consider = [&](float v, int k) {
-                const bool less = v < lo;
-                hi = raw_min_f32(hi, raw_max_f32(lo, v));
-                klo = less ? k : klo;
-                lo = less ? v : lo;
-            };
-            if (tile_full) { // every slot of this tile is a real centroid (uniform): no masking
+            auto evaluate = [&]() {
+                const f2v acc[4] = {__builtin_bit_cast(f2v, acc0), __builtin_bit_cast(f2v, acc1),
+                                    __builtin_bit_cast(f2v, acc2), __builtin_bit_cast(f2v, acc3)};
+                lo = __builtin_inff();
+                hi = __builtin_inff();
+                klo = -1;
+                auto consider = [&](float v, int k) {
+                    const bool less = v < lo;
+                    hi = raw_min_f32(hi, raw_max_f32(lo, v));
+                    klo = less ? k : klo;
+                    lo = less ? v : lo;
+                };
+                if (tile_full) { // every slot of this tile is a real centroid (uniform): no masking
 #pragma unroll
-                for (int a = 0; a < NPAIR; a++) {
+                    for (int a = 0; a < NPAIR; a++) {
 #pragma unroll
-                    for (int h = 0; h < 2; h++)
-                        consider(h ? acc[a].y : acc[a].x, PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
-                                                                  : k0 + 2 * PL * l4 + 2 * a + h);
-                }
-                if (PL == 5 && with_extra) consider(acc4, extra_k0 + l4);
-            } else {
+                        for (int h = 0; h < 2; h++)
+                            consider(h ? acc[a].y : acc[a].x, PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
+                                                                      : k0 + 2 * PL * l4 + 2 * a + h);
+                    }
+                    if (PL == 5 && with_extra) consider(acc4, extra_k0 + l4);
+                } else {
 #pragma unroll
-                for (int a = 0; a < NPAIR; a++) {
+                    for (int a = 0; a < NPAIR; a++) {
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int k = PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
-                                              : k0 + 2 * PL * l4 + 2 * a + h;
-                        const float v = h ? acc[a].y : acc[a].x;
-                        consider((k < K) ? v : __builtin_inff(), k);
+                        for (int h = 0; h < 2; h++) {
+                            const int k = PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
+                                                  : k0 + 2 * PL * l4 + 2 * a + h;
+                            const float v = h ? acc[a].y : acc[a].x;
+                            consider((k < K) ? v : __builtin_inff(), k);
+                        }
+                    }
+                    if (PL == 5 && with_extra) {
+                        const int k = extra_k0 + l4;
+                        consider((k < K) ? acc4 : __builtin_inff(), k);
                     }
                 }
-                if (PL == 5 && with_extra) {
-                    const int k = extra_k0 + l4;
-                    consider((k < K) ? acc4 : __builtin_inff(), k);
-                }
+                m1 = quad_min_f32(lo);
+                const bool win = (lo == m1);
+                seg = (unsigned)(__ballot(win) >> (ps * 4)) & 0xfu;
+                first = seg ? __builtin_ctz(seg) : 0;
+                m2 = quad_min_f32((l4 == first) ? hi : lo);
+            };
+            evaluate();
+            // Hinted two-phase screen: `hint` holds each point's min-distance of the PREVIOUS call.  If, for every
+            // point of this step, all non-leading centroids of the tile are already (by their partial sums) more
+            // than sqrt(hint_c) times that distance away, the step is finished for the leaders only; otherwise the
+            // remaining rounds are run for all centroids.  The hint steers the work, never a result.
+            int a_eff = a_rounds;
+            if (a_rounds < NR && hint != nullptr) {
+                const float hv = (float)hint[i < n ? i : n - 1];
+                const bool fine = !(i < n) || m2 >= hint_c * hv * hv; // false for NaN
+                if (!__all(fine)) {
+                    SPKM_QUAD_ROUNDS(SPKM_GUARD_B)
+                    evaluate();
+                    a_eff = NR;
+                } else
+                    npruned++;
             }
-            const float m1 = quad_min_f32(lo);
-            const bool win = (lo == m1);
-            const unsigned seg = (unsigned)(__ballot(win) >> (ps * 4)) & 0xfu;
-            const int first = seg ? __builtin_ctz(seg) : 0;
-            const float m2 = quad_min_f32((l4 == first) ? hi : lo);
             // Phase B (a_rounds < NR): the sums above cover only the first 4 a_rounds entries of each column.  They are
             // LOWER bounds of the full sums (every term is >= 0 and f32 addition is monotone), which is all the
             // certificate needs for the centroids that lose; only the tile's leader by partial sum is finished:
             // each lane adds ITS OWN remaining entries (no broadcast) for that one centroid, the quad adds up.
             //   m1 = full estimate of the leader, m2 = smallest partial sum among the others (<= their full sums)
             float full = m1;
-            if (a_rounds < NR) {
+            if (a_eff < NR) {
                 const int kwin = quad_min_i32((l4 == first && seg != 0u) ? klo : 0x7fffffff);
                 const bool is_extra = PL == 5 && kwin >= extra_k0;
                 const int cbase = is_extra ? extra_base + (kwin - extra_k0) * 4 : (kwin - k0) * 4;
@@ -877,6 +905,10 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                 SPKM_QUAD_FINISH(10) SPKM_QUAD_FINISH(11) SPKM_QUAD_FINISH(12) SPKM_QUAD_FINISH(13)
                 SPKM_QUAD_FINISH(14) SPKM_QUAD_FINISH(15)
 #undef SPKM_QUAD_FINISH
+#undef SPKM_QUAD_ROUNDS
+#undef SPKM_QUAD_ROUND_G
+#undef SPKM_GUARD_A
+#undef SPKM_GUARD_B
                 full = m1 + quad_sum_f32(kwin == 0x7fffffff ? 0.f : accb);
             }
             if (l4 == first && i < n) {
@@ -887,13 +919,15 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             }
         }
     }
+    if (counters != nullptr && lane == 0 && npruned) atomicAdd(counters + 2, npruned);
 }
 
 template <int NR, typename IR>
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
-    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int a_rounds, int share)
+    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int a_rounds, int share,
+    const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -919,10 +953,10 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
-    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
-    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
-    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
-    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share);
+    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
+    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
+    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
+    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)

@@ -285,3 +285,45 @@ def test_two_phase_screen_switches_itself_on_and_off(gpu_ctx, oracle):
         ra, rd = oracle.assign(p2, 6000, *parts(Y), bad.cpu().numpy().T, gam)
         assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)
     assert last[0] == last[1] or eng.last_path_info()[0] == 0    # back on the plain screen (or the exact kernels)
+
+
+def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle):
+    """Mid-run Lloyd state: some clusters are split between two nearby centres (runner-up within 2x: the
+    unconditional two-phase form stays off) and some have no centre of their own.  From the second call on the
+    previous min-distances, still in the caller's buffer, let 16-point steps finish early (form 2, counter of
+    early-finished steps > 0); outputs equal the oracle's bit for bit on every call, also after the buffer has
+    been scribbled over (hints then mislead: more work, same answers)."""
+    import time
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    K, n = 40, 8000
+    data = synth.sparsified_gmm_host(p=256, n=n, K=K, gamma=0.2, seed=11, fwht=oracle.fwht)
+    Y, p2, gam = data["Y"], data["p2"], data["gamma"]
+    cen = np.zeros((p2, K))
+    for k in range(K):
+        Yk = Y[:, data["labels"] == k]
+        S = np.asarray(Yk.sum(axis=1)).ravel()
+        Cnt = np.asarray((Yk != 0).sum(axis=1)).ravel()
+        cen[:, k] = gam * S / (Cnt + 1e-16)
+    rng = np.random.default_rng(3)
+    spread = np.abs(cen).mean()
+    for k in range(0, 10):                                  # clusters 30..39 lose their centre; 0..9 get two
+        delta = 0.3 * spread * rng.standard_normal(p2)
+        cen[:, 30 + k] = cen[:, k] + delta
+        cen[:, k] = cen[:, k] - delta
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, Y), K, gam)
+    centers = torch.tensor(np.ascontiguousarray(cen.T), device="cuda")
+    ra, rd = oracle.assign(p2, n, *parts(Y), cen, gam)
+    modes = []
+    for it in range(6):
+        if it == 4:
+            eng.mind.mul_(0.01)                             # a caller that reuses the buffer: misleading hints
+        eng.assign_accumulate_step(centers)
+        torch.cuda.synchronize()
+        time.sleep(0.01)
+        modes.append(eng.last_screen_mode())
+        assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)
+    assert modes[0][0] == 0                                 # nothing to go by on the first call
+    assert any(m[0] == 2 for m in modes[1:4]), modes
+    assert all(m[3] > 0 for m in modes if m[0] == 2), modes  # some steps did finish early
+    _check(eng, oracle, Y, cen, gam)
