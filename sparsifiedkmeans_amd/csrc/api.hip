@@ -950,6 +950,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         int a_share = share_extra ? Gs : 1;
         const double* a_hint = (quad && a_rounds < q_rounds) ? hint : nullptr; // nullptr: every step is finished for the leaders only
         float a_hc = 4.0f; // the other centroids of a tile must be > 2x the previous min-distance away (squared: 4x)
+        if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra, &a_rounds, &a_share,
                         &a_hint, &a_hc, &a_cnt};
@@ -1061,7 +1062,8 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         if (prune_a == 0 && !getenv("SPKM_NO_PRUNE") && !getenv("SPKM_NO_HINT") && sm->hint_ptr == d_mind &&
             sm->hint_cooldown == 0 && screen_use_quad(s)) {
             const int nr = (s->fixed_s + 3) / 4;
-            const int a_h = std::max(2, (3 * nr + 9) / 10);
+            int a_h = std::max(2, (3 * nr + 9) / 10);
+            if (const char* ev = getenv("SPKM_HINT_A")) a_h = std::max(1, atoi(ev));
             if (a_h < nr) { hint = d_mind; prune_a = a_h; }
         }
         rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, hint)
