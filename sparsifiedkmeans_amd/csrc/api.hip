@@ -877,14 +877,13 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         if (!quad) sm->xf_done = true;
     }
     if (quad && !sm->xfs) {
-        // f32 values + row ids, each column partitioned by row parity (k_screen_reorder)
+        // f32 values + row ids in the kernel's step-major lane order, columns partitioned by row parity (k_screen_reorder)
         const size_t isz = sizeof(IR);
-        HIP_TRY(hipMalloc((void**)&sm->xfs, (size_t)(s->nnz + 48) * 4));
-        HIP_TRY(hipMalloc((void**)&sm->irs, (size_t)(s->nnz + 48) * isz));
-        HIP_TRY(hipMemsetAsync(sm->xfs, 0, (size_t)(s->nnz + 48) * 4, ctx->stream));
-        HIP_TRY(hipMemsetAsync(sm->irs, 0, (size_t)(s->nnz + 48) * isz, ctx->stream));
+        const size_t slots = (size_t)((n + 15) / 16) * ((s->fixed_s + 3) / 4) * 64; // steps x rounds x lanes
+        HIP_TRY(hipMalloc((void**)&sm->xfs, slots * 4));
+        HIP_TRY(hipMalloc((void**)&sm->irs, slots * isz));
         hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
-                           0, ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, sm->xfs, (IR*)sm->irs,
+                           0, ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, p, sm->xfs, (IR*)sm->irs,
                            sm->norms_done ? (double*)nullptr : sm->xn1, sm->norms_done ? (double*)nullptr : sm->xn2);
         sm->norms_done = true;
     }
@@ -920,7 +919,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
                        0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
-                       (unsigned long long*)ctx->cmax.p, pl_last);
+                       (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0);
     hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0,
                        ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
     // 1. screen

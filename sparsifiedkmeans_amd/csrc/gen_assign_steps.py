@@ -286,10 +286,13 @@ def quad_round_block(nv: int, pl: int) -> str:
     entries of a point, owned by lanes 0..nv-1 of its quad; pl = centroid PAIRS per lane (4: full tile of 32
     centroids, two 16-B reads; 2: 16 centroids, one 16-B read; 1: 8 centroids, one 8-B read; 5: a full tile
     plus ONE extra centroid per lane held in a second LDS region with 16-B rows).  Per entry m:
-        a_m = off0 + ro[quad lane m]                   v_add_u32_dpp quad_perm:[m,m,m,m]
+        a_m = off0 ^ ro[quad lane m]                   v_xor_b32_dpp quad_perm:[m,m,m,m]
+                                                       (ro = row*128 | swizzle*16: the lane's 16-B piece l4 of a
+                                                        half-row sits at piece l4 ^ ((row >> 1) & 3), which spreads
+                                                        the COLUMN reads of the two-phase finish over 8 banks)
         b_m = a_m + delta                              v_add_u32            (pl >= 4: the other half-row,
                                                                              +64 or -64 by point slot)
-        e_m = (a_m >> 3) + ce                          v_lshrrev_b32, v_add_u32   (pl = 5: row*16 + lane const)
+        e_m = (a_m >> 7) * 16 + ce                     v_bfe_u32, v_lshl_add_u32  (pl = 5: row*16 + lane const)
         T   = LDS[a_m] (, LDS[b_m]) (, LDS[e_m])       ds_read_b128 / b64 (/ b32)
         x_m = xi[quad lane m]                          v_mov_b32_dpp
         T  += (x_m, x_m)   (pl pairs)                  v_pk_add_f32 op_sel_hi:[1,0]
@@ -301,15 +304,15 @@ def quad_round_block(nv: int, pl: int) -> str:
     L = ["s_nop 1"]
     two = pl >= 4
     for m in range(nv):
-        L.append(f"v_add_u32_dpp %[a{m}], %[ro], %[off0] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
+        L.append(f"v_xor_b32_dpp %[a{m}], %[ro], %[off0] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
         T = QT + 8 * m
         if two:
             L.append(f"v_add_u32 %[b{m}], %[a{m}], %[delta]")
             L.append(f"ds_read_b128 v[{T}:{T+3}], %[a{m}]")
             L.append(f"ds_read_b128 v[{T+4}:{T+7}], %[b{m}]")
             if pl == 5:
-                L.append(f"v_lshrrev_b32 %[e{m}], 3, %[a{m}]")
-                L.append(f"v_add_u32 %[e{m}], %[e{m}], %[ce]")
+                L.append(f"v_bfe_u32 %[e{m}], %[a{m}], 7, 16")
+                L.append(f"v_lshl_add_u32 %[e{m}], %[e{m}], 4, %[ce]")
                 L.append(f"ds_read_b32 v{QT + 32 + m}, %[e{m}]")
         elif pl == 2:
             L.append(f"ds_read_b128 v[{T}:{T+3}], %[a{m}]")

@@ -42,8 +42,11 @@
 //    in floats 16..31 (the two point pairs of an LDS phase read different copies);
 //  * pl_last = 5: the last <= 4 centroids are carried by the workgroups of tile G-2; the buffer of "tile" G-1
 //    then holds their (p+1) x 4 table E[r][j] = -fl32(C[(32 (G-1) + j)*p + r] / gamma) (16-B rows).
+//  * swz != 0: within each 64-B half-row the four 16-B pieces are permuted by the row: logical piece q sits at
+//    q ^ ((r >> 1) & 3) (the kernel's stored row ids carry the same two bits, k_screen_reorder).
 __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
-                                 float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits, int pl_last)
+                                 float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits, int pl_last,
+                                 int swz)
 {
     const size_t total = (size_t)G * (p + 1) * SCREEN_KT;
     double mx = 0.0;
@@ -52,6 +55,7 @@ __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int
         const size_t rest = t / SCREEN_KT;
         int r = (int)(rest % (p + 1));
         const int g = (int)(rest / (p + 1));
+        if (swz) kk ^= ((r >> 1) & 3) << 2; // physical -> logical position
         int k = g * SCREEN_KT + kk;
         if (g == G - 1 && pl_last == 5) {
             const size_t local = t - (size_t)g * (p + 1) * SCREEN_KT; // compact (p+1) x 4 table first, rest unused
@@ -103,32 +107,39 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
     }
 }
 
-// The screen's own copy of a fixed-stride shard: values as f32 and, per point, the entries PARTITIONED BY ROW
-// PARITY -- points with an even index list their even rows first, odd points their odd rows first.  The sum
-// of squares the screen estimates does not depend on the order; the order decides which LDS banks the
-// 4-lanes-per-point kernel below hits: the two points that read the same half-row in one 16-lane phase then
-// touch rows of opposite parity (= different 128-B halves of the 64 banks) for all but the few steps around
-// the middle of the column, where one of them has already switched class.
+// The screen's own copy of a fixed-stride shard, laid out the way the 4-lanes-per-point kernel consumes it.
+//  * values as f32;
+//  * per point, the entries PARTITIONED BY ROW PARITY -- points with an even index list their even rows first,
+//    odd points their odd rows first.  The sum of squares the screen estimates does not depend on the order;
+//    the order decides which LDS banks the kernel hits: the two points that read the same half-row in one
+//    16-lane phase then touch rows of opposite parity (= different 128-B halves of the 64 banks) for all but the
+//    few steps around the middle of the column, where one of them has already switched class;
+//  * STEP-MAJOR: a step is 16 consecutive points, a round 4 entries of each.  Element (step t, round r, lane L)
+//    sits at (t * NR + r) * 64 + L, where lane L = 4 * (point - 16 t) + l4 holds entry 4 r + l4 of its point:
+//    every load of a wave is one contiguous 256-B (values) / 128-B (16-bit row ids) piece.  Slots past the
+//    column (4 NR > fixed_s) and past the last point hold x = 0 on the all-zero row p;
+//  * row ids are stored as row * 8 ^ ((row >> 1) & 3): shifted left by 4 that is the row's LDS offset (128-B
+//    rows) with the tile's piece swizzle in bits 4..5 (k_prep_tiles_f32, swz), so the kernel's address
+//    arithmetic stays one XOR per broadcast entry.  Needs 8 (p + 1) <= 65536 for 16-bit ids (LDS: p <= 1279).
 template <typename IR>
 __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ ir, const double* __restrict__ x,
-                                                        long long n, int fixed_s, float* __restrict__ xfs,
+                                                        long long n, int fixed_s, int p, float* __restrict__ xfs,
                                                         IR* __restrict__ irs, double* __restrict__ xn1,
                                                         double* __restrict__ xn2)
 {
-    // 16 lanes per point, up to 4 rounds of 16 entries (fixed_s <= 64) held in registers; the partitioned
-    // column is staged in LDS so that both the reads and the writes are contiguous per point
+    // one step per workgroup pass: 16 lanes per point, up to 4 passes of 16 entries (fixed_s <= 64) held in
+    // registers; the partitioned columns are staged in LDS, then written out in lane order
     __shared__ float s_x[16][64];
     __shared__ IR s_r[16][64];
     const int sub = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
     const int lane = threadIdx.x & 63;
     const int gsh = lane & 48; // first lane of this 16-lane group
-    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
-    const long long rounds = (n + ng - 1) / ng;
+    const int NR = (fixed_s + 3) >> 2;
+    const long long nsteps = (n + 15) >> 4;
     const unsigned below = (1u << sub) - 1u;
-    for (long long t = 0; t < rounds; t++) {
-        const long long i = g0 + t * ng;
+    for (long long st = blockIdx.x; st < nsteps; st += gridDim.x) {
+        const long long i = st * 16 + grp;
         const bool live = i < n;
         const long long j0 = (live ? i : 0) * fixed_s;
         const unsigned want = (unsigned)(i & 1);
@@ -154,28 +165,25 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
-            if (live && e < fixed_s) {
-                const bool f = (mf[u] >> sub) & 1u;
-                const int pos = f ? cf + __builtin_popcount(mf[u] & below) : nfirst + cs + __builtin_popcount(mg[u] & below);
-                s_x[grp][pos] = (float)xv[u];
-                s_r[grp][pos] = rv[u];
-            }
+            const bool ok = live && e < fixed_s;
+            const bool f = (mf[u] >> sub) & 1u;
+            const int pos = ok ? (f ? cf + __builtin_popcount(mf[u] & below) : nfirst + cs + __builtin_popcount(mg[u] & below)) : e;
+            s_x[grp][pos] = ok ? (float)xv[u] : 0.f;   // slots past the column / past the last point: x = 0, row p
+            const unsigned row = ok ? (unsigned)rv[u] : (unsigned)p;
+            s_r[grp][pos] = (IR)((row << 3) ^ ((row >> 1) & 3u)); // LDS row offset / 16 with the tile swizzle folded in
             cf += __builtin_popcount(mf[u]);
             cs += __builtin_popcount(mg[u]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the group's 16 lanes belong to one wave
-        __builtin_amdgcn_wave_barrier();
-        if (live) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int e = u * 16 + sub;
-                if (e < fixed_s) {
-                    xfs[j0 + e] = s_x[grp][e];
-                    irs[j0 + e] = s_r[grp][e];
-                }
-            }
+        __syncthreads();
+        float* xo = xfs + (size_t)st * NR * 64;
+        IR* ro = irs + (size_t)st * NR * 64;
+        for (int idx = threadIdx.x; idx < NR * 64; idx += 256) {
+            const int r = idx >> 6, L = idx & 63;
+            const int e = 4 * r + (L & 3);
+            xo[idx] = s_x[L >> 2][e];
+            ro[idx] = s_r[L >> 2][e];
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         // the certificate's per-point norms (sum |x|, sum x^2; any order) ride on the same pass over x
         for (int off = 8; off > 0; off >>= 1) { na += __shfl_xor(na, off); nb += __shfl_xor(nb, off); }
         if (live && sub == 0 && xn1) { xn1[i] = na; xn2[i] = nb; }
@@ -734,7 +742,6 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  const double* __restrict__ hint, float hint_c,
                                                  unsigned* __restrict__ counters)
 {
-    constexpr int RS = SCREEN_KT * 4; // 128-B rows
     constexpr int PPS = 16;
     const int lane = threadIdx.x & 63;
     const int ps = lane >> 2, l4 = lane & 3;
@@ -745,8 +752,8 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     const int off0 = l4 * (PL == 1 ? 8 : 16) + (swp ? 64 : 0), off1 = l4 * 16 + (swp ? 0 : 64);
     const bool tile_full = (PL >= 4 ? k0 + SCREEN_KT <= K : k0 + 8 * PL <= K) && (PL != 5 || extra_k0 + 4 <= K);
     // PL = 5: the lane's extra centroid extra_k0 + l4 sits in a table of 16-B rows at extra_base:
-    // its address is (a >> 3) + ce for a = row * 128 + off0
-    const int ce = extra_base + l4 * 4 - (off0 >> 3);
+    // its address is (a >> 7) * 16 + ce for a = row * 128 + ...
+    const int ce = extra_base + l4 * 4;
     const int nchunks = (n + chunk_points - 1) / chunk_points;
     const int R = chunk_points / PPS;
     // chunk ids of this workgroup: (stream + ci * nstreams) * mul + add   (mul/add: XCD-local numbering)
@@ -776,14 +783,18 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             // PL = 5 with share > 1: the extra centroids are carried by all `share` tiles in turn -- this tile takes
             // them for every share-th step (uniform per step), so that all tiles cost the same per chunk
             const bool with_extra = PL == 5 && (share <= 1 || ((unsigned)(base >> 4) % (unsigned)share) == (unsigned)bm.tile);
-            const int ic = i < n ? i : n - 1;
-            const float* xp = xval + (size_t)ic * fixed_s + l4;
-            const IR* rp = ir + (size_t)ic * fixed_s + l4;
+            // step-major screen copy (k_screen_reorder): round r of this step is 64 consecutive elements
+            const float* xp = xval + (size_t)(base >> 4) * (NR * 64) + lane;
+            const IR* rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
+            // the hint is needed only after the first evaluation, but its load must not wait until then (a second
+            // exposed memory latency per step): issued first, pinned in a register before the rounds
+            double hraw = 0.0;
+            if (a_rounds < NR && hint != nullptr) hraw = hint[i < n ? i : n - 1];
             // scalars, not arrays: the compiler turns constant-indexed arrays into 16-wide register tuples and spills them
 #define SPKM_QUAD_LOAD(r)                                                              \
     float x##r = 0.f;                                                                  \
     int o##r = 0;                                                                      \
-    if constexpr (NR > r) { x##r = xp[r * 4]; o##r = (int)rp[r * 4]; } // past-the-column reads stay in the slack
+    if constexpr (NR > r) { x##r = xp[r * 64]; o##r = (int)rp[r * 64]; }
             SPKM_QUAD_LOAD(0) SPKM_QUAD_LOAD(1) SPKM_QUAD_LOAD(2) SPKM_QUAD_LOAD(3) SPKM_QUAD_LOAD(4) SPKM_QUAD_LOAD(5)
             SPKM_QUAD_LOAD(6) SPKM_QUAD_LOAD(7) SPKM_QUAD_LOAD(8) SPKM_QUAD_LOAD(9) SPKM_QUAD_LOAD(10)
             SPKM_QUAD_LOAD(11) SPKM_QUAD_LOAD(12) SPKM_QUAD_LOAD(13) SPKM_QUAD_LOAD(14) SPKM_QUAD_LOAD(15)
@@ -796,7 +807,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
 #define SPKM_QUAD_ROUND_G(r, COND)                                                                          \
     if constexpr (NR > r) if (COND(r)) {                                                                    \
         const int xi = __builtin_bit_cast(int, x##r);                                                       \
-        const int ro = (int)__umul24((unsigned)o##r, (unsigned)RS);                                         \
+        const int ro = o##r << 4; /* stored: row * 8 ^ swizzle -> row * 128 | swizzle * 16 */              \
         if (PL == 5 && !with_extra) {                                                                       \
             if (r < NR - 1 || nvl == 4) quad_round<4, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);    \
             else if (nvl == 3) quad_round<3, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);             \
@@ -812,6 +823,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     SPKM_QUAD_ROUND_G(4, COND) SPKM_QUAD_ROUND_G(5, COND) SPKM_QUAD_ROUND_G(6, COND) SPKM_QUAD_ROUND_G(7, COND)   \
     SPKM_QUAD_ROUND_G(8, COND) SPKM_QUAD_ROUND_G(9, COND) SPKM_QUAD_ROUND_G(10, COND) SPKM_QUAD_ROUND_G(11, COND) \
     SPKM_QUAD_ROUND_G(12, COND) SPKM_QUAD_ROUND_G(13, COND) SPKM_QUAD_ROUND_G(14, COND) SPKM_QUAD_ROUND_G(15, COND)
+            asm volatile("" : "+v"(hraw));
             SPKM_QUAD_ROUNDS(SPKM_GUARD_A)
             // lane's centroids.  PL = 4: first read -> k0 + off0/4 + 0..3, second read -> k0 + off1/4 + 0..3;
             // PL < 4: k0 + 2 PL l4 + 0 .. 2 PL - 1 (either copy)
@@ -872,7 +884,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             // remaining rounds are run for all centroids.  The hint steers the work, never a result.
             int a_eff = a_rounds;
             if (a_rounds < NR && hint != nullptr) {
-                const float hv = (float)hint[i < n ? i : n - 1];
+                const float hv = (float)hraw;
                 const bool fine = !(i < n) || m2 >= hint_c * hv * hv; // false for NaN
                 if (!__all(fine)) {
                     SPKM_QUAD_ROUNDS(SPKM_GUARD_B)
@@ -890,20 +902,29 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             if (a_eff < NR) {
                 const int kwin = quad_min_i32((l4 == first && seg != 0u) ? klo : 0x7fffffff);
                 const bool is_extra = PL == 5 && kwin >= extra_k0;
-                const int cbase = is_extra ? extra_base + (kwin - extra_k0) * 4 : (kwin - k0) * 4;
-                const int rshift = is_extra ? 4 : 7; // 16-B rows of the extra table, 128-B rows of the tile
+                // tile: float c = kwin - k0 of the row sits in 16-B piece (c >> 2) ^ swizzle(row), and the stored row id
+                // (o << 4 = row * 128 | swizzle * 16) carries the swizzle: address = ((o << 4) ^ piece * 16) + (c & 3) * 4.
+                // The 16 points of a step mostly share their leader: without the swizzle all 64 lanes of such a read
+                // would hit the two banks (row parity) of one column.  Extra table (rare leader): 16-B rows, no swizzle.
+                const int cpiece = ((kwin - k0) >> 2) << 4, celem = ((kwin - k0) & 3) << 2;
+                const int ebase = extra_base + (kwin - extra_k0) * 4;
                 float accb = 0.f;
-#define SPKM_QUAD_FINISH(r)                                                                                 \
+#define SPKM_QUAD_FINISH(r, EXTRA)                                                                          \
     if constexpr (NR > r) if (r >= a_rounds) {                                                              \
         const bool okr = (r < NR - 1) || l4 < nvl;                                                          \
-        const float cv = *reinterpret_cast<const float*>(smem + (o##r << rshift) + cbase);                  \
+        const int t4 = o##r << 4;                                                                           \
+        const int adr = (EXTRA && is_extra) ? ((t4 >> 7) << 4) + ebase : (t4 ^ cpiece) + celem;             \
+        const float cv = *reinterpret_cast<const float*>(smem + adr);                                       \
         const float tv = okr ? cv + x##r : 0.f;                                                             \
         accb = __builtin_fmaf(tv, tv, accb);                                                                \
     }
-                SPKM_QUAD_FINISH(0) SPKM_QUAD_FINISH(1) SPKM_QUAD_FINISH(2) SPKM_QUAD_FINISH(3) SPKM_QUAD_FINISH(4)
-                SPKM_QUAD_FINISH(5) SPKM_QUAD_FINISH(6) SPKM_QUAD_FINISH(7) SPKM_QUAD_FINISH(8) SPKM_QUAD_FINISH(9)
-                SPKM_QUAD_FINISH(10) SPKM_QUAD_FINISH(11) SPKM_QUAD_FINISH(12) SPKM_QUAD_FINISH(13)
-                SPKM_QUAD_FINISH(14) SPKM_QUAD_FINISH(15)
+#define SPKM_QUAD_FINISH_ALL(EXTRA)                                                                         \
+    SPKM_QUAD_FINISH(0, EXTRA) SPKM_QUAD_FINISH(1, EXTRA) SPKM_QUAD_FINISH(2, EXTRA) SPKM_QUAD_FINISH(3, EXTRA)     \
+    SPKM_QUAD_FINISH(4, EXTRA) SPKM_QUAD_FINISH(5, EXTRA) SPKM_QUAD_FINISH(6, EXTRA) SPKM_QUAD_FINISH(7, EXTRA)     \
+    SPKM_QUAD_FINISH(8, EXTRA) SPKM_QUAD_FINISH(9, EXTRA) SPKM_QUAD_FINISH(10, EXTRA) SPKM_QUAD_FINISH(11, EXTRA)   \
+    SPKM_QUAD_FINISH(12, EXTRA) SPKM_QUAD_FINISH(13, EXTRA) SPKM_QUAD_FINISH(14, EXTRA) SPKM_QUAD_FINISH(15, EXTRA)
+                if (PL == 5 && __any(is_extra)) { SPKM_QUAD_FINISH_ALL(true) } else { SPKM_QUAD_FINISH_ALL(false) }
+#undef SPKM_QUAD_FINISH_ALL
 #undef SPKM_QUAD_FINISH
 #undef SPKM_QUAD_ROUNDS
 #undef SPKM_QUAD_ROUND_G
