@@ -930,7 +930,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (const char* ev = getenv("SPKM_CHUNK")) chunk = std::max<long long>(sweep, (atoll(ev) / sweep) * sweep); // tuning aid
     {
         const size_t lds = (size_t)(p + 1) * (SCREEN_KT * 4 + (pl_last == 5 ? 16 : 0)) + 16;
-        const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4) : (const void*)k_screen_tile<IR>;
+        const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0) : (const void*)k_screen_tile<IR>;
         HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(timing_begin(ctx));
         const IR* a_ir = quad ? (const IR*)s->irs : (const IR*)s->ir;
@@ -942,8 +942,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float* a_m2 = (float*)ctx->scr_m2.p;
         int* a_k = (int*)ctx->scr_k.p;
         int a_extra = G - 1; // buffer / centroid block of the carried remainder (pl 5)
-        int a_rounds = (quad && prune_a > 0) ? std::min(q_rounds, prune_a) : q_rounds;
-        if (const char* ev = getenv("SPKM_SCREEN_A")) a_rounds = std::max(1, std::min(q_rounds, atoi(ev)));
+        // two-phase forms: the split is compiled into the kernel (quad_split, screen.hip)
+        const bool two = quad && prune_a > 0 && quad_split(q_rounds) < q_rounds;
+        const int a_rounds = two ? quad_split(q_rounds) : q_rounds;
         ctx->last_rounds_all = quad ? a_rounds : 0;
         ctx->last_rounds = quad ? q_rounds : 0;
         int a_share = share_extra ? Gs : 1;
@@ -951,7 +952,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float a_hc = 4.0f; // the other centroids of a tile must be > 2x the previous min-distance away (squared: 4x)
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
-        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra, &a_rounds, &a_share,
+        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra, &a_share,
                         &a_hint, &a_hc, &a_cnt};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
@@ -1034,7 +1035,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         const double listed = (double)sm->h_nlist[0], ambig = (double)sm->h_nlist[1], nn = (double)s->n;
         if (listed > 0.05 * nn) sm->exact_cooldown = 8;
         const int nr = (s->fixed_s + 3) / 4;
-        const int a_prune = std::max(2, (3 * nr + 9) / 10); // ~30 % of the rounds (s = 51: 4 of 13): a runner-up 2x away clears it
+        const int a_prune = quad_split(nr); // ~30 % of the rounds (s = 51: 4 of 13): a runner-up 2x away clears it
         if (sm->hint_pending) {
             // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only
             // while the hints do not mislead (stale buffer: many listed points)
@@ -1061,8 +1062,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         if (prune_a == 0 && !getenv("SPKM_NO_PRUNE") && !getenv("SPKM_NO_HINT") && sm->hint_ptr == d_mind &&
             sm->hint_cooldown == 0 && screen_use_quad(s)) {
             const int nr = (s->fixed_s + 3) / 4;
-            int a_h = std::max(2, (3 * nr + 9) / 10);
-            if (const char* ev = getenv("SPKM_HINT_A")) a_h = std::max(1, atoi(ev));
+            const int a_h = quad_split(nr);
             if (a_h < nr) { hint = d_mind; prune_a = a_h; }
         }
         rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, hint)

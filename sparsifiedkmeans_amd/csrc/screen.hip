@@ -733,12 +733,12 @@ __device__ __forceinline__ float quad_min_f32(float v)
     return v;
 }
 
-template <int NR, typename IR, int PL>
+template <int NR, typename IR, int PL, int A>
 __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
                                                  int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
-                                                 int extra_k0, int a_rounds, int share,
+                                                 int extra_k0, int share,
                                                  const double* __restrict__ hint, float hint_c,
                                                  unsigned* __restrict__ counters)
 {
@@ -789,7 +789,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             // the hint is needed only after the first evaluation, but its load must not wait until then (a second
             // exposed memory latency per step): issued first, pinned in a register before the rounds
             double hraw = 0.0;
-            if (a_rounds < NR && hint != nullptr) hraw = hint[i < n ? i : n - 1];
+            if (A < NR && hint != nullptr) hraw = hint[i < n ? i : n - 1];
             // scalars, not arrays: the compiler turns constant-indexed arrays into 16-wide register tuples and spills them
 #define SPKM_QUAD_LOAD(r)                                                              \
     float x##r = 0.f;                                                                  \
@@ -802,10 +802,10 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; // two f32 sums each (bit pattern 0 = (0.f, 0.f))
             float acc4 = 0.f;                                       // PL = 5: the lane's extra centroid
             // the last round broadcasts only the nvl = fixed_s - 4 (NR - 1) entries the column still has
-#define SPKM_GUARD_A(r) ((r) < a_rounds)
-#define SPKM_GUARD_B(r) ((r) >= a_rounds)
+#define SPKM_GUARD_A(r) ((r) < A)
+#define SPKM_GUARD_B(r) ((r) >= A)
 #define SPKM_QUAD_ROUND_G(r, COND)                                                                          \
-    if constexpr (NR > r) if (COND(r)) {                                                                    \
+    if constexpr (NR > r && COND(r)) {                                                                      \
         const int xi = __builtin_bit_cast(int, x##r);                                                       \
         const int ro = o##r << 4; /* stored: row * 8 ^ swizzle -> row * 128 | swizzle * 16 */              \
         if (PL == 5 && !with_extra) {                                                                       \
@@ -882,8 +882,8 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             // point of this step, all non-leading centroids of the tile are already (by their partial sums) more
             // than sqrt(hint_c) times that distance away, the step is finished for the leaders only; otherwise the
             // remaining rounds are run for all centroids.  The hint steers the work, never a result.
-            int a_eff = a_rounds;
-            if (a_rounds < NR && hint != nullptr) {
+            int a_eff = A;
+            if (A < NR && hint != nullptr) {
                 const float hv = (float)hraw;
                 const bool fine = !(i < n) || m2 >= hint_c * hv * hv; // false for NaN
                 if (!__all(fine)) {
@@ -893,7 +893,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                 } else
                     npruned++;
             }
-            // Phase B (a_rounds < NR): the sums above cover only the first 4 a_rounds entries of each column.  They are
+            // Phase B (A < NR): the sums above cover only the first 4 A entries of each column.  They are
             // LOWER bounds of the full sums (every term is >= 0 and f32 addition is monotone), which is all the
             // certificate needs for the centroids that lose; only the tile's leader by partial sum is finished:
             // each lane adds ITS OWN remaining entries (no broadcast) for that one centroid, the quad adds up.
@@ -910,7 +910,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                 const int ebase = extra_base + (kwin - extra_k0) * 4;
                 float accb = 0.f;
 #define SPKM_QUAD_FINISH(r, EXTRA)                                                                          \
-    if constexpr (NR > r) if (r >= a_rounds) {                                                              \
+    if constexpr (NR > r && r >= A) {                                                                       \
         const bool okr = (r < NR - 1) || l4 < nvl;                                                          \
         const int t4 = o##r << 4;                                                                           \
         const int adr = (EXTRA && is_extra) ? ((t4 >> 7) << 4) + ebase : (t4 ^ cpiece) + celem;             \
@@ -943,11 +943,17 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     if (counters != nullptr && lane == 0 && npruned) atomicAdd(counters + 2, npruned);
 }
 
-template <int NR, typename IR>
+// TWO: the two-phase forms -- the first A = quad_split(NR) rounds for all centroids, the rest only for each
+// tile's leader (or, hinted, for all again when a step's points do not clear their hints).  The split is a
+// compile-time constant: with a run-time split every round sits behind its own branch and the finish's LDS reads
+// are waited for one by one.
+__host__ __device__ constexpr int quad_split(int nr) { return nr >= 3 ? ((3 * nr + 9) / 10 > 2 ? (3 * nr + 9) / 10 : 2) : nr; }
+
+template <int NR, typename IR, bool TWO>
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
-    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int a_rounds, int share,
+    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int share,
     const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -974,17 +980,19 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
-    if (pl == 4) screen_quad_body<NR, IR, 4>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
-    else if (pl == 5) screen_quad_body<NR, IR, 5>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
-    else if (pl == 2) screen_quad_body<NR, IR, 2>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
-    else screen_quad_body<NR, IR, 1>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, a_rounds, share, hint, hint_c, counters);
+    constexpr int A = TWO ? quad_split(NR) : NR;
+    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
+    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
+    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
+    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
-template <typename IR> static const void* screen_quad_kernel(int rounds)
+template <typename IR> static const void* screen_quad_kernel(int rounds, bool two)
 {
     switch (rounds) {
-#define SPKM_QUAD_CASE(N) case N: return (const void*)k_screen_quad<N, IR>;
+#define SPKM_QUAD_CASE(N)                                                                                   \
+    case N: return two && quad_split(N) < N ? (const void*)k_screen_quad<N, IR, (quad_split(N) < N)> : (const void*)k_screen_quad<N, IR, false>;
         SPKM_QUAD_CASE(1) SPKM_QUAD_CASE(2) SPKM_QUAD_CASE(3) SPKM_QUAD_CASE(4) SPKM_QUAD_CASE(5) SPKM_QUAD_CASE(6)
         SPKM_QUAD_CASE(7) SPKM_QUAD_CASE(8) SPKM_QUAD_CASE(9) SPKM_QUAD_CASE(10) SPKM_QUAD_CASE(11) SPKM_QUAD_CASE(12)
         SPKM_QUAD_CASE(13) SPKM_QUAD_CASE(14) SPKM_QUAD_CASE(15) SPKM_QUAD_CASE(16)
