@@ -401,10 +401,10 @@ static int build_blockmap(spkm_ctx* ctx, int G)
 // c % NX) in the same order, so a chunk is fetched from HBM once and re-read from that XCD's L2.
 //   entry: tile, stream = index among the tile's workgroups on this XCD, nstreams = their number,
 //          pad = NX | xcd << 8 | pairs-per-lane << 16
-static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bool share_extra = false)
+static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
 {
     const int NB = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    const int key = G * 64 + pl_last * 8 + 1000003 * rounds + (getenv("SPKM_QUAD_W") ? 7 : 0) + (share_extra ? 3 : 0);
+    const int key = G * 64 + pl_last * 8 + 1000003 * rounds + (getenv("SPKM_QUAD_W") ? 7 : 0);
     if (ctx->bmapq_key == key && ctx->bmapq_blocks == NB) return SPKM_OK;
     const int NX = (NB % 8 == 0) ? 8 : 1;
     const int per = NB / NX;
@@ -422,8 +422,7 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bo
     if (const char* ev = getenv("SPKM_QUAD_W")) w[G - 1] = cost(4) * atof(ev); // tuning aid
     // apportionment of the XCD's workgroups, at least one per tile, minimising the makespan
     std::vector<int> cnt(G, 1);
-    if (share_extra) cnt.assign(G, per / G); // all tiles carry the remainder in turn: equal cost, equal counts, lock-step
-    for (int left = share_extra ? 0 : per - G; left > 0; left--) {
+    for (int left = per - G; left > 0; left--) {
         int best = 0;
         double worst = -1;
         for (int g = 0; g < G; g++)
@@ -439,7 +438,7 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bo
                 e.tile = g;
                 e.stream = j;
                 e.nstreams = cnt[g];
-                e.pad = NX | (x << 8) | ((g == G - 1 || share_extra ? pl_last : 4) << 16);
+                e.pad = NX | (x << 8) | ((g == G - 1 ? pl_last : 4) << 16);
             }
     }
     int rc = ensure(ctx, ctx->bmapq, NB * sizeof(spkm_blockmap));
@@ -898,8 +897,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (quad && getenv("SPKM_QUAD_EQUAL")) pl_last = 4; // A/B aid: every tile full width, equal workgroup counts (lock-step)
     const int Gs = pl_last == 5 ? G - 1 : G;
     const int q_rounds = (s->fixed_s + 3) / 4;
-    const bool share_extra = quad && pl_last == 5 && getenv("SPKM_SHARE_EXTRA") != nullptr;
-    if (quad) rc = build_blockmap_quad(ctx, Gs, pl_last, q_rounds, share_extra);
+    if (quad) rc = build_blockmap_quad(ctx, Gs, pl_last, q_rounds);
     else rc = build_blockmap(ctx, G);
     if (rc) return rc;
     const size_t tile_floats = (size_t)G * (p + 1) * SCREEN_KT;
@@ -947,12 +945,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const int a_rounds = two ? quad_split(q_rounds) : q_rounds;
         ctx->last_rounds_all = quad ? a_rounds : 0;
         ctx->last_rounds = quad ? q_rounds : 0;
-        int a_share = share_extra ? Gs : 1;
         const double* a_hint = (quad && a_rounds < q_rounds) ? hint : nullptr; // nullptr: every step is finished for the leaders only
         float a_hc = 4.0f; // the other centroids of a tile must be > 2x the previous min-distance away (squared: 4x)
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
-        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra, &a_share,
+        void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
                         &a_hint, &a_hc, &a_cnt};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }

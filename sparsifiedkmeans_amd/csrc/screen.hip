@@ -738,7 +738,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
-                                                 int extra_k0, int share,
+                                                 int extra_k0,
                                                  const double* __restrict__ hint, float hint_c,
                                                  unsigned* __restrict__ counters)
 {
@@ -780,9 +780,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
         const int base = point_of(t);
         if (base < n) {
             const int i = base + ps;
-            // PL = 5 with share > 1: the extra centroids are carried by all `share` tiles in turn -- this tile takes
-            // them for every share-th step (uniform per step), so that all tiles cost the same per chunk
-            const bool with_extra = PL == 5 && (share <= 1 || ((unsigned)(base >> 4) % (unsigned)share) == (unsigned)bm.tile);
+            constexpr bool with_extra = PL == 5;
             // step-major screen copy (k_screen_reorder): round r of this step is 64 consecutive elements
             const float* xp = xval + (size_t)(base >> 4) * (NR * 64) + lane;
             const IR* rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
@@ -953,7 +951,7 @@ template <int NR, typename IR, bool TWO>
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
-    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile, int share,
+    float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile,
     const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -981,10 +979,10 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
     constexpr int A = TWO ? quad_split(NR) : NR;
-    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
-    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
-    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
-    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, share, hint, hint_c, counters);
+    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
+    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
+    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
+    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
