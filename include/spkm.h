@@ -150,8 +150,8 @@ int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const in
  * variable SPKM_NO_SCREEN=1 forces the all-exact kernels.
  * Hints: when a shard is called again with the SAME d_mind pointer as in its previous call, the buffer's
  * contents on entry (that call's min-distances, if the caller left them alone) steer the screen: a group of
- * 16 points stops after ~30 % of its entries once every other centroid of a tile is already more than twice
- * the hinted distance away.  Hints only choose how much work is done -- every shortcut keeps a certified
+ * 16 points stops after a quarter of its entries once the partial squared distance of every other centroid of a
+ * tile already exceeds twice the hinted distance squared.  Hints only choose how much work is done -- every shortcut keeps a certified
  * lower bound, a stale or overwritten buffer costs time (and switches the hints off), never correctness.
  * SPKM_NO_HINT=1 disables them. */
 int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers,
@@ -163,12 +163,12 @@ int spkm_last_path_info(spkm_ctx *ctx, int64_t info[2]);
 /* After a screen call on the 4-lanes-per-point kernel: info[1] = rounds (of 4 stored entries) per column,
  * info[0] = rounds evaluated for ALL centroids.  info[0] < info[1]: the two-phase screen was used -- partial
  * sums (lower bounds) for every centroid, the remaining entries only for each tile's leader; the library
- * switches it on by itself when the previous call found almost no point with a runner-up within 2x of the
+ * switches it on by itself when the previous call found almost no point with a runner-up within 2.25x of the
  * winner, and off again when it certifies poorly.  SPKM_NO_PRUNE=1 disables it; outputs never change.
  * Both 0 after any other path. */
 int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
 /* info[0] = form of the last screen call: 0 plain, 1 two-phase, 2 hinted two-phase (-1: no screen);
- * info[1..3] = that call's counters: points listed for exact evaluation, points with a runner-up within 2x
+ * info[1..3] = that call's counters: points listed for exact evaluation, points with a runner-up within 2.25x
  * (a bound: over-counts in the two-phase forms), (16-point step, centroid tile) pairs finished early by the
  * hinted form.  Blocks on the stream. */
 int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[4]);

@@ -946,7 +946,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         ctx->last_rounds_all = quad ? a_rounds : 0;
         ctx->last_rounds = quad ? q_rounds : 0;
         const double* a_hint = (quad && a_rounds < q_rounds) ? hint : nullptr; // nullptr: every step is finished for the leaders only
-        float a_hc = 4.0f; // the other centroids of a tile must be > 2x the previous min-distance away (squared: 4x)
+        float a_hc = 2.0f; // the other centroids' partial sums must exceed 2x the previous min-distance squared
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
@@ -1024,7 +1024,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     // asynchronously and looked at one call later (no host sync on the hot path):
     //  * more than 5 % of the points on the exact list: the next 8 calls use the all-exact kernels;
     //  * two-phase screen (partial sums for all centroids, only each tile's leader finished -- screen.hip):
-    //    switched on when a plain screen found < 0.2 % of the points with a runner-up within 2x of the winner
+    //    switched on when a plain screen found < 0.2 % of the points with a runner-up within 2.25x of the winner
     //    (converged iterations on separated data), switched off for 16 calls when it listed > 0.5 %.
     if (sm->nlist_pending && hipEventQuery(sm->ev_nlist) == hipSuccess) {
         sm->nlist_pending = false;
@@ -1032,7 +1032,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         const double listed = (double)sm->h_nlist[0], ambig = (double)sm->h_nlist[1], nn = (double)s->n;
         if (listed > 0.05 * nn) sm->exact_cooldown = 8;
         const int nr = (s->fixed_s + 3) / 4;
-        const int a_prune = quad_split(nr); // ~30 % of the rounds (s = 51: 4 of 13): a runner-up 2x away clears it
+        const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
         if (sm->hint_pending) {
             // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only
             // while the hints do not mislead (stale buffer: many listed points)

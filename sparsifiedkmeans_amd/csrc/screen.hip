@@ -453,9 +453,10 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
             const unsigned at = atomicAdd(nlist, 1u);
             list[at] = (int)i;
         }
-        // nlist[1]: points whose runner-up is within 2x of the winner -- the ones a partial-sum lower bound
+        // nlist[1]: points whose runner-up is within 2.25x of the winner -- the ones a partial-sum lower bound (a
+        // quarter of the rounds: 5x in the squares leaves a margin) 
         // could not separate; the host decides from this count whether the next call may use the two-phase screen
-        if (!(r2 >= 2.0 * r1)) nambig++;
+        if (!(r2 >= 2.25 * r1)) nambig++;
     }
     for (int off = 32; off > 0; off >>= 1) nambig += __shfl_down(nambig, off);
     if ((threadIdx.x & 63) == 0 && nambig) atomicAdd(nlist + 1, nambig);
@@ -945,7 +946,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
 // tile's leader (or, hinted, for all again when a step's points do not clear their hints).  The split is a
 // compile-time constant: with a run-time split every round sits behind its own branch and the finish's LDS reads
 // are waited for one by one.
-__host__ __device__ constexpr int quad_split(int nr) { return nr >= 3 ? ((3 * nr + 9) / 10 > 2 ? (3 * nr + 9) / 10 : 2) : nr; }
+__host__ __device__ constexpr int quad_split(int nr) { return nr >= 3 ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : nr; }
 
 template <int NR, typename IR, bool TWO>
 __global__ __launch_bounds__(1024) void k_screen_quad(

@@ -252,7 +252,7 @@ def test_poorly_certifying_screen_backs_off_to_exact_kernels(gpu_ctx, oracle):
 
 def test_two_phase_screen_switches_itself_on_and_off(gpu_ctx, oracle):
     """Separated clusters with one centre each: after a plain screen has seen that no point has a runner-up within
-    2x of the winner, the next call evaluates only a third of the rounds for all centroids and finishes the tile
+    2.25x of the winner, the next call evaluates only a quarter of the rounds for all centroids and finishes the tile
     leaders (spkm_last_screen_rounds) -- with the oracle's outputs.  Ambiguous data (random centres) keeps or
     brings back the plain screen."""
     from sparsifiedkmeans_amd import synth
@@ -288,7 +288,7 @@ def test_two_phase_screen_switches_itself_on_and_off(gpu_ctx, oracle):
 
 
 def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle):
-    """Mid-run Lloyd state: some clusters are split between two nearby centres (runner-up within 2x: the
+    """Mid-run Lloyd state: some clusters are split between two nearby centres (runner-up within 2.25x: the
     unconditional two-phase form stays off) and some have no centre of their own.  From the second call on the
     previous min-distances, still in the caller's buffer, let 16-point steps finish early (form 2, counter of
     early-finished steps > 0); outputs equal the oracle's bit for bit on every call, also after the buffer has
