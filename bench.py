@@ -205,6 +205,9 @@ def main():
                    # (16-point step, centroid tile) pairs it finished early
                    "screen_form_last_iter": {0: "plain", 1: "two-phase", 2: "hinted"}.get(mode[0], "none"),
                    "early_finished_steps": mode[3] if mode[0] == 2 else None,
+                   # 16-point steps the screen skipped altogether in the last iteration: the bounds carried from the
+                   # previous call (triangle inequality under the centroids' drift) proved their assignments unchanged
+                   "skipped_steps_last_iter": mode[4],
                    "steps_per_centroid_tile": (n_local + 15) // 16},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

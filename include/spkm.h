@@ -153,7 +153,14 @@ int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const in
  * 16 points stops after a quarter of its entries once the partial squared distance of every other centroid of a
  * tile already exceeds twice the hinted distance squared.  Hints only choose how much work is done -- every shortcut keeps a certified
  * lower bound, a stale or overwritten buffer costs time (and switches the hints off), never correctness.
- * SPKM_NO_HINT=1 disables them. */
+ * SPKM_NO_HINT=1 disables them.
+ * Carried bounds: the library keeps, per shard, its own copy of the previous screen call's assignment, an
+ * upper bound of every point's distance to its centroid and a lower bound of its distance to all others, plus
+ * that call's centroids.  On the next call the centroids' movement (triangle inequality on the masked distances)
+ * proves for most points of a converging run that their centroid is unchanged; 16-point steps of such points
+ * skip the screen.  The exact pass still recomputes every point's distance to its centroid and all sums, so the
+ * outputs are the same bit for bit.  Nothing here depends on buffers the caller owns.  SPKM_NO_BOUNDS=1 disables
+ * the skipping; spkm_shard_reset_policy forgets the bounds. */
 int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers,
                                double gamma, int32_t *d_assign, double *d_mind, double *d_stats,
                                uint64_t *d_nk_u64, double *d_reduce);
@@ -168,10 +175,11 @@ int spkm_last_path_info(spkm_ctx *ctx, int64_t info[2]);
  * Both 0 after any other path. */
 int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
 /* info[0] = form of the last screen call: 0 plain, 1 two-phase, 2 hinted two-phase (-1: no screen);
- * info[1..3] = that call's counters: points listed for exact evaluation, points with a runner-up within 2.25x
+ * info[1..4] = that call's counters: points listed for exact evaluation, points with a runner-up within 2.25x
  * (a bound: over-counts in the two-phase forms), (16-point step, centroid tile) pairs finished early by the
- * hinted form.  Blocks on the stream. */
-int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[4]);
+ * hinted form, 16-point steps skipped altogether on the bounds carried from the previous call (see
+ * spkm_assign_accumulate_dev).  Blocks on the stream. */
+int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[5]);
 
 /* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
  * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;

@@ -80,6 +80,14 @@ struct spkm_shard {
     const double* hint_ptr = nullptr;
     bool hint_pending = false;
     int hint_cooldown = 0;
+    // bounds carried between screen calls (screen.hip, k_center_drift): ub | lb | assignment | drift table, the
+    // centroids of the call that produced them, and whether they describe this shard's previous call
+    float* hb = nullptr;
+    double* hb_centers = nullptr;
+    size_t hb_centers_len = 0;
+    long long hb_npad = 0;
+    int hb_K = 0;
+    bool hb_valid = false;
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -308,6 +316,8 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xf) (void)hipFree(s->xf);
     if (s->xfs) (void)hipFree(s->xfs);
     if (s->irs) (void)hipFree(s->irs);
+    if (s->hb) (void)hipFree(s->hb);
+    if (s->hb_centers) (void)hipFree(s->hb_centers);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
     if (s->ev_nlist) (void)hipEventDestroy(s->ev_nlist);
     if (s->owned) {
@@ -327,6 +337,7 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->prune_pending_a = 0;
     s->hint_ptr = nullptr;
     s->hint_cooldown = 0;
+    s->hb_valid = false;
     return SPKM_OK;
 }
 
@@ -912,7 +923,35 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 12, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 16, ctx->stream));
+    // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
+    // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
+    const long long npad = (n + 63) / 64 * 64;
+    bool skipping = false;
+    if (quad) {
+        if (!sm->hb || sm->hb_npad != npad) {
+            if (sm->hb) (void)hipFree(sm->hb);
+            sm->hb = nullptr;
+            sm->hb_valid = false;
+            HIP_TRY(hipMalloc((void**)&sm->hb, ((size_t)3 * npad + 65536 + 2) * 4));
+            sm->hb_npad = npad;
+        }
+        if (sm->hb_centers_len < pk) {
+            if (sm->hb_centers) (void)hipFree(sm->hb_centers);
+            sm->hb_centers = nullptr;
+            sm->hb_valid = false;
+            HIP_TRY(hipMalloc((void**)&sm->hb_centers, pk * 8));
+            sm->hb_centers_len = pk;
+        }
+        if (sm->hb_valid && sm->hb_K == K && !getenv("SPKM_NO_BOUNDS")) {
+            HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
+                               d_centers, K, p, gamma, sm->hb + 3 * npad);
+            skipping = true;
+        }
+        sm->hb_valid = false; // until this call has gone through
+    } else
+        sm->hb_valid = false;
     HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
@@ -949,8 +988,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float a_hc = 2.0f; // the other centroids' partial sums must exceed 2x the previous min-distance squared
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
+        const float* a_bnd = skipping ? sm->hb : nullptr;
+        long long a_npad = npad;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
-                        &a_hint, &a_hc, &a_cnt};
+                        &a_hint, &a_hc, &a_cnt, &a_bnd, &a_npad};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -960,10 +1001,13 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), 0, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
-                       (int*)ctx->list.p, (unsigned int*)ctx->nlist.p);
+                       (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad, K,
+                       skipping ? 1 : 0);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign);
+    if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls)
+        HIP_TRY(hipMemcpyAsync(sm->hb + 2 * npad, d_assign, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     // 4. counting sort by cluster
     hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
                        ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p);
@@ -999,7 +1043,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;
     hipLaunchKernelGGL(k2, dim3(ab), dim3(threads), lds2, ctx->stream, (const IR*)s->ir, (const double*)s->x,
                        (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
-                       (const int*)ctx->nitems.p, d_centers, gamma, p, s->fixed_s, pts, d_mind, sums, counts,
+                       (const int*)ctx->nitems.p, d_centers, gamma, p, s->fixed_s, pts, d_mind,
+                       quad ? sm->hb : (float*)nullptr, sums, counts,
                        (double*)ctx->blk_obj.p, (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p);
     hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
                        (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, ab, (double*)ctx->stats.p);
@@ -1007,6 +1052,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (const unsigned long long*)ctx->nk.p, K, nk_f);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(obj2, ctx->stats.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
+        HIP_TRY(hipMemcpyAsync(sm->hb_centers, d_centers, pk * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        sm->hb_K = K;
+        sm->hb_valid = true;
+    }
     ctx->last_path = 1;
     return SPKM_OK;
 }
@@ -1036,8 +1086,9 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         if (sm->hint_pending) {
             // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only
             // while the hints do not mislead (stale buffer: many listed points)
-            const double steps = (nn / 16.0) * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
-            if (listed > 0.005 * nn || (double)sm->h_nlist[2] < 0.05 * steps) sm->hint_cooldown = 16;
+            // (steps skipped on the carried bounds never got as far as their hints)
+            const double steps = std::max(0.0, nn / 16.0 - (double)sm->h_nlist[3]) * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
+            if (listed > 0.005 * nn || ((double)sm->h_nlist[2] < 0.05 * steps && steps > 0.01 * nn / 16.0)) sm->hint_cooldown = 16;
             // runner-up bounds of early-finished steps are partial sums, so `ambig` over-counts: still small
             // means the unconditional form (no hint loads, no second evaluation) is safe to try
             else if (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) sm->prune_next_a = a_prune;
@@ -1072,7 +1123,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
         }
         if (!sm->nlist_pending) {
-            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
             sm->nlist_pending = true;
             sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
@@ -1083,6 +1134,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         return SPKM_OK;
     }
     ctx->last_path = 0;
+    sm->hb_valid = false; // the carried bounds describe the previous SCREEN call only
     rc = spkm_assign_dev(ctx, s, K64, d_centers, gamma, d_assign, d_mind, d_stats, d_nk_u64);
     if (rc) return rc;
     return spkm_accumulate_dev(ctx, s, K64, d_assign, d_reduce);
@@ -1097,18 +1149,18 @@ extern "C" int spkm_last_screen_rounds(spkm_ctx* ctx, int64_t info[2])
 }
 
 // Form and counters of the last screen call.  Blocks on the stream (diagnostics, not the hot path).
-extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[4])
+extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[5])
 {
     if (!ctx || !info) return SPKM_ERR_NULL_ARG;
     info[0] = -1;
-    info[1] = info[2] = info[3] = 0;
+    info[1] = info[2] = info[3] = info[4] = 0;
     if (ctx->last_path == 1 && ctx->nlist.p) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        unsigned v[3] = {0, 0, 0};
-        HIP_TRY(hipMemcpy(v, ctx->nlist.p, 12, hipMemcpyDeviceToHost));
+        unsigned v[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(v, ctx->nlist.p, 16, hipMemcpyDeviceToHost));
         info[0] = ctx->last_mode;
-        for (int j = 0; j < 3; j++) info[1 + j] = v[j];
+        for (int j = 0; j < 4; j++) info[1 + j] = v[j];
     }
     return SPKM_OK;
 }

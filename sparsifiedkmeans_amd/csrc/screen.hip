@@ -411,6 +411,48 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
     }
 }
 
+// Bounds carried from one call to the next (exact acceleration in the manner of Hamerly's k-means, adapted to the
+// masked distances): after a screen call every point has
+//     ub[i] >= D_a(i)        its TRUE distance to its assigned centroid (from the exact phase-2 value), and
+//     lb[i] <= D_k(i)        for every other centroid k (from the certificate: r2 - eps2; 0 if uncertified).
+// The masked distance D_k(i) = || x_i - c_k/gamma || over the support S of x_i obeys the triangle inequality in
+// R^S, and || (c'_k - c_k)/gamma ||_S <= || (c'_k - c_k)/gamma ||_2 =: delta_k.  So for the next centroids c'
+//     D'_a <= ub + delta_a,      D'_k >= lb - max_k delta_k,
+// and (ub + delta_a)(1+nu) < (lb - dmax)(1-nu) proves -- without touching the point -- that the reference's argmin
+// is unchanged (strictly: no tie).  A 16-point step whose points all pass is skipped by the screen; phase 2 still
+// evaluates every point's exact distance to its centroid and the sums, so every output stays exact.
+// Buffer layout (floats): ub[npad] | lb[npad] | a[npad] (int32) | delta[K] | dmax | flag   (npad = n rounded up to 64)
+//
+// delta_k (rounded up, f32) for all k; delta[K] = max (bit pattern atomicMax: the values are >= 0).
+// The reference divides each entry by gamma in f64 first: 2^-50 (|c| + |c'|)/gamma covers those roundings.
+__global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__ prev, const double* __restrict__ cur,
+                                                      int K, int p, double gamma, float* __restrict__ delta)
+{
+    __shared__ double sh[3][4];
+    const int k = blockIdx.x;
+    const double g = gamma > 0.0 ? gamma : 1.0;
+    double d2 = 0.0, a2 = 0.0, b2 = 0.0;
+    for (int r = threadIdx.x; r < p; r += blockDim.x) {
+        const double a = prev[(size_t)k * p + r], b = cur[(size_t)k * p + r];
+        d2 += (b - a) * (b - a);
+        a2 += a * a;
+        b2 += b * b;
+    }
+    for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off); a2 += __shfl_down(a2, off); b2 += __shfl_down(b2, off); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = d2; sh[1][threadIdx.x >> 6] = a2; sh[2][threadIdx.x >> 6] = b2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d2 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        a2 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        b2 = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+        const double d = (sqrt(d2) * (1.0 + 1e-9) + 0x1p-50 * (sqrt(a2) + sqrt(b2))) / g * (1.0 + 1e-9);
+        float f = __double2float_ru(d);
+        if (!(f >= 0.f)) f = __builtin_inff(); // NaN centres: nothing is skipped
+        delta[k] = f;
+        atomicMax(reinterpret_cast<unsigned*>(delta + K), __builtin_bit_cast(unsigned, f));
+    }
+}
+
 // Per point: best / second-best estimate over the G tiles, certification, candidate assignment.
 // Uncertified points are appended to list[] (count in *nlist); a tile that reports "no candidate"
 // (+inf, +inf, -1) can never certify.
@@ -421,8 +463,14 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         const double* __restrict__ xn2, int fixed_s,
                                                         const unsigned long long* __restrict__ cmax_bits,
                                                         int* __restrict__ assign, int* __restrict__ list,
-                                                        unsigned int* __restrict__ nlist)
+                                                        unsigned int* __restrict__ nlist,
+                                                        float* __restrict__ bnd, long long npad, int K, int skipping)
 {
+    // bnd != nullptr: write each point's new lower bound (k_center_drift's comment); skipping: the screen marked
+    // the points of skipped steps with k = -2 in tile 0 -- assignment unchanged, bound moved by the largest drift
+    float* lbv = bnd ? bnd + npad : nullptr;
+    const int* aprev = bnd ? reinterpret_cast<const int*>(bnd + 2 * npad) : nullptr;
+    const float dmaxf = (bnd && skipping) ? bnd[3 * npad + K] : 0.f;
     const double cmax = __builtin_bit_cast(double, *cmax_bits);
     const double u = 0x1p-24;
     const double eu = (2.0 * u + u * u) * (1.0 + 1e-9);
@@ -431,6 +479,11 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     unsigned nambig = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
+        if (skipping && scr_k[i] == -2) {
+            assign[i] = aprev[i];
+            lbv[i] = __double2float_rd(((double)lbv[i] - (double)dmaxf) * (1.0 - 0x1p-20));
+            continue;
+        }
         float b1 = __builtin_inff(), b2 = __builtin_inff();
         int bk = -1;
         for (int g = 0; g < G; g++) {
@@ -449,6 +502,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         const double e1 = E + gacc * r1 + 1e-20, e2 = E + gacc * r2 + 1e-20;
         const bool certified = (bk >= 0) && ((r1 + e1) * (1.0 + nu) < (r2 - e2) * (1.0 - nu));
         assign[i] = bk >= 0 ? bk : 0;
+        if (lbv) lbv[i] = certified ? fmaxf(0.f, __double2float_rd((r2 - e2) * (1.0 - nu))) : 0.f;
         if (!certified) {
             const unsigned at = atomicAdd(nlist, 1u);
             list[at] = (int)i;
@@ -539,6 +593,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                                                           const int* __restrict__ nitems,
                                                           const double* __restrict__ C, double gamma, int p,
                                                           int fixed_s, int pts, double* __restrict__ mind,
+                                                          float* __restrict__ ubv, // carried bounds: ub[i] >= true distance (or null)
                                                           double* __restrict__ sums, double* __restrict__ counts,
                                                           double* __restrict__ blk_obj2,
                                                           double* __restrict__ blk_max,
@@ -636,6 +691,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #endif
                 const double dist = sqrt(acc);
                 mind[my_i] = dist;
+                if (ubv) ubv[my_i] = __double2float_ru(dist * (1.0 + 1e-12)); // the reference value is within 2^-45 of the true one
                 obj2 += dist * dist;
                 if (dist > dmax || (dist == dmax && my_i < imax)) { dmax = dist; imax = my_i; }
             }
@@ -741,7 +797,8 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
                                                  int extra_k0,
                                                  const double* __restrict__ hint, float hint_c,
-                                                 unsigned* __restrict__ counters)
+                                                 unsigned* __restrict__ counters, const float* __restrict__ bnd,
+                                                 long long npad)
 {
     constexpr int PPS = 16;
     const int lane = threadIdx.x & 63;
@@ -777,11 +834,28 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     // prefetch across steps: the other three waves of the SIMD cover the load latency.
     const int nvl = fixed_s - 4 * (NR - 1);
     unsigned npruned = 0; // steps this wave finished in the hinted two-phase form
+    unsigned nskipped = 0; // steps skipped on the carried bounds (counted by tile 0)
     for (int t = draw(); t < Tn; t = draw()) {
         const int base = point_of(t);
         if (base < n) {
             const int i = base + ps;
             constexpr bool with_extra = PL == 5;
+            // carried bounds (k_center_drift's comment): a step whose 16 points all keep their centroid provably is
+            // skipped -- by every tile alike (same inputs); tile 0 leaves the marker k = -2 for k_combine_screen
+            if (bnd != nullptr) {
+                const int ii = i < n ? i : n - 1;
+                const float ubi = bnd[ii], lbi = bnd[npad + ii];
+                const int ap = reinterpret_cast<const int*>(bnd)[2 * npad + ii];
+                const float da = bnd[3 * npad + ap], dmx = bnd[3 * npad + K];
+                const bool keep = (ubi + da) * 1.000001f < (lbi - dmx) * 0.999999f; // false for NaN
+                if (__all(keep)) {
+                    if (bm.tile == 0) {
+                        if (l4 == 0 && i < n) ko[i] = -2;
+                        nskipped++;
+                    }
+                    continue;
+                }
+            }
             // step-major screen copy (k_screen_reorder): round r of this step is 64 consecutive elements
             const float* xp = xval + (size_t)(base >> 4) * (NR * 64) + lane;
             const IR* rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
@@ -940,6 +1014,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
         }
     }
     if (counters != nullptr && lane == 0 && npruned) atomicAdd(counters + 2, npruned);
+    if (counters != nullptr && lane == 0 && nskipped) atomicAdd(counters + 3, nskipped);
 }
 
 // TWO: the two-phase forms -- the first A = quad_split(NR) rounds for all centroids, the rest only for each
@@ -953,7 +1028,8 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile,
-    const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters)
+    const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const float* __restrict__ bnd,
+    long long npad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -980,10 +1056,10 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
     constexpr int A = TWO ? quad_split(NR) : NR;
-    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
-    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
-    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
-    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters);
+    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
+    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
+    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
+    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)

@@ -287,7 +287,7 @@ def test_two_phase_screen_switches_itself_on_and_off(gpu_ctx, oracle):
     assert last[0] == last[1] or eng.last_path_info()[0] == 0    # back on the plain screen (or the exact kernels)
 
 
-def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle):
+def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle, monkeypatch):
     """Mid-run Lloyd state: some clusters are split between two nearby centres (runner-up within 2.25x: the
     unconditional two-phase form stays off) and some have no centre of their own.  From the second call on the
     previous min-distances, still in the caller's buffer, let 16-point steps finish early (form 2, counter of
@@ -296,6 +296,7 @@ def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle):
     import time
     from sparsifiedkmeans_amd import synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    monkeypatch.setenv("SPKM_NO_BOUNDS", "1")               # same centres every call: the carried bounds would skip it all
     K, n = 40, 8000
     data = synth.sparsified_gmm_host(p=256, n=n, K=K, gamma=0.2, seed=11, fwht=oracle.fwht)
     Y, p2, gam = data["Y"], data["p2"], data["gamma"]
@@ -327,3 +328,49 @@ def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle):
     assert any(m[0] == 2 for m in modes[1:4]), modes
     assert all(m[3] > 0 for m in modes if m[0] == 2), modes  # some steps did finish early
     _check(eng, oracle, Y, cen, gam)
+
+
+def test_carried_bounds_skip_steps_and_stay_exact(gpu_ctx, oracle):
+    """A converging Lloyd run: from the second call on, the bounds carried inside the library (previous assignment,
+    upper / lower distance bounds, centroid drift) let the screen skip whole 16-point steps; every call's outputs
+    still equal the oracle's bit for bit -- also when the caller scribbles over its output buffers in between (the
+    bounds live in the library's own copies), after a jump of the centres (nothing may be skipped wrongly), and
+    with SPKM_NO_BOUNDS-like behaviour after reset_policy (bounds forgotten)."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    K, n = 40, 8000
+    data = synth.sparsified_gmm_host(p=256, n=n, K=K, gamma=0.2, seed=13, fwht=oracle.fwht)
+    Y, p2, gam = data["Y"], data["p2"], data["gamma"]
+    cen = np.zeros((p2, K))
+    for k in range(K):
+        Yk = Y[:, data["labels"] == k]
+        cen[:, k] = gam * np.asarray(Yk.sum(axis=1)).ravel() / (np.asarray((Yk != 0).sum(axis=1)).ravel() + 1e-16)
+    rng = np.random.default_rng(5)
+    sh = Shard.from_scipy(gpu_ctx, Y)
+    eng = LloydEngine(sh, K, gam)
+    skipped = []
+
+    def call(cm):
+        centers = torch.tensor(np.ascontiguousarray(cm.T), device="cuda")
+        eng.assign_accumulate_step(centers)
+        torch.cuda.synchronize()
+        skipped.append(eng.last_screen_mode()[4])
+        _check(eng, oracle, Y, cm, gam)
+
+    call(cen)                                               # 0: nothing carried yet
+    call(cen * (1 + 1e-6))                                  # 1: tiny drift
+    eng.assign.fill_(7)                                     # the caller's buffers are not what the bounds live in
+    eng.mind.fill_(0.0)
+    call(cen * (1 + 2e-6))                                  # 2
+    moved = cen.copy()
+    moved[:, 3] = cen[:, 17]                                # 3: centre 3 jumps onto centre 17: ties and reassignments
+    call(moved)
+    call(moved)                                             # 4: no drift at all
+    jitter = moved + 0.05 * np.abs(cen).mean() * rng.standard_normal(cen.shape)
+    call(jitter)                                            # 5: every centre moves a little
+    sh.reset_policy()
+    call(jitter)                                            # 6: bounds forgotten
+    assert skipped[0] == 0 and skipped[6] == 0, skipped
+    assert skipped[1] > 0.5 * (n // 16) and skipped[2] > 0.5 * (n // 16), skipped
+    assert skipped[3] < skipped[2], skipped
+    assert skipped[4] > 0, skipped
