@@ -131,7 +131,7 @@ def main():
     for _ in range(args.warmup):
         eng.iterate(centers)
     L = _lib.lib()
-    _lib.check(L.spkm_timing_log(ctx.handle, 1))
+    _lib.check(L.spkm_timing_log(ctx.handle, 2))   # screen path: two pairs per call (screen, exact accumulation)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -147,18 +147,36 @@ def main():
     rounds_all, rounds = eng.last_screen_rounds()
     mode = eng.last_screen_mode()
     # dominant kernel (tiled assignment) durations of exactly the timed launches, HIP events on our stream
-    buf = (C.c_double * max(args.steps, 1))()
+    cap = 2 * max(args.steps, 1)
+    buf = (C.c_double * cap)()
     cnt = C.c_int()
-    _lib.check(L.spkm_timing_read(ctx.handle, buf, args.steps, C.byref(cnt)))
+    _lib.check(L.spkm_timing_read(ctx.handle, buf, cap, C.byref(cnt)))
     _lib.check(L.spkm_timing_log(ctx.handle, 0))
-    kms = np.array(buf[:min(cnt.value, args.steps)])
-    k_ms = float(kms.mean()) if kms.size else float("nan")
+    kms = np.array(buf[:min(cnt.value, cap)])
+    if path == 1 and kms.size == 2 * args.steps:
+        screen_ms, acc_ms = float(kms[0::2].mean()), float(kms[1::2].mean())
+    else:                                       # all-exact path (or a mix after a back-off): the tile kernel only
+        screen_ms, acc_ms = (float(kms.mean()) if kms.size else float("nan")), 0.0
 
     out = eng.out.cpu().numpy()
     nnz_local = int(shard.nnz)
-    # algorithmic bytes of one Lloyd iteration over this GPU's points
+    irb = 2 if p2 <= 65536 else 4
+    # algorithmic bytes of one Lloyd iteration over this GPU's points ...
     b_iter = nnz_local * 12 + (n_local + 1) * 8 + n_local * 12 + 24 * p2 * K
-    achieved = b_iter / (k_ms * 1e-3) / 1e9 if k_ms == k_ms else None
+    # ... and of the exact accumulation pass alone: values + row ids once, the sort permutation in, the
+    # min-distances out, the per-cluster sums and counts out
+    b_acc = nnz_local * (8 + irb) + n_local * 12 + 16 * p2 * K
+    # the roofline object describes whichever of the two kernels took longer over the timed iterations
+    if acc_ms > screen_ms:
+        kern, k_ms, b_kern = "k_exact_accumulate", acc_ms, b_acc
+        note = ("HBM bound: one pass over the f64 values and row ids in counting-sort order, reference arithmetic for "
+                "each point's distance to its centroid fused with the per-cluster sums; see DESIGN.md section 4.3")
+    else:
+        kern, k_ms, b_kern = dominant_kernel(path, s), screen_ms, b_iter
+        note = ("VALU-issue / LDS bound at K=100, not HBM bound: the f32 screen spends 10 issue slots of 4 "
+                "cycles per stored entry for 16 points x 32 centroids (exact f64 tiles: 4 slots per entry "
+                "for 4 points x 16 centroids); see DESIGN.md section 4")
+    achieved = b_kern / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     ops = 3.0 * nnz_local * K
     traffic = None
     valu_pmc = {}
@@ -166,13 +184,15 @@ def main():
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
-                rec = json.load(f)
-            kern = dominant_kernel(path, s)
-            if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
-                    and str(rec.get("kernel", "")).startswith(kern)):
-                traffic = rec.get("hbm_bytes_per_launch")
-                valu_pmc = {"issue_utilization_pmc": rec.get("valu_issue_utilization"),
-                            "effective_clock_ghz_pmc": rec.get("effective_clock_ghz")}
+                recs = json.load(f)
+            for rec in (recs if isinstance(recs, list) else [recs]):
+                if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
+                        and rec.get("start", "sample") == args.start
+                        and str(rec.get("kernel", "")).startswith(kern)):
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    if kern.startswith("k_screen"):
+                        valu_pmc = {"issue_utilization_pmc": rec.get("valu_issue_utilization"),
+                                    "effective_clock_ghz_pmc": rec.get("effective_clock_ghz")}
         except Exception:
             traffic = None
 
@@ -211,13 +231,12 @@ def main():
                    "steps_per_centroid_tile": (n_local + 15) // 16},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "kernel": dominant_kernel(path, s), "kernel_ms": k_ms,
-                     "algorithmic_bytes_per_launch": b_iter,
-                     "note": "VALU-issue / LDS bound at K=100, not HBM bound: the f32 screen spends 10 issue slots of 4 "
-                             "cycles per stored entry for 16 points x 32 centroids (exact f64 tiles: 4 slots per entry "
-                             "for 4 points x 16 centroids); see DESIGN.md section 4"},
-        "valu": {"distance_terms_per_s": (nnz_local * K) / (k_ms * 1e-3) if k_ms == k_ms else None,
-                 "exact_f64_op_equivalent_Tops": ops / (k_ms * 1e-3) / 1e12 if k_ms == k_ms else None,
+                     "kernel": kern, "kernel_ms": k_ms,
+                     "algorithmic_bytes_per_launch": b_kern,
+                     "kernels_ms": {dominant_kernel(path, s): screen_ms, "k_exact_accumulate": acc_ms},
+                     "note": note},
+        "valu": {"distance_terms_per_s": (nnz_local * K) / (screen_ms * 1e-3) if screen_ms == screen_ms else None,
+                 "exact_f64_op_equivalent_Tops": ops / (screen_ms * 1e-3) / 1e12 if screen_ms == screen_ms else None,
                  "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS, **valu_pmc},
         "whole_iter_gbs": b_iter / (elapsed / args.steps) / 1e9,
         "fwht": fw,

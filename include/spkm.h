@@ -229,7 +229,9 @@ int spkm_dense_accumulate_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, const doubl
 int spkm_last_assign_kernel_ms(spkm_ctx *ctx, double *ms);
 /* Per-launch log of the same kernel: enable=1 starts (and clears) the log, every later
  * spkm_assign_dev records one event pair without any host sync; spkm_timing_read blocks on the
- * stream and returns up to cap durations (ms) and the number recorded. */
+ * stream and returns up to cap durations (ms) and the number recorded.  enable=2: calls of
+ * spkm_assign_accumulate_dev that take the screen path record two pairs each, the screen kernel and then the
+ * exact accumulation kernel (k_exact_accumulate), alternating in the log. */
 int spkm_timing_log(spkm_ctx *ctx, int enable);
 /* Developer aid: per-workgroup (start, end) wall-clock stamps (100 MHz) of the tiled assignment
  * kernel.  enable=1 arms it; enable=0 copies up to cap pairs into out and reports the grid size. */

@@ -33,7 +33,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
@@ -43,6 +43,7 @@ struct spkm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tlog;
     size_t tlog_used = 0;
     bool tlog_on = false;
+    bool tlog_both = false; // fused screen path: log the exact accumulation kernel too (pairs alternate)
     int assign_KT = 0, assign_G = 0; // of the last assign call
     int last_path = 0;               // 0 = exact tiled/generic, 1 = f32 screen + exact confirmation
     unsigned last_listed = 0;        // points sent to the exact list by the last screen (read lazily)
@@ -732,6 +733,7 @@ extern "C" int spkm_timing_log(spkm_ctx* ctx, int enable)
 {
     if (!ctx) return SPKM_ERR_NULL_ARG;
     ctx->tlog_on = enable != 0;
+    ctx->tlog_both = enable == 2;
     ctx->tlog_used = 0;
     return SPKM_OK;
 }
@@ -923,7 +925,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 16, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 32, ctx->stream));
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
@@ -947,6 +949,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
                                d_centers, K, p, gamma, sm->hb + 3 * npad);
+            // settle the steps the bounds certify, list the others for the screen
+            if ((rc = ensure(ctx, ctx->todo, (size_t)(npad / 16 + 1) * 4))) return rc;
+            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)((npad + BOUNDS_SPAN - 1) / BOUNDS_SPAN)), dim3(256), 0,
+                               ctx->stream, sm->hb, npad, n, K, (int*)ctx->scr_k.p, (int*)d_assign, (int*)ctx->todo.p,
+                               (unsigned*)ctx->nlist.p);
             skipping = true;
         }
         sm->hb_valid = false; // until this call has gone through
@@ -988,10 +995,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float a_hc = 2.0f; // the other centroids' partial sums must exceed 2x the previous min-distance squared
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
-        const float* a_bnd = skipping ? sm->hb : nullptr;
-        long long a_npad = npad;
+        const int* a_todo = skipping ? (const int*)ctx->todo.p : nullptr;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
-                        &a_hint, &a_hc, &a_cnt, &a_bnd, &a_npad};
+                        &a_hint, &a_hc, &a_cnt, &a_todo};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -1001,7 +1007,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), 0, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
-                       (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad, K,
+                       (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
                        skipping ? 1 : 0);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
@@ -1041,11 +1047,13 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;
+    if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
     hipLaunchKernelGGL(k2, dim3(ab), dim3(threads), lds2, ctx->stream, (const IR*)s->ir, (const double*)s->x,
                        (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
                        (const int*)ctx->nitems.p, d_centers, gamma, p, s->fixed_s, pts, d_mind,
                        quad ? sm->hb : (float*)nullptr, sums, counts,
                        (double*)ctx->blk_obj.p, (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p);
+    if (ctx->tlog_both) HIP_TRY(timing_end(ctx));
     hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
                        (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, ab, (double*)ctx->stats.p);
     hipLaunchKernelGGL(k_nk_to_f64, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,

@@ -453,6 +453,64 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
     }
 }
 
+// One thread per point, 16-lane groups = the screen's steps.  A step whose points all pass the carried-bounds
+// test (k_center_drift's comment) is settled here: assignment = the previous one, lower bound moved by the largest
+// drift, marker k = -2 in tile 0's result slot (k_combine_screen passes over it).  Every other step is appended
+// to todo[] (its index; order within the list does not matter), counters[4] = length, counters[3] = steps skipped.
+#define BOUNDS_SPAN 16384 // points per workgroup of k_bounds_steps (1024 steps)
+__global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
+                                                      int* __restrict__ k_tile0, int* __restrict__ assign,
+                                                      int* __restrict__ todo, unsigned* __restrict__ counters)
+{
+    // the steps that stay are collected per workgroup in LDS and appended with ONE global atomic (a wave-level
+    // append costs ~8 ms at N = 1e8 when nothing can be skipped: 1.5 M atomics on one address)
+    __shared__ int s_todo[BOUNDS_SPAN / 16];
+    __shared__ unsigned s_cnt, s_pos;
+    const float dmx = bnd[3 * npad + K];
+    const int lane = threadIdx.x & 63;
+    unsigned nskip = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const long long span0 = (long long)blockIdx.x * BOUNDS_SPAN;
+    for (int it = 0; it < BOUNDS_SPAN / 256; it++) {
+        const long long i = span0 + it * 256 + threadIdx.x;
+        if (span0 + it * 256 >= npad) break; // npad: whole waves
+        bool keep = true;
+        float lbi = 0.f;
+        int ap = 0;
+        if (i < n) {
+            const float ubi = bnd[i];
+            lbi = bnd[npad + i];
+            ap = reinterpret_cast<const int*>(bnd)[2 * npad + i];
+            const float da = bnd[3 * npad + ap];
+            keep = (ubi + da) * 1.000001f < (lbi - dmx) * 0.999999f; // false for NaN
+        }
+        const unsigned long long b = __ballot(keep);
+        const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
+        const bool skip = grp == 0xffffu;
+        const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
+        if (skip && i < n) {
+            assign[i] = ap;
+            bnd[npad + i] = __double2float_rd(((double)lbi - (double)dmx) * (1.0 - 0x1p-20));
+            k_tile0[i] = -2;
+        }
+        const bool lead = (lane & 15) == 0 && live_step && !skip;
+        const unsigned long long lm = __ballot(lead);
+        if (lm) {
+            unsigned basepos = 0;
+            if (lane == 0) basepos = atomicAdd(&s_cnt, (unsigned)__popcll(lm));
+            basepos = __builtin_amdgcn_readfirstlane(basepos);
+            if (lead) s_todo[basepos + __popcll(lm & ((1ull << lane) - 1ull))] = (int)(i >> 4);
+        }
+        nskip += (unsigned)__popcll(__ballot((lane & 15) == 0 && live_step && skip));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo[s_pos + j] = s_todo[j];
+    if (lane == 0 && nskip) atomicAdd(counters + 3, nskip);
+}
+
 // Per point: best / second-best estimate over the G tiles, certification, candidate assignment.
 // Uncertified points are appended to list[] (count in *nlist); a tile that reports "no candidate"
 // (+inf, +inf, -1) can never certify.
@@ -464,13 +522,11 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         const unsigned long long* __restrict__ cmax_bits,
                                                         int* __restrict__ assign, int* __restrict__ list,
                                                         unsigned int* __restrict__ nlist,
-                                                        float* __restrict__ bnd, long long npad, int K, int skipping)
+                                                        float* __restrict__ bnd, long long npad, int skipping)
 {
-    // bnd != nullptr: write each point's new lower bound (k_center_drift's comment); skipping: the screen marked
-    // the points of skipped steps with k = -2 in tile 0 -- assignment unchanged, bound moved by the largest drift
+    // bnd != nullptr: write each point's new lower bound (k_center_drift's comment); skipping: k_bounds_steps marked
+    // the points of skipped steps with k = -2 in tile 0 and settled them
     float* lbv = bnd ? bnd + npad : nullptr;
-    const int* aprev = bnd ? reinterpret_cast<const int*>(bnd + 2 * npad) : nullptr;
-    const float dmaxf = (bnd && skipping) ? bnd[3 * npad + K] : 0.f;
     const double cmax = __builtin_bit_cast(double, *cmax_bits);
     const double u = 0x1p-24;
     const double eu = (2.0 * u + u * u) * (1.0 + 1e-9);
@@ -479,11 +535,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     unsigned nambig = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        if (skipping && scr_k[i] == -2) {
-            assign[i] = aprev[i];
-            lbv[i] = __double2float_rd(((double)lbv[i] - (double)dmaxf) * (1.0 - 0x1p-20));
-            continue;
-        }
+        if (skipping && scr_k[i] == -2) continue; // settled by k_bounds_steps
         float b1 = __builtin_inff(), b2 = __builtin_inff();
         int bk = -1;
         for (int g = 0; g < G; g++) {
@@ -792,13 +844,12 @@ __device__ __forceinline__ float quad_min_f32(float v)
 
 template <int NR, typename IR, int PL, int A>
 __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
-                                                 int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
+                                                 int nv, int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
                                                  int extra_k0,
                                                  const double* __restrict__ hint, float hint_c,
-                                                 unsigned* __restrict__ counters, const float* __restrict__ bnd,
-                                                 long long npad)
+                                                 unsigned* __restrict__ counters, const int* __restrict__ todo)
 {
     constexpr int PPS = 16;
     const int lane = threadIdx.x & 63;
@@ -812,7 +863,9 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     // PL = 5: the lane's extra centroid extra_k0 + l4 sits in a table of 16-B rows at extra_base:
     // its address is (a >> 7) * 16 + ce for a = row * 128 + ...
     const int ce = extra_base + l4 * 4;
-    const int nchunks = (n + chunk_points - 1) / chunk_points;
+    // todo != nullptr: only the steps listed there are processed (k_bounds_steps: the others were skipped on the
+    // carried bounds); tickets and chunks then number the LIST -- nv = 16 x its length stands in for n
+    const int nchunks = (nv + chunk_points - 1) / chunk_points;
     const int R = chunk_points / PPS;
     // chunk ids of this workgroup: (stream + ci * nstreams) * mul + add   (mul/add: XCD-local numbering)
     const int mul = bm.pad & 0xff, add = (bm.pad >> 8) & 0xff;
@@ -825,37 +878,21 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
         return (int)__builtin_amdgcn_readfirstlane(v);
     };
     auto point_of = [&](int t) {
-        if (t >= Tn) return n;
+        if (t >= Tn) return nv;
         const int ci = t / R, rr = t - ci * R;
         const int base = ((bm.stream + ci * bm.nstreams) * mul + add) * chunk_points + rr * PPS;
-        return (base < 0 || base > n) ? n : base;
+        return (base < 0 || base > nv) ? nv : base;
     };
     // a step's entries: NR rounds of 4 (entries past the column become x = 0 on the zero row p).  No software
     // prefetch across steps: the other three waves of the SIMD cover the load latency.
     const int nvl = fixed_s - 4 * (NR - 1);
     unsigned npruned = 0; // steps this wave finished in the hinted two-phase form
-    unsigned nskipped = 0; // steps skipped on the carried bounds (counted by tile 0)
     for (int t = draw(); t < Tn; t = draw()) {
-        const int base = point_of(t);
-        if (base < n) {
+        const int vbase = point_of(t);
+        if (vbase < nv) {
+            const int base = todo != nullptr ? todo[vbase >> 4] << 4 : vbase;
             const int i = base + ps;
             constexpr bool with_extra = PL == 5;
-            // carried bounds (k_center_drift's comment): a step whose 16 points all keep their centroid provably is
-            // skipped -- by every tile alike (same inputs); tile 0 leaves the marker k = -2 for k_combine_screen
-            if (bnd != nullptr) {
-                const int ii = i < n ? i : n - 1;
-                const float ubi = bnd[ii], lbi = bnd[npad + ii];
-                const int ap = reinterpret_cast<const int*>(bnd)[2 * npad + ii];
-                const float da = bnd[3 * npad + ap], dmx = bnd[3 * npad + K];
-                const bool keep = (ubi + da) * 1.000001f < (lbi - dmx) * 0.999999f; // false for NaN
-                if (__all(keep)) {
-                    if (bm.tile == 0) {
-                        if (l4 == 0 && i < n) ko[i] = -2;
-                        nskipped++;
-                    }
-                    continue;
-                }
-            }
             // step-major screen copy (k_screen_reorder): round r of this step is 64 consecutive elements
             const float* xp = xval + (size_t)(base >> 4) * (NR * 64) + lane;
             const IR* rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
@@ -1014,7 +1051,6 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
         }
     }
     if (counters != nullptr && lane == 0 && npruned) atomicAdd(counters + 2, npruned);
-    if (counters != nullptr && lane == 0 && nskipped) atomicAdd(counters + 3, nskipped);
 }
 
 // TWO: the two-phase forms -- the first A = quad_split(NR) rounds for all centroids, the rest only for each
@@ -1028,8 +1064,7 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile,
-    const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const float* __restrict__ bnd,
-    long long npad)
+    const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const int* __restrict__ todo)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -1056,10 +1091,15 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
     constexpr int A = TWO ? quad_split(NR) : NR;
-    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
-    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
-    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
-    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, fixed_s, K, bm, chunk_points, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, bnd, npad);
+    int nv = n, chunk_v = chunk_points;
+    if (todo != nullptr) { // counters[4] = length of the list; chunks small enough that every workgroup gets several
+        nv = (int)counters[4] * 16;
+        chunk_v = max(256, min(chunk_points, (nv / (int)(gridDim.x * 2)) & ~255));
+    }
+    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
+    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
+    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
+    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
