@@ -88,6 +88,7 @@ struct spkm_shard {
     size_t hb_centers_len = 0;
     long long hb_npad = 0;
     int hb_K = 0;
+    double hb_gamma = 0.0;
     bool hb_valid = false;
 };
 
@@ -945,7 +946,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             HIP_TRY(hipMalloc((void**)&sm->hb_centers, pk * 8));
             sm->hb_centers_len = pk;
         }
-        if (sm->hb_valid && sm->hb_K == K && !getenv("SPKM_NO_BOUNDS")) {
+        if (sm->hb_valid && sm->hb_K == K && sm->hb_gamma == gamma && !getenv("SPKM_NO_BOUNDS")) {
             HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
                                d_centers, K, p, gamma, sm->hb + 3 * npad);
@@ -1063,6 +1064,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
         HIP_TRY(hipMemcpyAsync(sm->hb_centers, d_centers, pk * 8, hipMemcpyDeviceToDevice, ctx->stream));
         sm->hb_K = K;
+        sm->hb_gamma = gamma;
         sm->hb_valid = true;
     }
     ctx->last_path = 1;

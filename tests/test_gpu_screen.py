@@ -370,6 +370,14 @@ def test_carried_bounds_skip_steps_and_stay_exact(gpu_ctx, oracle):
     call(jitter)                                            # 5: every centre moves a little
     sh.reset_policy()
     call(jitter)                                            # 6: bounds forgotten
+    call(jitter)                                            # 7: carried again
+    eng.gamma = gam * 1.25                                  # 8: another scaling of the centres: the bounds do not apply
+    centers = torch.tensor(np.ascontiguousarray(jitter.T), device="cuda")
+    eng.assign_accumulate_step(centers)
+    torch.cuda.synchronize()
+    skipped.append(eng.last_screen_mode()[4])
+    _check(eng, oracle, Y, jitter, gam * 1.25)
+    assert skipped[7] > 0 and skipped[8] == 0, skipped
     assert skipped[0] == 0 and skipped[6] == 0, skipped
     assert skipped[1] > 0.5 * (n // 16) and skipped[2] > 0.5 * (n // 16), skipped
     assert skipped[3] < skipped[2], skipped
