@@ -178,8 +178,9 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * info[1..4] = that call's counters: points listed for exact evaluation, points with a runner-up within 2.25x
  * (a bound: over-counts in the two-phase forms), (16-point step, centroid tile) pairs finished early by the
  * hinted form, 16-point steps skipped altogether on the bounds carried from the previous call (see
- * spkm_assign_accumulate_dev).  Blocks on the stream. */
-int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[5]);
+ * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context.
+ * Blocks on the stream. */
+int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[6]);
 
 /* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
  * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;

@@ -921,7 +921,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->scr_m2, (size_t)Gs * n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->scr_k, (size_t)Gs * n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->list, (size_t)n * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->nlist, 64))) return rc;
+    {
+        const bool fresh = ctx->nlist.p == nullptr;
+        if ((rc = ensure(ctx, ctx->nlist, 64))) return rc;
+        if (fresh) HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 64, ctx->stream)); // [8..9]: running total of skipped steps
+    }
     if ((rc = ensure(ctx, ctx->ct, pk * 8))) return rc;
     if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
@@ -1159,18 +1163,19 @@ extern "C" int spkm_last_screen_rounds(spkm_ctx* ctx, int64_t info[2])
 }
 
 // Form and counters of the last screen call.  Blocks on the stream (diagnostics, not the hot path).
-extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[5])
+extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[6])
 {
     if (!ctx || !info) return SPKM_ERR_NULL_ARG;
     info[0] = -1;
-    info[1] = info[2] = info[3] = info[4] = 0;
+    info[1] = info[2] = info[3] = info[4] = info[5] = 0;
     if (ctx->last_path == 1 && ctx->nlist.p) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        unsigned v[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(v, ctx->nlist.p, 16, hipMemcpyDeviceToHost));
+        unsigned v[10] = {0};
+        HIP_TRY(hipMemcpy(v, ctx->nlist.p, 40, hipMemcpyDeviceToHost));
         info[0] = ctx->last_mode;
         for (int j = 0; j < 4; j++) info[1 + j] = v[j];
+        info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
     }
     return SPKM_OK;
 }

@@ -508,7 +508,10 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     if (threadIdx.x == 0) s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
     __syncthreads();
     for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo[s_pos + j] = s_todo[j];
-    if (lane == 0 && nskip) atomicAdd(counters + 3, nskip);
+    if (lane == 0 && nskip) {
+        atomicAdd(counters + 3, nskip);
+        atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)nskip); // never reset: running total
+    }
 }
 
 // Per point: best / second-best estimate over the G tiles, certification, candidate assignment.
