@@ -194,7 +194,8 @@ def main():
                 recs = json.load(f)
             for rec in (recs if isinstance(recs, list) else [recs]):
                 if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
-                        and rec.get("start", "sample") == args.start
+                        and (rec.get("start", "sample") == args.start or kern == "k_exact_accumulate")  # (its stream
+                        # is the same from any start; the screen's launches are not)
                         and str(rec.get("kernel", "")).startswith(kern)):
                     traffic = rec.get("hbm_bytes_per_launch")
                     if kern.startswith("k_screen"):
