@@ -339,6 +339,8 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->prune_pending_a = 0;
     s->hint_ptr = nullptr;
     s->hint_cooldown = 0;
+    s->hint_pending = false;
+    s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
     return SPKM_OK;
 }

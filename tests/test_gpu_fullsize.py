@@ -94,3 +94,42 @@ def test_fixed_point_is_idempotent(workload):
     eng.iterate(c)
     assert torch.equal(eng.assign, prev)
     assert torch.allclose(c, c_fix, rtol=1e-12, atol=1e-14)     # same points per cluster -> same means (atomics order)
+
+
+def test_lloyd_run_with_every_layer_equals_exact_kernels_each_iteration(workload):
+    """The benchmark's regime at full size: a Lloyd run from sampled (duplicate) centres.  The default path goes
+    through the plain screen, the hinted two-phase screen and, once the centres settle, the carried bounds that skip
+    whole steps; after EVERY iteration its assignments and min-distances equal, bit for bit, what the all-exact f64
+    kernels give for the same centres (a second shard object over the same device buffers, so that the exact calls
+    do not disturb the state the layers live on)."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_device
+    w = workload
+    d, K, p2 = w["keep"], w["K"], w["p2"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(234 + 17)
+    lab = torch.randint(0, K, (K,), generator=g, device="cuda")
+    start = d["means"][lab] + 0.1 * torch.randn((K, 1024), generator=g, device="cuda", dtype=torch.float64)
+    c = mix_device(w["shard"].ctx, start.contiguous(), p2, d["sign"], 1.0, float(np.sqrt(np.float64(p2))))
+    twin = Shard.from_device(w["shard"].ctx, p2, d["jc"], d["ir"], d["x"], nnz=d["nnz"])
+    w["shard"].reset_policy()                                   # the other tests of this module used the shard
+    eng = LloydEngine(w["shard"], K, w["gamma"])
+    exact = LloydEngine(twin, K, w["gamma"])
+    forms, skipped = [], []
+    for it in range(14):
+        c_in = c.clone()
+        eng.iterate(c)                                          # updates c in place
+        torch.cuda.synchronize()
+        m = eng.last_screen_mode()
+        forms.append(m[0])
+        skipped.append(m[4])
+        os.environ["SPKM_NO_SCREEN"] = "1"
+        try:
+            exact.assign_accumulate_step(c_in)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SPKM_NO_SCREEN", None)
+        assert exact.last_path_info()[0] == 0
+        assert torch.equal(eng.assign, exact.assign), f"iteration {it}"
+        assert torch.equal(eng.mind, exact.mind), f"iteration {it}"
+    assert forms[0] == 0 and 2 in forms, forms                  # plain first, hinted later
+    assert skipped[-1] > 0.5 * (w["n"] // 16), skipped          # the run has settled: most steps are skipped
