@@ -1038,7 +1038,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
                        (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
     // 5. exact distance to the assigned centroid + per-cluster accumulation
-    const int threads = 1024, nw = threads / 64;
+    int threads = 1024;
+    if (const char* ev = getenv("SPKM_ACC_THREADS")) threads = atoi(ev) == 512 ? 512 : 1024; // A/B aid
+    const int nw = threads / 64;
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     const size_t fixed_lds = (size_t)p * 20 + 16;
     // 1 KB headroom: the kernel also has 384 B of static LDS (per-wave partial statistics)
@@ -1048,7 +1050,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
     int per_cu = 1;
     if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
-    auto k2 = k_exact_accumulate<IR, 16, 4>; // 16 points' loads in flight per wave, 4 waves per SIMD
+    auto k2 = threads == 512 ? k_exact_accumulate<IR, 16, 2> : k_exact_accumulate<IR, 16, 4>; // 16 points' loads in flight per wave, 4 waves per SIMD
     HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * per_cu);
     if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;

@@ -739,11 +739,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             if (lane < have) {
                 double acc = 0.0;
                 const double* mq = ms + (size_t)lane * S1;
-#ifdef SPKM_EXP_NOSUM
-                for (int j = 0; j < 2; j++) acc = acc + mq[j];
-#else
-                for (int j = 0; j < fixed_s; j++) acc = acc + mq[j];
-#endif
+                // the additions are a dependent chain in storage order; the LDS reads are not: eight in flight
+                int j = 0;
+                for (; j + 8 <= fixed_s; j += 8) {
+                    const double m0 = mq[j], m1 = mq[j + 1], m2 = mq[j + 2], m3 = mq[j + 3], m4 = mq[j + 4],
+                                 m5 = mq[j + 5], m6 = mq[j + 6], m7 = mq[j + 7];
+                    acc = acc + m0; acc = acc + m1; acc = acc + m2; acc = acc + m3;
+                    acc = acc + m4; acc = acc + m5; acc = acc + m6; acc = acc + m7;
+                }
+                for (; j < fixed_s; j++) acc = acc + mq[j];
                 const double dist = sqrt(acc);
                 mind[my_i] = dist;
                 if (ubv) ubv[my_i] = __double2float_ru(dist * (1.0 + 1e-12)); // the reference value is within 2^-45 of the true one

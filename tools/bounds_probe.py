@@ -19,6 +19,9 @@ eng = LloydEngine(sh, K, gamma)
 ir = d["ir"][: n * s].view(n, s).long() & 0xffff
 x = d["x"][: n * s].view(n, s)
 
+TILES = [(0, 32), (32, 64), (64, 100)]
+tl = [torch.empty(n, device='cuda', dtype=torch.float64) for _ in TILES]
+
 def dists(cent):
     cg = cent / gamma                                   # K x p2
     out1 = torch.empty(n, device="cuda", dtype=torch.float64); out2 = torch.empty_like(out1); a = torch.empty(n, device="cuda", dtype=torch.long)
@@ -28,13 +31,18 @@ def dists(cent):
         dd = ((x[i0:i1][None] - cc) ** 2).sum(-1).sqrt().T   # m x K
         v, idx = torch.topk(dd, 2, dim=1, largest=False)
         out1[i0:i1], out2[i0:i1], a[i0:i1] = v[:, 0], v[:, 1], idx[:, 0]
+        # per-tile lower bounds (tiles of 32 centroids; the carried remainder rides in tile 2): min over the tile's
+        # centroids other than the assigned one
+        dd2 = dd.clone(); dd2[torch.arange(i1 - i0), idx[:, 0]] = float("inf")
+        for t, (lo, hi) in enumerate(TILES):
+            tl[t][i0:i1] = dd2[:, lo:hi].min(dim=1).values
     return out1, out2, a
 
 prev = None
 for it in range(14):
     d1, d2, a = dists(c)
     if prev is not None:
-        pc, ub, lb, pa = prev
+        pc, ub, lb, pa, ptl = prev
         delta = ((c - pc) / gamma).norm(dim=1)
         dmax = delta.max()
         U = ub + delta[pa]
@@ -45,8 +53,21 @@ for it in range(14):
         print(f"iter {it}: drift max {dmax:.3g} mean {delta.mean():.3g}  d1 mean {d1.mean():.3g} gap mean {(d2-d1).mean():.3g}  points certified {ok.float().mean():.4f}  steps certified {steps_ok:.4f}  reassigned {changed:.5f}")
         # carried bounds (Hamerly): certified points keep the moved lower bound, the others get fresh ones
         lb = torch.where(ok, Lb, d2)
+        # per-tile version: a (step, tile) pair is skipped when all 16 points pass for that tile and the tile is not
+        # the own tile of any of them -- unless every tile passes (then the whole step is skipped)
+        passes = []
+        for t, (lo, hi) in enumerate(TILES):
+            passes.append(U < ptl[t] - delta[lo:hi].max())
+        P = torch.stack(passes, 1)                                  # n x T
+        own = torch.stack([(pa >= lo) & (pa < hi) for lo, hi in TILES], 1)
+        allp = P.all(dim=1)
+        skip_pt = (P & ~own) | allp[:, None]
+        st = skip_pt.view(-1, 16, len(TILES)).all(dim=1).float().mean().item()
+        print(f"          per-tile bounds: (step, tile) pairs skippable {st:.4f}; tile drifts {[round(delta[lo:hi].max().item(), 1) for lo, hi in TILES]}")
+        newtl = [torch.where(P[:, t], ptl[t] - delta[lo:hi].max(), tl[t]) for t, (lo, hi) in enumerate(TILES)]
     else:
         lb = d2
-    prev = (c.clone(), d1.clone(), lb, a.clone())
+        newtl = [x_.clone() for x_ in tl]
+    prev = (c.clone(), d1.clone(), lb, a.clone(), newtl)
     eng.iterate(c)
     torch.cuda.synchronize()
