@@ -1187,7 +1187,14 @@ __global__ __launch_bounds__(1024) void k_exact_dist1(const IR* __restrict__ ir,
         if (lane < have) {
             double acc = 0.0;
             const double* mq = ms + (size_t)lane * S1;
-            for (int j = 0; j < fixed_s; j++) acc = acc + mq[j];
+            int j = 0; // dependent chain of additions in storage order, eight independent LDS reads in flight
+            for (; j + 8 <= fixed_s; j += 8) {
+                const double m0 = mq[j], m1 = mq[j + 1], m2 = mq[j + 2], m3 = mq[j + 3], m4 = mq[j + 4], m5 = mq[j + 5],
+                             m6 = mq[j + 6], m7 = mq[j + 7];
+                acc = acc + m0; acc = acc + m1; acc = acc + m2; acc = acc + m3;
+                acc = acc + m4; acc = acc + m5; acc = acc + m6; acc = acc + m7;
+            }
+            for (; j < fixed_s; j++) acc = acc + mq[j];
             const double dist = sqrt(acc);
             const long long i = b0 + lane;
             mind[i] = dist;
