@@ -15,6 +15,11 @@
 
 static spkm_shard *g_shard = NULL;
 static const mxArray *g_shard_key = NULL; /* identity of the uploaded X (MATLAB shares data pointers) */
+/* per-point outputs stay allocated between calls: the library uses the previous call's min-distances, found in
+ * the same buffer, as hints for the next one (spkm.h, spkm_assign_accumulate_dev) */
+static double *g_dmind = NULL;
+static int32_t *g_dassign = NULL;
+static size_t g_npts = 0;
 
 static void *dmalloc(size_t bytes) { void *p = NULL; if (hipMalloc(&p, bytes) != hipSuccess) mexErrMsgTxt("hipMalloc failed"); return p; }
 
@@ -23,7 +28,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     char cmd[16] = {0};
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgTxt("first argument must be a command string");
     spkm_ctx *ctx = spkm_mex_ctx();
-    if (!strcmp(cmd, "release")) { spkm_shard_destroy(g_shard); g_shard = NULL; g_shard_key = NULL; return; }
+    if (!strcmp(cmd, "release")) {
+        spkm_shard_destroy(g_shard); g_shard = NULL; g_shard_key = NULL;
+        hipFree(g_dmind); hipFree(g_dassign); g_dmind = NULL; g_dassign = NULL; g_npts = 0;
+        return;
+    }
     if (strcmp(cmd, "iterate") || nrhs != 4) mexErrMsgTxt("usage: spkm_lloyd('iterate', X, centers, gamma)");
     const mxArray *X = prhs[1], *C = prhs[2];
     if (!mxIsSparse(X)) mexErrMsgTxt("Requires first input to be a sparse matrix");
@@ -38,9 +47,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         g_shard_key = (const mxArray *)mxGetPr(X);
     }
     const size_t pk = (size_t)p * K, rl = (size_t)spkm_reduce_len(p, K);
-    double *dC = (double *)dmalloc(pk * 8), *dred = (double *)dmalloc(rl * 8), *dmind = (double *)dmalloc((n + 1) * 8);
+    if (g_npts != (size_t)n) {
+        hipFree(g_dmind); hipFree(g_dassign);
+        g_dmind = (double *)dmalloc(((size_t)n + 1) * 8);
+        g_dassign = (int32_t *)dmalloc(((size_t)n + 1) * 4);
+        g_npts = (size_t)n;
+    }
+    double *dC = (double *)dmalloc(pk * 8), *dred = (double *)dmalloc(rl * 8), *dmind = g_dmind;
     double *dout = (double *)dmalloc(16);
-    int32_t *dassign = (int32_t *)dmalloc((n + 1) * 4);
+    int32_t *dassign = g_dassign;
     hipMemcpy(dC, mxGetPr(C), pk * 8, hipMemcpyHostToDevice);
     /* assignment + accumulation in one call: the certified f32 screen with exact f64 confirmation where the
      * shard qualifies (every column the same length, as randsample_fixedNumberEntries produces), the exact
@@ -64,5 +79,5 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(sqrt(out[0]));   /* norm(centersOld-centers,'fro') */
     if (nlhs > 4) plhs[4] = mxCreateDoubleScalar(sqrt(out[1]));   /* sqrt(sum(distances.^2))        */
     if (nlhs > 5) { plhs[5] = mxCreateDoubleMatrix(1, K, mxREAL); hipMemcpy(mxGetPr(plhs[5]), dred + 2 * pk, K * 8, hipMemcpyDeviceToHost); }
-    hipFree(dC); hipFree(dred); hipFree(dmind); hipFree(dout); hipFree(dassign);
+    hipFree(dC); hipFree(dred); hipFree(dout);
 }
