@@ -959,7 +959,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             // settle the steps the bounds certify, list the others for the screen
             if ((rc = ensure(ctx, ctx->todo, (size_t)(npad / 16 + 1) * 4))) return rc;
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)((npad + BOUNDS_SPAN - 1) / BOUNDS_SPAN)), dim3(256), 0,
-                               ctx->stream, sm->hb, npad, n, K, (int*)ctx->scr_k.p, (int*)d_assign, (int*)ctx->todo.p,
+                               ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p);
             skipping = true;
         }
@@ -1015,7 +1015,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
-                       skipping ? 1 : 0);
+                       skipping ? 1 : 0, (const int*)ctx->todo.p);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign);

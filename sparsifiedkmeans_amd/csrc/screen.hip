@@ -455,63 +455,73 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
 
 // One thread per point, 16-lane groups = the screen's steps.  A step whose points all pass the carried-bounds
 // test (k_center_drift's comment) is settled here: assignment = the previous one, lower bound moved by the largest
-// drift, marker k = -2 in tile 0's result slot (k_combine_screen passes over it).  Every other step is appended
-// to todo[] (its index; order within the list does not matter), counters[4] = length, counters[3] = steps skipped.
+// drift.  Every other step is appended to todo[] (its index; order within the list does not matter) -- the list
+// the screen kernel and k_combine_screen iterate; counters[4] = length, counters[3] = steps skipped.
 #define BOUNDS_SPAN 16384 // points per workgroup of k_bounds_steps (1024 steps)
 __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
-                                                      int* __restrict__ k_tile0, int* __restrict__ assign,
+                                                      int* __restrict__ assign,
                                                       int* __restrict__ todo, unsigned* __restrict__ counters)
 {
-    // the steps that stay are collected per workgroup in LDS and appended with ONE global atomic (a wave-level
-    // append costs ~8 ms at N = 1e8 when nothing can be skipped: 1.5 M atomics on one address)
+    // the steps that stay are collected per workgroup in LDS and appended with ONE global atomic, the skipped ones
+    // counted per workgroup (wave-level atomics on one address cost ~8 ms at N = 1e8 when nothing can be skipped)
     __shared__ int s_todo[BOUNDS_SPAN / 16];
-    __shared__ unsigned s_cnt, s_pos;
+    __shared__ unsigned s_cnt, s_pos, s_skip;
     const float dmx = bnd[3 * npad + K];
     const int lane = threadIdx.x & 63;
     unsigned nskip = 0;
-    if (threadIdx.x == 0) s_cnt = 0;
+    if (threadIdx.x == 0) { s_cnt = 0; s_skip = 0; }
     __syncthreads();
     const long long span0 = (long long)blockIdx.x * BOUNDS_SPAN;
-    for (int it = 0; it < BOUNDS_SPAN / 256; it++) {
-        const long long i = span0 + it * 256 + threadIdx.x;
-        if (span0 + it * 256 >= npad) break; // npad: whole waves
-        bool keep = true;
-        float lbi = 0.f;
-        int ap = 0;
-        if (i < n) {
-            const float ubi = bnd[i];
-            lbi = bnd[npad + i];
-            ap = reinterpret_cast<const int*>(bnd)[2 * npad + i];
-            const float da = bnd[3 * npad + ap];
-            keep = (ubi + da) * 1.000001f < (lbi - dmx) * 0.999999f; // false for NaN
+    constexpr int UN = 4; // rounds whose (dependent) loads are in flight together
+    for (int it0 = 0; it0 < BOUNDS_SPAN / 256; it0 += UN) {
+        if (span0 + it0 * 256 >= npad) break; // npad: whole waves
+        float ubv[UN], lbv[UN], dav[UN];
+        int apv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
+            const bool in = i < n;
+            ubv[u] = in ? bnd[i] : 0.f;
+            lbv[u] = in ? bnd[npad + i] : 0.f;
+            apv[u] = in ? reinterpret_cast<const int*>(bnd)[2 * npad + i] : 0;
         }
-        const unsigned long long b = __ballot(keep);
-        const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
-        const bool skip = grp == 0xffffu;
-        const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
-        if (skip && i < n) {
-            assign[i] = ap;
-            bnd[npad + i] = __double2float_rd(((double)lbi - (double)dmx) * (1.0 - 0x1p-20));
-            k_tile0[i] = -2;
+#pragma unroll
+        for (int u = 0; u < UN; u++) dav[u] = bnd[3 * npad + apv[u]];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
+            if (span0 + (it0 + u) * 256 >= npad) break;
+            const bool keep = !(i < n) || (ubv[u] + dav[u]) * 1.000001f < (lbv[u] - dmx) * 0.999999f; // false for NaN
+            const unsigned long long b = __ballot(keep);
+            const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
+            const bool skip = grp == 0xffffu;
+            const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
+            if (skip && i < n) {
+                assign[i] = apv[u];
+                bnd[npad + i] = __double2float_rd(((double)lbv[u] - (double)dmx) * (1.0 - 0x1p-20));
+            }
+            const bool lead = (lane & 15) == 0 && live_step && !skip;
+            const unsigned long long lm = __ballot(lead);
+            if (lm) {
+                unsigned basepos = 0;
+                if (lane == 0) basepos = atomicAdd(&s_cnt, (unsigned)__popcll(lm));
+                basepos = __builtin_amdgcn_readfirstlane(basepos);
+                if (lead) s_todo[basepos + __popcll(lm & ((1ull << lane) - 1ull))] = (int)(i >> 4);
+            }
+            nskip += (unsigned)__popcll(__ballot((lane & 15) == 0 && live_step && skip));
         }
-        const bool lead = (lane & 15) == 0 && live_step && !skip;
-        const unsigned long long lm = __ballot(lead);
-        if (lm) {
-            unsigned basepos = 0;
-            if (lane == 0) basepos = atomicAdd(&s_cnt, (unsigned)__popcll(lm));
-            basepos = __builtin_amdgcn_readfirstlane(basepos);
-            if (lead) s_todo[basepos + __popcll(lm & ((1ull << lane) - 1ull))] = (int)(i >> 4);
-        }
-        nskip += (unsigned)__popcll(__ballot((lane & 15) == 0 && live_step && skip));
     }
+    if (lane == 0 && nskip) atomicAdd(&s_skip, nskip);
     __syncthreads();
-    if (threadIdx.x == 0) s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
+    if (threadIdx.x == 0) {
+        s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
+        if (s_skip) {
+            atomicAdd(counters + 3, s_skip);
+            atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)s_skip); // never reset: running total
+        }
+    }
     __syncthreads();
     for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo[s_pos + j] = s_todo[j];
-    if (lane == 0 && nskip) {
-        atomicAdd(counters + 3, nskip);
-        atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)nskip); // never reset: running total
-    }
 }
 
 // Per point: best / second-best estimate over the G tiles, certification, candidate assignment.
@@ -525,10 +535,10 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         const unsigned long long* __restrict__ cmax_bits,
                                                         int* __restrict__ assign, int* __restrict__ list,
                                                         unsigned int* __restrict__ nlist,
-                                                        float* __restrict__ bnd, long long npad, int skipping)
+                                                        float* __restrict__ bnd, long long npad, int skipping,
+                                                        const int* __restrict__ todo)
 {
-    // bnd != nullptr: write each point's new lower bound (k_center_drift's comment); skipping: k_bounds_steps marked
-    // the points of skipped steps with k = -2 in tile 0 and settled them
+    // bnd != nullptr: write each point's new lower bound (k_center_drift's comment)
     float* lbv = bnd ? bnd + npad : nullptr;
     const double cmax = __builtin_bit_cast(double, *cmax_bits);
     const double u = 0x1p-24;
@@ -536,9 +546,12 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     const double gacc = (double)(fixed_s + 1) * u * (1.0 + 1e-4);
     const double nu = 0x1p-45;
     unsigned nambig = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        if (skipping && scr_k[i] == -2) continue; // settled by k_bounds_steps
+    // skipping: k_bounds_steps has settled the skipped steps; only the listed ones (nlist[4] of them) are looked at
+    const long long total = skipping ? (long long)nlist[4] * 16 : n;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+         q += (long long)gridDim.x * blockDim.x) {
+        const long long i = skipping ? (long long)todo[q >> 4] * 16 + (q & 15) : q;
+        if (i >= n) continue;
         float b1 = __builtin_inff(), b2 = __builtin_inff();
         int bk = -1;
         for (int g = 0; g < G; g++) {
@@ -592,7 +605,17 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
         int bk = 0x7fffffff;
         for (int k = lane; k < K; k += 64) {
             double acc = 0.0;
-            for (long long j = j0; j < j1; j++) {
+            long long j = j0;
+            for (; j + 4 <= j1; j += 4) { // four independent gathers in flight; the additions stay in storage order
+                const double c0 = Cs[(size_t)ir[j] * K + k], c1 = Cs[(size_t)ir[j + 1] * K + k],
+                             c2 = Cs[(size_t)ir[j + 2] * K + k], c3 = Cs[(size_t)ir[j + 3] * K + k];
+                const double d0 = xval[j] - c0, d1 = xval[j + 1] - c1, d2 = xval[j + 2] - c2, d3 = xval[j + 3] - c3;
+                acc = acc + d0 * d0;
+                acc = acc + d1 * d1;
+                acc = acc + d2 * d2;
+                acc = acc + d3 * d3;
+            }
+            for (; j < j1; j++) {
                 const double d = xval[j] - Cs[(size_t)ir[j] * K + k];
                 acc = acc + d * d;
             }
