@@ -259,8 +259,12 @@ def test_adaptive_policy_soak(gpu_ctx, monkeypatch):
     g = torch.Generator(device="cuda")
     g.manual_seed(5)
     eng = LloydEngine(shard, K, d["gamma"])
-    ref = LloydEngine(shard, K, d["gamma"])
+    # the all-exact reference runs on a second shard object over the same device buffers: an exact call on the
+    # same shard would make the library forget the bounds it carries between screen calls
+    twin = Shard.from_device(gpu_ctx, d["p2"], d["jc"], d["ir"], d["x"], nnz=d["nnz"])
+    ref = LloydEngine(twin, K, d["gamma"])
     modes = set()
+    skipped = 0
     for it in range(60):
         phase = (it // 6) % 4
         if phase in (0, 1):
@@ -277,6 +281,7 @@ def test_adaptive_policy_soak(gpu_ctx, monkeypatch):
         path, listed = eng.last_path_info()
         ra, rn = eng.last_screen_rounds()
         modes.add("exact" if path == 0 else ("two-phase" if ra < rn else "plain"))
+        skipped += eng.last_screen_mode()[4]
         os.environ["SPKM_NO_SCREEN"] = "1"
         ref.assign_accumulate_step(c)
         torch.cuda.synchronize()
@@ -284,3 +289,40 @@ def test_adaptive_policy_soak(gpu_ctx, monkeypatch):
         assert torch.equal(eng.assign, ref.assign), f"call {it}"
         assert torch.equal(eng.mind, ref.mind), f"call {it}"
     assert "two-phase" in modes and "plain" in modes           # the policy really moved between modes
+    assert skipped > 0                                          # and the carried bounds skipped steps on the way
+
+
+@pytest.mark.parametrize("seed", range(12 * _SW))
+def test_lloyd_runs_random_shapes_equal_oracle_every_iteration(gpu_ctx, oracle, seed):
+    """Short Lloyd runs on drawn shapes (n not a multiple of 16 or 64, K with narrow / carried remainders, 1..64
+    entries per column): every iteration's assignments and min-distances equal the oracle's for the centres that went
+    in, while the library moves through its forms (plain / two-phase / hinted screen, carried bounds) on its own."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    rng = np.random.default_rng(9000 + seed)
+    p = int(rng.choice([64, 128, 256, 500, 1024]))
+    s_ = int(rng.integers(1, min(p, 64) + 1))
+    K = int(rng.choice([2, 3, 17, 33, 36, 40, 64, 68, 100]))
+    n = int(rng.integers(200, 3000))
+    X = random_csc(p, n, s_, seed=seed)
+    # clustered values so that runs converge: shift every column by one of K centres' entries
+    lab = (np.arange(n) * K) // n
+    cen0 = rng.standard_normal((p, K)) * 2.0
+    X = X.tocsc()
+    for i in range(n):
+        sl = slice(X.indptr[i], X.indptr[i + 1])
+        X.data[sl] = 0.3 * X.data[sl] + cen0[X.indices[sl], lab[i]]
+    gam = s_ / p
+    C = gam * cen0 + 0.05 * rng.standard_normal((p, K))        # near the ML-scaled planted centres
+    if seed % 3 == 0:
+        C[:, 1 % K] = C[:, 0]                                   # a duplicate centre: ties
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, X), K, gam)
+    cd = torch.tensor(np.ascontiguousarray(C.T), device="cuda")
+    forms = set()
+    for it in range(7):
+        cin = cd.cpu().numpy().T.copy()
+        eng.iterate(cd)
+        torch.cuda.synchronize()
+        forms.add(eng.last_screen_mode()[0])
+        ra, rd = oracle.assign(p, n, *parts(X), cin, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra), f"iteration {it}"
+        assert np.array_equal(eng.mind.cpu().numpy(), rd), f"iteration {it}"
