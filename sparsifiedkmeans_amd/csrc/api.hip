@@ -43,6 +43,11 @@ struct spkm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tlog;
     size_t tlog_used = 0;
     bool tlog_on = false;
+    // counting sort kept from the last screen call (perm / offs / items / nitems / nk describe THAT call's assignment):
+    // whose shard and shape it was; cleared by everything else that writes those buffers
+    const void* sort_owner = nullptr;
+    int sort_K = 0, sort_seg = 0;
+    long long sort_n = 0;
     bool tlog_both = false; // fused screen path: log the exact accumulation kernel too (pairs alternate)
     int assign_KT = 0, assign_G = 0; // of the last assign call
     int last_path = 0;               // 0 = exact tiled/generic, 1 = f32 screen + exact confirmation
@@ -104,6 +109,7 @@ struct spkm_shard {
 static int ensure(spkm_ctx* ctx, devbuf& b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return SPKM_OK;
+    ctx->sort_owner = nullptr; // (any reallocation: the kept counting sort may have lived there)
     if (b.p) HIP_TRY(hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -312,6 +318,7 @@ extern "C" int spkm_shard_create_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint
 extern "C" void spkm_shard_destroy(spkm_shard* s)
 {
     if (!s) return;
+    if (s->ctx && s->ctx->sort_owner == s) s->ctx->sort_owner = nullptr;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     if (s->xn1) (void)hipFree(s->xn1);
     if (s->xn2) (void)hipFree(s->xn2);
@@ -540,6 +547,7 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
 {
     if (!ctx || !s || !d_centers || !d_assign || !d_mind) return SPKM_ERR_NULL_ARG;
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;
@@ -661,6 +669,7 @@ extern "C" int spkm_assign_sparse_centers_dev(spkm_ctx* ctx, const spkm_shard* s
 {
     if (!ctx || !s || !d_centers || !d_mask || !d_assign || !d_mind) return SPKM_ERR_NULL_ARG;
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;
@@ -774,6 +783,7 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
 {
     if (!ctx || !s || !d_assign || !d_reduce) return SPKM_ERR_NULL_ARG;
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;
@@ -796,11 +806,11 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
             if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
             hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream,
                                (const unsigned long long*)ctx->nk.p, K, SEG_POINTS, (long long*)ctx->offs.p,
-                               (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p, (int*)ctx->nitems.p);
+                               (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p, (int*)ctx->nitems.p, (const unsigned*)nullptr);
             const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
             const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
             hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n,
-                               K, (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
+                               K, (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, (const unsigned*)nullptr);
             const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
             if (s->ir_bits == 16)
                 hipLaunchKernelGGL((k_accumulate_sorted<unsigned short>), dim3(ab), dim3(256), slab, ctx->stream,
@@ -936,7 +946,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
-    bool skipping = false;
+    bool skipping = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
             if (sm->hb) (void)hipFree(sm->hb);
@@ -952,7 +962,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             HIP_TRY(hipMalloc((void**)&sm->hb_centers, pk * 8));
             sm->hb_centers_len = pk;
         }
-        if (sm->hb_valid && sm->hb_K == K && sm->hb_gamma == gamma && !getenv("SPKM_NO_BOUNDS")) {
+        bounds_ok = sm->hb_valid && sm->hb_K == K && sm->hb_gamma == gamma;
+        if (bounds_ok && !getenv("SPKM_NO_BOUNDS")) {
             HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
                                d_centers, K, p, gamma, sm->hb + 3 * npad);
@@ -966,7 +977,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         sm->hb_valid = false; // until this call has gone through
     } else
         sm->hb_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->nk.p, 0, (size_t)K * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
                        0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
@@ -1018,25 +1028,44 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        skipping ? 1 : 0, (const int*)ctx->todo.p);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
-                       s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign);
-    if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls)
-        HIP_TRY(hipMemcpyAsync(sm->hb + 2 * npad, d_assign, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    // 4. counting sort by cluster
-    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
-                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p);
-    const int max_items = (int)(n / seg_points(n, ctx->num_cus)) + K + 1;
+                       s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
+                       bounds_ok ? (const int*)(sm->hb + 2 * npad) : (const int*)nullptr, (unsigned*)ctx->nlist.p + 5);
+    // 4. counting sort by cluster.  When the context still holds the sort of THIS shard's previous screen call (same
+    // K, n, segment length; nothing else has written those buffers since) and no assignment changed -- nlist[5],
+    // counted on the device by the combine and list kernels against the library's copy of the previous assignment --
+    // the histogram, plan and scatter kernels return at once and the previous permutation is used again.
+    // SPKM_NO_SORT_REUSE=1: A/B switch.
+    const int seg = seg_points(n, ctx->num_cus);
+    const int max_items = (int)(n / seg) + K + 1;
     if ((rc = ensure(ctx, ctx->perm, (size_t)n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->offs, (size_t)(K + 1) * 8))) return rc;
     if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
     if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
+    const bool reuse = quad && bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n &&
+                       ctx->sort_seg == seg && !getenv("SPKM_NO_SORT_REUSE");
+    const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
+    ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
+    if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls)
+        hipLaunchKernelGGL(k_copy_i32_gated, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0,
+                           ctx->stream, (int*)(sm->hb + 2 * npad), (const int*)d_assign, n, gate);
+    hipLaunchKernelGGL(k_zero_u64_gated, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                       (unsigned long long*)ctx->nk.p, K, gate);
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
+                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p, gate);
     hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
-                       seg_points(n, ctx->num_cus), (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
-                       (int*)ctx->nitems.p);
+                       seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                       (int*)ctx->nitems.p, gate);
     const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
     hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
-                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
+                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate);
+    if (quad) {
+        ctx->sort_owner = sm;
+        ctx->sort_K = K;
+        ctx->sort_n = n;
+        ctx->sort_seg = seg;
+    }
     // 5. exact distance to the assigned centroid + per-cluster accumulation
     int threads = 1024;
     if (const char* ev = getenv("SPKM_ACC_THREADS")) threads = atoi(ev) == 512 ? 512 : 1024; // A/B aid
@@ -1475,6 +1504,7 @@ extern "C" int spkm_dense_accumulate_dev(spkm_ctx* ctx, uint64_t p64, uint64_t n
 {
     if (!ctx || !d_X || !d_assign || !d_sums || !d_counts) return SPKM_ERR_NULL_ARG;
     if (K64 == 0 || K64 > 65536 || p64 == 0 || p64 > (1u << 24) || n64 > 0x7fffffffull) return SPKM_ERR_UNSUPPORTED;
+    ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
     if (n64 == 0) return SPKM_OK;
     const int p = (int)p64, K = (int)K64;
@@ -1490,14 +1520,14 @@ extern "C" int spkm_dense_accumulate_dev(spkm_ctx* ctx, uint64_t p64, uint64_t n
     if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->dn_nk.p, 0, (size_t)K * 8, ctx->stream));
     hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
-                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->dn_nk.p);
+                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->dn_nk.p, (const unsigned*)nullptr);
     hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->dn_nk.p, K, seg,
                        (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
-                       (int*)ctx->nitems.p);
+                       (int*)ctx->nitems.p, (const unsigned*)nullptr);
     const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
     hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
-                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p);
+                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, (const unsigned*)nullptr);
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
     hipLaunchKernelGGL(k_dense_accumulate, dim3(ab), dim3(256), 0, ctx->stream, d_X, p, (const int*)ctx->perm.p,
                        (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)ctx->nitems.p, d_sums);

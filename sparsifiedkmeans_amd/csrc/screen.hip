@@ -524,6 +524,21 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo[s_pos + j] = s_todo[j];
 }
 
+// dst = src / dst = 0 unless *gate == 0 (gate == nullptr: always)
+__global__ __launch_bounds__(256) void k_copy_i32_gated(int* __restrict__ dst, const int* __restrict__ src, long long n,
+                                                        const unsigned* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0u) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+__global__ void k_zero_u64_gated(unsigned long long* __restrict__ dst, int n, const unsigned* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0u) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = 0ull;
+}
+
 // Per point: best / second-best estimate over the G tiles, certification, candidate assignment.
 // Uncertified points are appended to list[] (count in *nlist); a tile that reports "no candidate"
 // (+inf, +inf, -1) can never certify.
@@ -538,6 +553,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         float* __restrict__ bnd, long long npad, int skipping,
                                                         const int* __restrict__ todo)
 {
+    // nlist[5]: points whose (tentative) assignment differs from the previous call's (the library's copy in bnd)
+    const int* aprev = bnd ? reinterpret_cast<const int*>(bnd + 2 * npad) : nullptr;
+    bool changed = false;
     // bnd != nullptr: write each point's new lower bound (k_center_drift's comment)
     float* lbv = bnd ? bnd + npad : nullptr;
     const double cmax = __builtin_bit_cast(double, *cmax_bits);
@@ -570,6 +588,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         const double e1 = E + gacc * r1 + 1e-20, e2 = E + gacc * r2 + 1e-20;
         const bool certified = (bk >= 0) && ((r1 + e1) * (1.0 + nu) < (r2 - e2) * (1.0 - nu));
         assign[i] = bk >= 0 ? bk : 0;
+        if (aprev && aprev[i] != (bk >= 0 ? bk : 0)) changed = true;
         if (lbv) lbv[i] = certified ? fmaxf(0.f, __double2float_rd((r2 - e2) * (1.0 - nu))) : 0.f;
         if (!certified) {
             const unsigned at = atomicAdd(nlist, 1u);
@@ -582,6 +601,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     }
     for (int off = 32; off > 0; off >>= 1) nambig += __shfl_down(nambig, off);
     if ((threadIdx.x & 63) == 0 && nambig) atomicAdd(nlist + 1, nambig);
+    if (__any(changed) && (threadIdx.x & 63) == 0) atomicAdd(nlist + 5, 1u);
 }
 
 // Listed points: exact reference arithmetic over all K centroids (row-major scaled centres Cs in
@@ -591,7 +611,8 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      const double* __restrict__ xval, const double* __restrict__ Cs,
                                                      int K, int fixed_s, const int* __restrict__ list,
                                                      const unsigned int* __restrict__ nlist,
-                                                     int* __restrict__ assign)
+                                                     int* __restrict__ assign, const int* __restrict__ aprev,
+                                                     unsigned* __restrict__ changed)
 {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -627,14 +648,20 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
             const int ok = __shfl_xor(bk, off);
             if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
         }
-        if (lane == 0) assign[i] = bk;
+        if (lane == 0) {
+            assign[i] = bk;
+            if (aprev && aprev[i] != bk) atomicAdd(changed, 1u);
+        }
     }
 }
 
+// gate != nullptr: the kernel does nothing when *gate == 0 (no assignment changed since the call whose counting sort
+// is still in the context's buffers -- spkm_assign_accumulate_dev)
 __global__ __launch_bounds__(256) void k_hist(const int* __restrict__ assign, long long n, int K,
-                                              unsigned long long* __restrict__ nk)
+                                              unsigned long long* __restrict__ nk, const unsigned* __restrict__ gate)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate != nullptr && *gate == 0u) return;
     unsigned int* hist = reinterpret_cast<unsigned int*>(smem);
     for (int k = threadIdx.x; k < K; k += blockDim.x) hist[k] = 0;
     __syncthreads();
@@ -815,9 +842,9 @@ template __global__ void k_screen_tile<unsigned short>(const unsigned short*, co
 template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const float*, const float*, int, int, int,
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*);
+    const double*, int, int, const int*, const unsigned int*, int*, const int*, unsigned*);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*);
+    const double*, int, int, const int*, const unsigned int*, int*, const int*, unsigned*);
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));

@@ -147,9 +147,11 @@ __global__ __launch_bounds__(256) void k_accumulate_atomic(const long long* __re
 __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long* __restrict__ nk, int K, int seg,
                                                        long long* __restrict__ offs,
                                                        unsigned long long* __restrict__ cursor,
-                                                       int4* __restrict__ items, int* __restrict__ nitems)
+                                                       int4* __restrict__ items, int* __restrict__ nitems,
+                                                       const unsigned* __restrict__ gate)
 {
     __shared__ long long s_pts[256];
+    if (gate != nullptr && *gate == 0u) return; // nothing changed: the previous plan stands (see k_hist)
     __shared__ int s_items[256];
     __shared__ long long s_run_pts;
     __shared__ int s_run_items;
@@ -193,9 +195,10 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
 // perm[cursor[assign[i]]++] = i, with one global atomic per (block, cluster) via an LDS histogram.
 __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restrict__ assign, long long n, int K,
                                                             unsigned long long* __restrict__ cursor,
-                                                            int* __restrict__ perm)
+                                                            int* __restrict__ perm, const unsigned* __restrict__ gate)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate != nullptr && *gate == 0u) return; // nothing changed: the previous permutation stands (see k_hist)
     unsigned int* cnt = reinterpret_cast<unsigned int*>(smem);             // K
     unsigned long long* base = reinterpret_cast<unsigned long long*>(cnt + ((K + 1) & ~1)); // K
     const int tid = threadIdx.x;

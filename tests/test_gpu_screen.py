@@ -382,3 +382,50 @@ def test_carried_bounds_skip_steps_and_stay_exact(gpu_ctx, oracle):
     assert skipped[1] > 0.5 * (n // 16) and skipped[2] > 0.5 * (n // 16), skipped
     assert skipped[3] < skipped[2], skipped
     assert skipped[4] > 0, skipped
+
+
+def test_kept_counting_sort_is_reused_only_when_it_is_still_this_call_s(gpu_ctx, oracle):
+    """Converged calls reuse the previous call's counting sort (no assignment changed: the histogram / plan / scatter
+    kernels return at once).  The sort lives in buffers of the CONTEXT: calls on another shard, the non-fused
+    entry points and a change of assignments in between must all lead to correct sums, counts and cluster sizes."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    K = 40
+    dA = synth.sparsified_gmm_host(p=256, n=6000, K=K, gamma=0.2, seed=21, fwht=oracle.fwht)
+    dB = synth.sparsified_gmm_host(p=256, n=4500, K=K, gamma=0.2, seed=22, fwht=oracle.fwht)
+
+    def centres(d):
+        Y, gam = d["Y"], d["gamma"]
+        c = np.zeros((d["p2"], K))
+        for k in range(K):
+            Yk = Y[:, d["labels"] == k]
+            c[:, k] = gam * np.asarray(Yk.sum(axis=1)).ravel() / (np.asarray((Yk != 0).sum(axis=1)).ravel() + 1e-16)
+        return c
+
+    cA, cB = centres(dA), centres(dB)
+    eA = LloydEngine(Shard.from_scipy(gpu_ctx, dA["Y"]), K, dA["gamma"])
+    eB = LloydEngine(Shard.from_scipy(gpu_ctx, dB["Y"]), K, dB["gamma"])
+
+    def call(e, d, c):
+        e.assign_accumulate_step(torch.tensor(np.ascontiguousarray(c.T), device="cuda"))
+        torch.cuda.synchronize()
+        _check(e, oracle, d["Y"], c, d["gamma"])
+
+    call(eA, dA, cA)
+    call(eA, dA, cA)                                        # reuse possible from here on
+    call(eA, dA, cA)
+    call(eB, dB, cB)                                        # another shard writes the context's sort buffers
+    call(eA, dA, cA)
+    call(eB, dB, cB)
+    call(eB, dB, cB)
+    t = torch.tensor(np.ascontiguousarray(cA.T), device="cuda")
+    eA.assign_step(t)                                       # the non-fused entry points use the same buffers
+    eA.accumulate_step()
+    torch.cuda.synchronize()
+    call(eA, dA, cA)
+    call(eA, dA, cA)
+    moved = cA.copy()
+    moved[:, 5] = cA[:, 6] * 1.001                          # assignments change: the sort must be redone
+    call(eA, dA, moved)
+    call(eA, dA, moved)
+    call(eA, dA, cA)
