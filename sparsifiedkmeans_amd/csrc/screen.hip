@@ -949,7 +949,6 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
         if (vbase < nv) {
             const int base = todo != nullptr ? todo[vbase >> 4] << 4 : vbase;
             const int i = base + ps;
-            constexpr bool with_extra = PL == 5;
             // step-major screen copy (k_screen_reorder): round r of this step is 64 consecutive elements
             const float* xp = xval + (size_t)(base >> 4) * (NR * 64) + lane;
             const IR* rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
@@ -975,12 +974,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     if constexpr (NR > r && COND(r)) {                                                                      \
         const int xi = __builtin_bit_cast(int, x##r);                                                       \
         const int ro = o##r << 4; /* stored: row * 8 ^ swizzle -> row * 128 | swizzle * 16 */              \
-        if (PL == 5 && !with_extra) {                                                                       \
-            if (r < NR - 1 || nvl == 4) quad_round<4, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);    \
-            else if (nvl == 3) quad_round<3, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);             \
-            else if (nvl == 2) quad_round<2, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);             \
-            else quad_round<1, 4>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);                           \
-        } else if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);   \
+        if (r < NR - 1 || nvl == 4) quad_round<4, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);        \
         else if (nvl == 3) quad_round<3, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);            \
         else if (nvl == 2) quad_round<2, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);            \
         else quad_round<1, PL>(xi, ro, off0, off1 - off0, ce, acc0, acc1, acc2, acc3, acc4);                          \
@@ -1021,7 +1015,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                             consider(h ? acc[a].y : acc[a].x, PL >= 4 ? k0 + ((a < 2 ? off0 : off1) >> 2) + 2 * (a & 1) + h
                                                                       : k0 + 2 * PL * l4 + 2 * a + h);
                     }
-                    if (PL == 5 && with_extra) consider(acc4, extra_k0 + l4);
+                    if (PL == 5) consider(acc4, extra_k0 + l4);
                 } else {
 #pragma unroll
                     for (int a = 0; a < NPAIR; a++) {
@@ -1033,7 +1027,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                             consider((k < K) ? v : __builtin_inff(), k);
                         }
                     }
-                    if (PL == 5 && with_extra) {
+                    if (PL == 5) {
                         const int k = extra_k0 + l4;
                         consider((k < K) ? acc4 : __builtin_inff(), k);
                     }
