@@ -178,9 +178,11 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * info[1..4] = that call's counters: points listed for exact evaluation, points with a runner-up within 2.25x
  * (a bound: over-counts in the two-phase forms), (16-point step, centroid tile) pairs finished early by the
  * hinted form, 16-point steps skipped altogether on the bounds carried from the previous call (see
- * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context.
+ * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context;
+ * info[6] = of info[4], the steps skipped only because the centroids that moved most were bounded explicitly
+ * (a narrow screen tile over the 8 largest movers; SPKM_NO_JUMPERS=1 disables it); info[7] = 0 (reserved).
  * Blocks on the stream. */
-int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[6]);
+int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[8]);
 
 /* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
  * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;

@@ -33,10 +33,11 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, todo2, bmapj, t32j;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
+    int bmapj_key = -1, bmapj_blocks = 0; // block map of the one-tile jumper screen
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     // optional per-launch timing log of the dominant assignment kernel (bench.py)
@@ -54,6 +55,7 @@ struct spkm_ctx {
     unsigned last_listed = 0;        // points sent to the exact list by the last screen (read lazily)
     int last_rounds_all = 0, last_rounds = 0; // rounds for all centroids / total rounds of the last 4-lane screen call
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
+    bool last_skipping = false;      // the last screen call ran the carried-bounds test
     char errmsg[256] = {0};
 };
 
@@ -86,6 +88,7 @@ struct spkm_shard {
     const double* hint_ptr = nullptr;
     bool hint_pending = false;
     int hint_cooldown = 0;
+    int hint_fail_streak = 0; // consecutive hinted calls that did not pay: the pause doubles (2, 4, 8, 16 calls)
     // bounds carried between screen calls (screen.hip, k_center_drift): ub | lb | assignment | drift table, the
     // centroids of the call that produced them, and whether they describe this shard's previous call
     float* hb = nullptr;
@@ -95,6 +98,8 @@ struct spkm_shard {
     int hb_K = 0;
     double hb_gamma = 0.0;
     bool hb_valid = false;
+    bool skip_pending = false; // the call whose counters are pending ran the bounds test
+    bool j_on = true;          // explicit bounds for the largest movers (k_pick_jumpers): on until the plain test suffices
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -181,7 +186,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->todo2, &ctx->bmapj, &ctx->t32j};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -346,7 +351,10 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->prune_pending_a = 0;
     s->hint_ptr = nullptr;
     s->hint_cooldown = 0;
+    s->hint_fail_streak = 0;
     s->hint_pending = false;
+    s->skip_pending = false;
+    s->j_on = true;
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
     return SPKM_OK;
@@ -423,11 +431,14 @@ static int build_blockmap(spkm_ctx* ctx, int G)
 // c % NX) in the same order, so a chunk is fetched from HBM once and re-read from that XCD's L2.
 //   entry: tile, stream = index among the tile's workgroups on this XCD, nstreams = their number,
 //          pad = NX | xcd << 8 | pairs-per-lane << 16
-static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
+static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bool jumper_slot = false)
 {
+    devbuf& buf = jumper_slot ? ctx->bmapj : ctx->bmapq;
+    int& slot_key = jumper_slot ? ctx->bmapj_key : ctx->bmapq_key;
+    int& slot_blocks = jumper_slot ? ctx->bmapj_blocks : ctx->bmapq_blocks;
     const int NB = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const int key = G * 64 + pl_last * 8 + 1000003 * rounds + (getenv("SPKM_QUAD_W") ? 7 : 0);
-    if (ctx->bmapq_key == key && ctx->bmapq_blocks == NB) return SPKM_OK;
+    if (slot_key == key && slot_blocks == NB) return SPKM_OK;
     const int NX = (NB % 8 == 0) ? 8 : 1;
     const int per = NB / NX;
     if (per < G) return SPKM_ERR_UNSUPPORTED;
@@ -463,11 +474,11 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
                 e.pad = NX | (x << 8) | ((g == G - 1 ? pl_last : 4) << 16);
             }
     }
-    int rc = ensure(ctx, ctx->bmapq, NB * sizeof(spkm_blockmap));
+    int rc = ensure(ctx, buf, NB * sizeof(spkm_blockmap));
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->bmapq.p, bm.data(), NB * sizeof(spkm_blockmap), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(buf.p, bm.data(), NB * sizeof(spkm_blockmap), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->bmapq_key = key; ctx->bmapq_blocks = NB;
+    slot_key = key; slot_blocks = NB;
     return SPKM_OK;
 }
 
@@ -935,24 +946,25 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->list, (size_t)n * 4))) return rc;
     {
         const bool fresh = ctx->nlist.p == nullptr;
-        if ((rc = ensure(ctx, ctx->nlist, 64))) return rc;
-        if (fresh) HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 64, ctx->stream)); // [8..9]: running total of skipped steps
+        if ((rc = ensure(ctx, ctx->nlist, 256))) return rc;
+        if (fresh) HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 256, ctx->stream)); // [8..9]: running total of skipped steps
     }
     if ((rc = ensure(ctx, ctx->ct, pk * 8))) return rc;
     if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 16, ctx->stream)); // [0] all tiles, [1] the jumper tile
     HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 32, ctx->stream));
+    HIP_TRY(hipMemsetAsync((char*)ctx->nlist.p + 40, 0, 128 - 40, ctx->stream)); // (not the running total at [8..9])
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
-    bool skipping = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
+    bool skipping = false, jumpers = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
             if (sm->hb) (void)hipFree(sm->hb);
             sm->hb = nullptr;
             sm->hb_valid = false;
-            HIP_TRY(hipMalloc((void**)&sm->hb, ((size_t)3 * npad + 65536 + 2) * 4));
+            HIP_TRY(hipMalloc((void**)&sm->hb, ((size_t)3 * npad + 65536 + 2 + NJUMP + 6) * 4));
             sm->hb_npad = npad;
         }
         if (sm->hb_centers_len < pk) {
@@ -973,6 +985,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p);
             skipping = true;
+            // while a few centres still jump and the rest have settled, bound the jumpers explicitly (screen.hip,
+            // k_pick_jumpers): a narrow screen tile over them on the steps the plain test left, then a second test.
+            // On until the plain test alone skips most steps (lagging counters); SPKM_NO_JUMPERS=1: A/B switch.
+            jumpers = K >= 3 * NJUMP && sm->j_on && !getenv("SPKM_NO_JUMPERS") &&
+                      (size_t)(p + 1) * SCREEN_KT * 4 + 16 <= ctx->lds_max;
         }
         sm->hb_valid = false; // until this call has gone through
     } else
@@ -980,7 +997,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
                        0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
-                       (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0);
+                       (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0, (const int*)nullptr);
     hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0,
                        ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
     // 1. screen
@@ -996,6 +1013,44 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         HIP_TRY(timing_begin(ctx));
         const IR* a_ir = quad ? (const IR*)s->irs : (const IR*)s->ir;
         const float* a_xf = quad ? (const float*)s->xfs : (const float*)s->xf;
+        if (jumpers) {
+            // the jumper tile: pick, lay out (one narrow tile of NJUMP centroids), screen the listed steps with the
+            // PLAIN kernel, test again, commit the shorter list.  Results go through tile 0's slots, which the main
+            // screen overwrites afterwards for the steps that stay.
+            unsigned* cn = (unsigned*)ctx->nlist.p;
+            float* dl = sm->hb + 3 * npad;
+            hipLaunchKernelGGL(k_pick_jumpers, dim3(1), dim3(256), 0, ctx->stream, dl, K, cn);
+            hipLaunchKernelGGL(k_jumper_list_length, dim3(1), dim3(1), 0, ctx->stream, cn, 28);
+            const size_t jfloats = (size_t)(p + 1) * SCREEN_KT;
+            if ((rc = ensure(ctx, ctx->t32j, jfloats * 4))) return rc;
+            if ((rc = ensure(ctx, ctx->todo2, (size_t)(npad / 16 + 1) * 4))) return rc;
+            hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((jfloats + 255) / 256, 2048)), dim3(256), 0,
+                               ctx->stream, d_centers, p, K, 1, gamma, (float*)ctx->t32j.p,
+                               (unsigned long long*)ctx->cmax.p + 1, 1, 1, (const int*)(dl + K + 2));
+            if ((rc = build_blockmap_quad(ctx, 1, 1, q_rounds, true))) return rc;
+            const void* kj = screen_quad_kernel<IR>(q_rounds, false);
+            const size_t ldsj = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
+            HIP_TRY(hipFuncSetAttribute(kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, ldsj)));
+            const float* j_t = (const float*)ctx->t32j.p;
+            int j_p = p, j_n = (int)n, j_s = s->fixed_s, j_K = NJUMP, j_chunk = (int)chunk, j_extra = 0;
+            const spkm_blockmap* j_bm = (const spkm_blockmap*)ctx->bmapj.p;
+            float* j_m1 = (float*)ctx->scr_m1.p;
+            float* j_m2 = (float*)ctx->scr_m2.p;
+            int* j_k = (int*)ctx->scr_k.p;
+            const double* j_hint = nullptr;
+            float j_hc = 0.f;
+            unsigned* j_cnt = cn + 24; // its list length sits at [24 + 4]
+            const int* j_todo = (const int*)ctx->todo.p;
+            void* jargs[] = {&a_ir, &a_xf, &j_t, &j_p, &j_n, &j_s, &j_K, &j_bm, &j_chunk, &j_m1, &j_m2, &j_k, &j_extra,
+                             &j_hint, &j_hc, &j_cnt, &j_todo};
+            HIP_TRY(hipLaunchKernel(kj, dim3(ctx->bmapj_blocks), dim3(1024), jargs, ldsj, ctx->stream));
+            hipLaunchKernelGGL(k_bounds_steps2, dim3(2048), dim3(256), 0, ctx->stream, sm->hb, npad, n, K,
+                               (const int*)ctx->todo.p, (int*)ctx->todo2.p, cn, (const float*)ctx->scr_m1.p,
+                               (const double*)s->xn1, (const double*)s->xn2,
+                               (const unsigned long long*)ctx->cmax.p + 1, s->fixed_s, (int*)d_assign);
+            hipLaunchKernelGGL(k_commit_list, dim3(1), dim3(1), 0, ctx->stream, cn);
+            if (kj == kern) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         const float* a_t = (const float*)ctx->t32.p;
         int a_p = p, a_n = (int)n, a_s = s->fixed_s, a_K = K, a_chunk = (int)chunk;
         const spkm_blockmap* a_bm = (const spkm_blockmap*)(quad ? ctx->bmapq.p : ctx->bmap.p);
@@ -1012,20 +1067,21 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float a_hc = 2.0f; // the other centroids' partial sums must exceed 2x the previous min-distance squared
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
-        const int* a_todo = skipping ? (const int*)ctx->todo.p : nullptr;
+        const int* a_todo = skipping ? (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p) : nullptr;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
                         &a_hint, &a_hc, &a_cnt, &a_todo};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(timing_end(ctx));
+    ctx->last_skipping = skipping;
     // 2. certification, 3. exact evaluation of the uncertified points
     const int cb = (int)std::min<long long>(4096, (n + 255) / 256);
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), 0, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
-                       skipping ? 1 : 0, (const int*)ctx->todo.p);
+                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p));
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1128,6 +1184,8 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         ctx->last_listed = sm->h_nlist[0];
         const double listed = (double)sm->h_nlist[0], ambig = (double)sm->h_nlist[1], nn = (double)s->n;
         if (listed > 0.05 * nn) sm->exact_cooldown = 8;
+        // explicit bounds for the largest movers: worth their pass until the plain test alone skips most steps
+        if (sm->skip_pending) sm->j_on = ((double)sm->h_nlist[3] - (double)sm->h_nlist[6]) < 0.5 * (nn / 16.0);
         const int nr = (s->fixed_s + 3) / 4;
         const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
         if (sm->hint_pending) {
@@ -1135,10 +1193,15 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             // while the hints do not mislead (stale buffer: many listed points)
             // (steps skipped on the carried bounds never got as far as their hints)
             const double steps = std::max(0.0, nn / 16.0 - (double)sm->h_nlist[3]) * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
-            if (listed > 0.005 * nn || ((double)sm->h_nlist[2] < 0.05 * steps && steps > 0.01 * nn / 16.0)) sm->hint_cooldown = 16;
-            // runner-up bounds of early-finished steps are partial sums, so `ambig` over-counts: still small
-            // means the unconditional form (no hint loads, no second evaluation) is safe to try
-            else if (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) sm->prune_next_a = a_prune;
+            if (listed > 0.005 * nn || ((double)sm->h_nlist[2] < 0.05 * steps && steps > 0.01 * nn / 16.0)) {
+                sm->hint_fail_streak = std::min(sm->hint_fail_streak + 1, 4);
+                sm->hint_cooldown = 1 << sm->hint_fail_streak; // early iterations mislead briefly, not for 16 calls
+            } else {
+                sm->hint_fail_streak = 0;
+                // runner-up bounds of early-finished steps are partial sums, so `ambig` over-counts: still small
+                // means the unconditional form (no hint loads, no second evaluation) is safe to try
+                if (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) sm->prune_next_a = a_prune;
+            }
         } else if (sm->prune_pending_a == 0)
             sm->prune_next_a = (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) ? a_prune : 0;
         else if (listed > 0.005 * nn) { sm->prune_next_a = 0; sm->prune_cooldown = 16; }
@@ -1170,11 +1233,12 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
         }
         if (!sm->nlist_pending) {
-            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 32, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
             sm->nlist_pending = true;
             sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
             sm->hint_pending = hint != nullptr;
+            sm->skip_pending = ctx->last_skipping;
         }
         if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1196,11 +1260,11 @@ extern "C" int spkm_last_screen_rounds(spkm_ctx* ctx, int64_t info[2])
 }
 
 // Form and counters of the last screen call.  Blocks on the stream (diagnostics, not the hot path).
-extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[6])
+extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
 {
     if (!ctx || !info) return SPKM_ERR_NULL_ARG;
     info[0] = -1;
-    info[1] = info[2] = info[3] = info[4] = info[5] = 0;
+    info[1] = info[2] = info[3] = info[4] = info[5] = info[6] = info[7] = 0;
     if (ctx->last_path == 1 && ctx->nlist.p) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1209,6 +1273,7 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[6])
         info[0] = ctx->last_mode;
         for (int j = 0; j < 4; j++) info[1 + j] = v[j];
         info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
+        info[6] = v[6];
     }
     return SPKM_OK;
 }

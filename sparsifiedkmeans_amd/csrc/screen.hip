@@ -35,6 +35,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #define SCREEN_KT 32 // centroids per tile (two per lane of a 16-lane row)
+#define NJUMP 8      // centroids bounded explicitly when they move much more than the rest (k_pick_jumpers)
 
 // T32[g][r][kk] = -fl32(C[(g*32+kk)*p + r] / gamma), row p zero; cmax_bits = max |C/gamma| (f64 bits, atomicMax).
 // 4-lanes-per-point kernel only:
@@ -46,8 +47,10 @@
 //    q ^ ((r >> 1) & 3) (the kernel's stored row ids carry the same two bits, k_screen_reorder).
 __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
                                  float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits, int pl_last,
-                                 int swz)
+                                 int swz, const int* __restrict__ kmap)
 {
+    // kmap != nullptr (one narrow tile, G = 1, pl_last = 1): slot kk < NJUMP holds centroid kmap[kk] -- the tile of
+    // the centroids that moved most since the previous call (k_pick_jumpers)
     const size_t total = (size_t)G * (p + 1) * SCREEN_KT;
     double mx = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -64,6 +67,7 @@ __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int
         } else if (g == G - 1 && pl_last < 4) {
             kk &= 15;
             k = g * SCREEN_KT + kk;
+            if (kmap != nullptr) k = kk < NJUMP ? kmap[kk] : K;
         }
         float v = 0.f;
         if (r < p && k < K) {
@@ -457,6 +461,133 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
 // test (k_center_drift's comment) is settled here: assignment = the previous one, lower bound moved by the largest
 // drift.  Every other step is appended to todo[] (its index; order within the list does not matter) -- the list
 // the screen kernel and k_combine_screen iterate; counters[4] = length, counters[3] = steps skipped.
+// The carried bounds use ONE drift for "all other centroids"; while a few centres still jump and the rest have
+// settled, that single maximum keeps every point on the screen.  So the NJUMP largest movers are singled out:
+//     delta[K + 1] = largest drift among the others,  jlist = (int*)(delta + K + 2)[0..NJUMP),
+//     flags[7]     = 1 when that is worth it: the others' maximum is at most a quarter of the overall maximum.
+// A narrow screen tile over the jumpers (k_screen_quad on the list of steps the plain test left) then gives every
+// point a certified lower bound of its distance to each of them, and k_bounds_steps2 repeats the test with
+// min(lb - delta[K + 1], that bound).  One workgroup.
+__global__ __launch_bounds__(256) void k_pick_jumpers(float* __restrict__ delta, int K, unsigned* __restrict__ flags)
+{
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ int chosen[NJUMP];
+    int* jl = reinterpret_cast<int*>(delta + K + 2);
+    const int tid = threadIdx.x;
+    for (int r = 0; r <= NJUMP; r++) { // round NJUMP: the maximum of what is left
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+        for (int k = tid; k < K; k += 256) {
+            bool taken = false;
+            for (int q = 0; q < r && q < NJUMP; q++) taken |= chosen[q] == k;
+            const float v = delta[k];
+            if (!taken && (v > bv || (v == bv && k < bi))) { bv = v; bi = k; }
+        }
+        sv[tid] = bv;
+        si[tid] = bi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off && (sv[tid + off] > sv[tid] || (sv[tid + off] == sv[tid] && si[tid + off] < si[tid]))) {
+                sv[tid] = sv[tid + off];
+                si[tid] = si[tid + off];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (r < NJUMP) { chosen[r] = si[0]; jl[r] = si[0] < K ? si[0] : 0; }
+            else {
+                const float rest = sv[0] >= 0.f ? sv[0] : 0.f, all = delta[K];
+                delta[K + 1] = rest;
+                flags[7] = (K >= 3 * NJUMP && all > 0.f && rest <= 0.25f * all) ? 1u : 0u; // false for NaN / inf rest
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// after k_bounds_steps: the jumper tile runs over the whole list of remaining steps, or over nothing
+__global__ void k_jumper_list_length(unsigned* __restrict__ counters, int to)
+{
+    counters[to] = counters[7] ? counters[4] : 0u;
+}
+__global__ void k_commit_list(unsigned* __restrict__ counters) { counters[4] = counters[20]; }
+
+// Second test of the steps on todo[] (16 threads per step), with the jumpers bounded by the narrow tile's result
+// m1J (smallest f32 estimate over the NJUMP jumpers; r - eps(r) is a certified lower bound of the distance to each of
+// them, k_combine_screen's error bound with the jumpers' own max |c|): steps that pass are settled as in
+// k_bounds_steps, the others go to todo2[] (length in counters[20]).  Without flags[7] every step goes to todo2.
+__global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, long long npad, long long n, int K,
+                                                       const int* __restrict__ todo, int* __restrict__ todo2,
+                                                       unsigned* __restrict__ counters, const float* __restrict__ m1J,
+                                                       const double* __restrict__ xn1, const double* __restrict__ xn2,
+                                                       const unsigned long long* __restrict__ cmaxJ_bits, int fixed_s,
+                                                       int* __restrict__ assign)
+{
+    constexpr int CH = 1024; // steps per workgroup pass: one global atomic each
+    __shared__ int s_todo[CH];
+    __shared__ unsigned s_cnt, s_pos, s_skip;
+    const unsigned ntodo = counters[4];
+    if (counters[7] == 0u) { // nothing to bound explicitly: the list stays as it is
+        for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < ntodo; q += gridDim.x * 256u) todo2[q] = todo[q];
+        if (blockIdx.x == 0 && threadIdx.x == 0) counters[20] = ntodo;
+        return;
+    }
+    const float rest = bnd[3 * npad + K + 1];
+    const double cmax = __builtin_bit_cast(double, *cmaxJ_bits);
+    const double u = 0x1p-24, eu = (2.0 * u + u * u) * (1.0 + 1e-9), gacc = (double)(fixed_s + 1) * u * (1.0 + 1e-4),
+                 nu = 0x1p-45;
+    const int lane = threadIdx.x & 63;
+    for (unsigned c0 = blockIdx.x * CH; c0 < ntodo; c0 += gridDim.x * CH) {
+        if (threadIdx.x == 0) { s_cnt = 0; s_skip = 0; }
+        __syncthreads();
+        for (unsigned q0 = c0; q0 < c0 + CH && q0 < ntodo; q0 += 16) {
+            const unsigned q = q0 + (threadIdx.x >> 4);
+            const bool live = q < ntodo && q < c0 + CH;
+            const long long step = live ? todo[q] : 0;
+            const long long i = step * 16 + (threadIdx.x & 15);
+            bool keep = true;
+            float newlb = 0.f;
+            int ap = 0;
+            if (live && i < n) {
+                const float ubi = bnd[i], lbi = bnd[npad + i];
+                ap = reinterpret_cast<const int*>(bnd)[2 * npad + i];
+                const float da = bnd[3 * npad + ap];
+                const double W = (xn2[i] + 2.0 * cmax * xn1[i] + (double)fixed_s * cmax * cmax) * (1.0 + 1e-9);
+                const double E = eu * sqrt(W) * (1.0 + 1e-9);
+                const double r = sqrt((double)m1J[i]);
+                const double mj = (r - (E + gacc * r + 1e-20)) * (1.0 - nu);
+                const double lo = fmin((double)lbi - (double)rest, mj); // NaN mj: guarded below
+                keep = mj == mj && (double)(ubi + da) * 1.000001 < lo * 0.999999;
+                newlb = __double2float_rd(lo * (1.0 - 0x1p-20));
+            }
+            const unsigned long long b = __ballot(keep);
+            const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
+            const bool skip = live && grp == 0xffffu;
+            if (skip && i < n) {
+                assign[i] = ap;
+                bnd[npad + i] = newlb;
+            }
+            if (live && (threadIdx.x & 15) == 0) {
+                if (skip) atomicAdd(&s_skip, 1u);
+                else s_todo[atomicAdd(&s_cnt, 1u)] = (int)step;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_pos = s_cnt ? atomicAdd(counters + 20, s_cnt) : 0u;
+            if (s_skip) {
+                atomicAdd(counters + 3, s_skip);
+                atomicAdd(counters + 6, s_skip);
+                atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)s_skip);
+            }
+        }
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo2[s_pos + j] = s_todo[j];
+        __syncthreads();
+    }
+}
+
 #define BOUNDS_SPAN 16384 // points per workgroup of k_bounds_steps (1024 steps)
 __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
                                                       int* __restrict__ assign,
@@ -1046,6 +1177,8 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             int a_eff = A;
             if (A < NR && hint != nullptr) {
                 const float hv = (float)hraw;
+                // (stale hints -- the first iterations of a run, a reused buffer -- send steps to the exact list; the host
+                // sees the count one call later and pauses the hints, api.hip)
                 const bool fine = !(i < n) || m2 >= hint_c * hv * hv; // false for NaN
                 if (!__all(fine)) {
                     SPKM_QUAD_ROUNDS(SPKM_GUARD_B)

@@ -161,11 +161,12 @@ class LloydEngine:
         _lib.check(_lib.lib().spkm_last_screen_rounds(self.ctx.handle, a))
         return int(a[0]), int(a[1])
 
-    def last_screen_mode(self) -> tuple[int, int, int, int, int, int]:
+    def last_screen_mode(self) -> tuple[int, ...]:
         """(form of the last screen call: 0 plain / 1 two-phase / 2 hinted / -1 none, then its counters:
         listed points, ambiguous points, early-finished (step, tile) pairs, steps skipped on the carried bounds,
-        and the running total of skipped steps on this context; blocks) -- spkm_last_screen_mode."""
-        a = (C.c_int64 * 6)()
+        the running total of skipped steps on this context, steps skipped thanks to the explicit bounds of the
+        largest movers, 0; blocks) -- spkm_last_screen_mode."""
+        a = (C.c_int64 * 8)()
         _lib.check(_lib.lib().spkm_last_screen_mode(self.ctx.handle, a))
         return tuple(int(v) for v in a)
 

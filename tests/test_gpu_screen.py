@@ -429,3 +429,36 @@ def test_kept_counting_sort_is_reused_only_when_it_is_still_this_call_s(gpu_ctx,
     call(eA, dA, moved)
     call(eA, dA, moved)
     call(eA, dA, cA)
+
+
+def test_largest_movers_are_bounded_explicitly(gpu_ctx, oracle):
+    """Most centres have settled, three still jump: the single largest drift would keep every point on the screen, so
+    the library bounds the 8 largest movers through a narrow screen tile of their own and tests again
+    (spkm_last_screen_mode()[6] counts the steps skipped that way).  Outputs equal the oracle's on every call."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    K, n = 64, 9000
+    data = synth.sparsified_gmm_host(p=256, n=n, K=K, gamma=0.2, seed=31, fwht=oracle.fwht)
+    Y, p2, gam = data["Y"], data["p2"], data["gamma"]
+    cen = np.zeros((p2, K))
+    for k in range(K):
+        Yk = Y[:, data["labels"] == k]
+        cen[:, k] = gam * np.asarray(Yk.sum(axis=1)).ravel() / (np.asarray((Yk != 0).sum(axis=1)).ravel() + 1e-16)
+    rng = np.random.default_rng(7)
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, Y), K, gam)
+    via_movers = []
+
+    def call(cm):
+        eng.assign_accumulate_step(torch.tensor(np.ascontiguousarray(cm.T), device="cuda"))
+        torch.cuda.synchronize()
+        via_movers.append(eng.last_screen_mode()[6])
+        _check(eng, oracle, Y, cm, gam)
+
+    call(cen)
+    cur = cen.copy()
+    for it in range(5):
+        cur = cur * (1 + 1e-7 * (it + 1))                       # everybody drifts a hair ...
+        for k in (5, 23, 41):                                   # ... three centres jump around their clusters
+            cur[:, k] = cen[:, k] + 0.4 * np.abs(cen).mean() * rng.standard_normal(p2)
+        call(cur)
+    assert max(via_movers) > 0.3 * (n // 16), via_movers

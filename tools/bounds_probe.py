@@ -22,6 +22,9 @@ x = d["x"][: n * s].view(n, s)
 TILES = [(0, 32), (32, 64), (64, 100)]
 tl = [torch.empty(n, device='cuda', dtype=torch.float64) for _ in TILES]
 
+JSET = None
+minJ = torch.empty(n, device='cuda', dtype=torch.float64)
+
 def dists(cent):
     cg = cent / gamma                                   # K x p2
     out1 = torch.empty(n, device="cuda", dtype=torch.float64); out2 = torch.empty_like(out1); a = torch.empty(n, device="cuda", dtype=torch.long)
@@ -36,10 +39,16 @@ def dists(cent):
         dd2 = dd.clone(); dd2[torch.arange(i1 - i0), idx[:, 0]] = float("inf")
         for t, (lo, hi) in enumerate(TILES):
             tl[t][i0:i1] = dd2[:, lo:hi].min(dim=1).values
+        if JSET is not None:
+            minJ[i0:i1] = dd2[:, JSET].min(dim=1).values
     return out1, out2, a
 
 prev = None
+lbj = None
 for it in range(14):
+    if prev is not None:
+        delta_ = ((c - prev[0]) / gamma).norm(dim=1)
+        JSET = torch.topk(delta_, 8).indices
     d1, d2, a = dists(c)
     if prev is not None:
         pc, ub, lb, pa, ptl = prev
@@ -53,6 +62,11 @@ for it in range(14):
         print(f"iter {it}: drift max {dmax:.3g} mean {delta.mean():.3g}  d1 mean {d1.mean():.3g} gap mean {(d2-d1).mean():.3g}  points certified {ok.float().mean():.4f}  steps certified {steps_ok:.4f}  reassigned {changed:.5f}")
         # carried bounds (Hamerly): certified points keep the moved lower bound, the others get fresh ones
         lb = torch.where(ok, Lb, d2)
+        # jumper version: the 8 largest movers bounded explicitly (exact distance here), the others by their own max drift
+        rest = delta.clone(); rest[JSET] = 0
+        okj = (U < lbj - rest.max()) & (U < minJ) & ~torch.isin(pa, JSET)
+        print(f"          jumpers: top-8 drifts {[round(v, 1) for v in delta[JSET].tolist()]}, others' max {rest.max():.3g}; points {okj.float().mean():.4f}  steps {okj.view(-1, 16).all(dim=1).float().mean().item():.4f}")
+        lbj = torch.where(okj, torch.minimum(lbj - rest.max(), minJ), d2)
         # per-tile version: a (step, tile) pair is skipped when all 16 points pass for that tile and the tile is not
         # the own tile of any of them -- unless every tile passes (then the whole step is skipped)
         passes = []
@@ -67,6 +81,7 @@ for it in range(14):
         newtl = [torch.where(P[:, t], ptl[t] - delta[lo:hi].max(), tl[t]) for t, (lo, hi) in enumerate(TILES)]
     else:
         lb = d2
+        lbj = d2.clone()
         newtl = [x_.clone() for x_ in tl]
     prev = (c.clone(), d1.clone(), lb, a.clone(), newtl)
     eng.iterate(c)
