@@ -148,12 +148,13 @@ int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const in
  * screen cannot certify, and the exact distance of every point to its assigned centroid fused into the
  * accumulation pass (csrc/screen.hip).  Nothing computed in f32 reaches an output.  The environment
  * variable SPKM_NO_SCREEN=1 forces the all-exact kernels.
- * Hints: when a shard is called again with the SAME d_mind pointer as in its previous call, the buffer's
- * contents on entry (that call's min-distances, if the caller left them alone) steer the screen: a group of
- * 16 points stops after a quarter of its entries once the partial squared distance of every other centroid of a
- * tile already exceeds twice the hinted distance squared.  Hints only choose how much work is done -- every shortcut keeps a certified
- * lower bound, a stale or overwritten buffer costs time (and switches the hints off), never correctness.
- * SPKM_NO_HINT=1 disables them.
+ * Work-saving state: all of it lives in the library's own buffers, per shard; nothing depends on what the caller
+ * does with its output buffers between calls, and none of it changes an output.
+ * Hints: from the second screen call on a shard, the screen compares the competition's partial sums with a
+ * per-point estimate of the distance to the previous centroid (previous exact distance and that centroid's
+ * movement): a group of 16 points stops after a quarter of its entries once the partial squared distance of every
+ * other centroid of a tile already exceeds 1.5x the hinted distance squared.  A misleading hint costs time (and
+ * pauses the hints for a few calls), never correctness.  SPKM_NO_HINT=1 disables them.
  * Carried bounds: the library keeps, per shard, its own copy of the previous screen call's assignment, an
  * upper bound of every point's distance to its centroid and a lower bound of its distance to all others, plus
  * that call's centroids.  On the next call the centroids' movement (triangle inequality on the masked distances)

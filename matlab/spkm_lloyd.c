@@ -15,8 +15,7 @@
 
 static spkm_shard *g_shard = NULL;
 static const mxArray *g_shard_key = NULL; /* identity of the uploaded X (MATLAB shares data pointers) */
-/* per-point outputs stay allocated between calls: the library uses the previous call's min-distances, found in
- * the same buffer, as hints for the next one (spkm.h, spkm_assign_accumulate_dev) */
+/* per-point outputs stay allocated between calls (no reallocation of 1.2 GB per iteration at N = 1e8) */
 static double *g_dmind = NULL;
 static int32_t *g_dassign = NULL;
 static size_t g_npts = 0;

@@ -56,6 +56,7 @@ struct spkm_ctx {
     int last_rounds_all = 0, last_rounds = 0; // rounds for all centroids / total rounds of the last 4-lane screen call
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
+    bool last_hinted = false;        // ... used the hinted two-phase form
     char errmsg[256] = {0};
 };
 
@@ -85,7 +86,8 @@ struct spkm_shard {
     int prune_pending_a = 0, prune_next_a = 0, prune_cooldown = 0;
     // hinted two-phase screen: the d_mind buffer the previous fused call wrote (its contents are that call's
     // min-distances as long as the caller reuses the buffer), whether the pending call used it, calls to wait
-    const double* hint_ptr = nullptr;
+    float* hintu = nullptr;   // per-point hints of the two-phase screen (k_bounds_steps), npad floats
+    long long hintu_len = 0;
     bool hint_pending = false;
     int hint_cooldown = 0;
     int hint_fail_streak = 0; // consecutive hinted calls that did not pay: the pause doubles (2, 4, 8, 16 calls)
@@ -331,6 +333,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xfs) (void)hipFree(s->xfs);
     if (s->irs) (void)hipFree(s->irs);
     if (s->hb) (void)hipFree(s->hb);
+    if (s->hintu) (void)hipFree(s->hintu);
     if (s->hb_centers) (void)hipFree(s->hb_centers);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
     if (s->ev_nlist) (void)hipEventDestroy(s->ev_nlist);
@@ -349,7 +352,6 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->prune_next_a = 0;
     s->prune_cooldown = 0;
     s->prune_pending_a = 0;
-    s->hint_ptr = nullptr;
     s->hint_cooldown = 0;
     s->hint_fail_streak = 0;
     s->hint_pending = false;
@@ -883,7 +885,7 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
 
 template <typename IR>
 static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d_centers, double gamma,
-                      int32_t* d_assign, double* d_mind, double* d_reduce, int prune_a, const double* hint)
+                      int32_t* d_assign, double* d_mind, double* d_reduce, int prune_a, bool want_hint)
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
@@ -958,7 +960,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
-    bool skipping = false, jumpers = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
+    bool skipping = false, jumpers = false, hinted = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
             if (sm->hb) (void)hipFree(sm->hb);
@@ -975,15 +977,30 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             sm->hb_centers_len = pk;
         }
         bounds_ok = sm->hb_valid && sm->hb_K == K && sm->hb_gamma == gamma;
-        if (bounds_ok && !getenv("SPKM_NO_BOUNDS")) {
+        // hinted two-phase form: needs the carried bounds (the hints are ub + drift) and a split that saves rounds
+        hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds;
+        if (hinted) {
+            prune_a = quad_split(q_rounds);
+            if (sm->hintu_len < npad) {
+                if (sm->hintu) (void)hipFree(sm->hintu);
+                sm->hintu = nullptr;
+                HIP_TRY(hipMalloc((void**)&sm->hintu, (size_t)npad * 4));
+                sm->hintu_len = npad;
+            }
+        }
+        const bool skip_enabled = bounds_ok && !getenv("SPKM_NO_BOUNDS");
+        if (skip_enabled || hinted) {
             HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
                                d_centers, K, p, gamma, sm->hb + 3 * npad);
-            // settle the steps the bounds certify, list the others for the screen
+            // settle the steps the bounds certify, list the others for the screen; write the hints
             if ((rc = ensure(ctx, ctx->todo, (size_t)(npad / 16 + 1) * 4))) return rc;
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)((npad + BOUNDS_SPAN - 1) / BOUNDS_SPAN)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
-                               (unsigned*)ctx->nlist.p);
+                               (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
+                               2.0f * (float)s->fixed_s / (float)p);
+        }
+        if (skip_enabled) {
             skipping = true;
             // while a few centres still jump and the rest have settled, bound the jumpers explicitly (screen.hip,
             // k_pick_jumpers): a narrow screen tile over them on the steps the plain test left, then a second test.
@@ -1037,7 +1054,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             float* j_m1 = (float*)ctx->scr_m1.p;
             float* j_m2 = (float*)ctx->scr_m2.p;
             int* j_k = (int*)ctx->scr_k.p;
-            const double* j_hint = nullptr;
+            const float* j_hint = nullptr;
             float j_hc = 0.f;
             unsigned* j_cnt = cn + 24; // its list length sits at [24 + 4]
             const int* j_todo = (const int*)ctx->todo.p;
@@ -1063,8 +1080,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const int a_rounds = two ? quad_split(q_rounds) : q_rounds;
         ctx->last_rounds_all = quad ? a_rounds : 0;
         ctx->last_rounds = quad ? q_rounds : 0;
-        const double* a_hint = (quad && a_rounds < q_rounds) ? hint : nullptr; // nullptr: every step is finished for the leaders only
-        float a_hc = 2.0f; // the other centroids' partial sums must exceed 2x the previous min-distance squared
+        const float* a_hint = (hinted && a_rounds < q_rounds) ? sm->hintu : nullptr; // nullptr: every step is finished for the leaders only
+        float a_hc = 1.5f; // the other centroids' partial sums must exceed 1.5 x the hinted distance squared
+        ctx->last_hinted = a_hint != nullptr;
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
         const int* a_todo = skipping ? (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p) : nullptr;
@@ -1213,21 +1231,15 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     if (s->n > 0 && !cooling && screen_eligible(ctx, s, (int)K64)) {
         ctx->ev_valid = false;
         int prune_a = getenv("SPKM_NO_PRUNE") ? 0 : sm->prune_next_a;
-        // Hinted two-phase screen: the caller hands in the same d_mind buffer as last time, so it still holds the
-        // previous call's min-distances -- used as per-point hints for how far the competition has to be before a
-        // step may stop early (screen.hip).  Chosen when the unconditional two-phase form is not, and not cooling.
-        const double* hint = nullptr;
-        if (prune_a == 0 && !getenv("SPKM_NO_PRUNE") && !getenv("SPKM_NO_HINT") && sm->hint_ptr == d_mind &&
-            sm->hint_cooldown == 0 && screen_use_quad(s)) {
-            const int nr = (s->fixed_s + 3) / 4;
-            const int a_h = quad_split(nr);
-            if (a_h < nr) { hint = d_mind; prune_a = a_h; }
-        }
-        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, hint)
-                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, hint);
+        // Hinted two-phase screen: when the unconditional two-phase form is not chosen and hints are not paused, the
+        // screen compares the competition's partial sums with per-point upper bounds taken from the carried bounds
+        // (run_screen / k_bounds_steps); needs this shard's previous call to have been a screen call.
+        const bool want_hint = prune_a == 0 && !getenv("SPKM_NO_PRUNE") && !getenv("SPKM_NO_HINT") &&
+                               sm->hint_cooldown == 0 && screen_use_quad(s);
+        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint)
+                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint);
         if (rc) return rc;
-        sm->hint_ptr = d_mind;
-        ctx->last_mode = hint ? 2 : (ctx->last_rounds_all < ctx->last_rounds ? 1 : 0);
+        ctx->last_mode = ctx->last_hinted ? 2 : (ctx->last_rounds_all < ctx->last_rounds ? 1 : 0);
         if (!sm->h_nlist) {
             HIP_TRY(hipHostMalloc((void**)&sm->h_nlist, 64, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
@@ -1237,7 +1249,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
             sm->nlist_pending = true;
             sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
-            sm->hint_pending = hint != nullptr;
+            sm->hint_pending = ctx->last_hinted;
             sm->skip_pending = ctx->last_skipping;
         }
         if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));

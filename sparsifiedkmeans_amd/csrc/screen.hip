@@ -591,8 +591,14 @@ __global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, 
 #define BOUNDS_SPAN 16384 // points per workgroup of k_bounds_steps (1024 steps)
 __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
                                                       int* __restrict__ assign,
-                                                      int* __restrict__ todo, unsigned* __restrict__ counters)
+                                                      int* __restrict__ todo, unsigned* __restrict__ counters,
+                                                      float* __restrict__ hintu, int skip_enabled, float hint_w)
 {
+    // hintu != nullptr: every point's ESTIMATE of its distance to its previous centroid under the NEW centroids --
+    // the hint of the two-phase screen (k_screen_quad), what the competition's partial sums are compared with.  Not
+    // the rigorous ub + delta_a (far too pessimistic: a centroid's move is almost orthogonal to x - c, and only its
+    // part on the point's support counts) but sqrt(ub^2 + hint_w delta_a^2), hint_w = 2 s / p: hints steer work,
+    // they prove nothing.  skip_enabled == 0: that is all this kernel does (SPKM_NO_BOUNDS).
     // the steps that stay are collected per workgroup in LDS and appended with ONE global atomic, the skipped ones
     // counted per workgroup (wave-level atomics on one address cost ~8 ms at N = 1e8 when nothing can be skipped)
     __shared__ int s_todo[BOUNDS_SPAN / 16];
@@ -618,6 +624,14 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) dav[u] = bnd[3 * npad + apv[u]];
+        if (hintu != nullptr) {
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
+                if (i < n) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
+            }
+        }
+        if (!skip_enabled) continue;
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
@@ -1036,7 +1050,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
                                                  int extra_k0,
-                                                 const double* __restrict__ hint, float hint_c,
+                                                 const float* __restrict__ hint, float hint_c,
                                                  unsigned* __restrict__ counters, const int* __restrict__ todo)
 {
     constexpr int PPS = 16;
@@ -1085,7 +1099,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             const IR* rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
             // the hint is needed only after the first evaluation, but its load must not wait until then (a second
             // exposed memory latency per step): issued first, pinned in a register before the rounds
-            double hraw = 0.0;
+            float hraw = 0.f;
             if (A < NR && hint != nullptr) hraw = hint[i < n ? i : n - 1];
             // scalars, not arrays: the compiler turns constant-indexed arrays into 16-wide register tuples and spills them
 #define SPKM_QUAD_LOAD(r)                                                              \
@@ -1170,13 +1184,14 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                 m2 = quad_min_f32((l4 == first) ? hi : lo);
             };
             evaluate();
-            // Hinted two-phase screen: `hint` holds each point's min-distance of the PREVIOUS call.  If, for every
-            // point of this step, all non-leading centroids of the tile are already (by their partial sums) more
-            // than sqrt(hint_c) times that distance away, the step is finished for the leaders only; otherwise the
+            // Hinted two-phase screen: `hint` holds, per point, an estimate of its distance to the centroid it had in
+            // the previous call (from the library's carried bound and that centroid's drift, k_bounds_steps).  If, for
+            // every point of this step, all non-leading centroids of the tile are already (by their partial sums)
+            // more than sqrt(hint_c) times that far away, the step is finished for the leaders only; otherwise the
             // remaining rounds are run for all centroids.  The hint steers the work, never a result.
             int a_eff = A;
             if (A < NR && hint != nullptr) {
-                const float hv = (float)hraw;
+                const float hv = hraw;
                 // (stale hints -- the first iterations of a run, a reused buffer -- send steps to the exact list; the host
                 // sees the count one call later and pauses the hints, api.hip)
                 const bool fine = !(i < n) || m2 >= hint_c * hv * hv; // false for NaN
@@ -1248,7 +1263,7 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile,
-    const double* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const int* __restrict__ todo)
+    const float* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const int* __restrict__ todo)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];

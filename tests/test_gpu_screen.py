@@ -290,9 +290,9 @@ def test_two_phase_screen_switches_itself_on_and_off(gpu_ctx, oracle):
 def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle, monkeypatch):
     """Mid-run Lloyd state: some clusters are split between two nearby centres (runner-up within 2.25x: the
     unconditional two-phase form stays off) and some have no centre of their own.  From the second call on the
-    previous min-distances, still in the caller's buffer, let 16-point steps finish early (form 2, counter of
-    early-finished steps > 0); outputs equal the oracle's bit for bit on every call, also after the buffer has
-    been scribbled over (hints then mislead: more work, same answers)."""
+    library's per-point distance estimates let 16-point steps finish early (form 2, counter of early-finished steps
+    > 0); outputs equal the oracle's bit for bit on every call, also after the caller has scribbled over its output
+    buffers (the hints live in the library's own state)."""
     import time
     from sparsifiedkmeans_amd import synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
@@ -318,7 +318,7 @@ def test_hinted_two_phase_screen_uses_previous_distances(gpu_ctx, oracle, monkey
     modes = []
     for it in range(6):
         if it == 4:
-            eng.mind.mul_(0.01)                             # a caller that reuses the buffer: misleading hints
+            eng.mind.mul_(0.01)                             # a caller that reuses its buffers: no effect on the hints
         eng.assign_accumulate_step(centers)
         torch.cuda.synchronize()
         time.sleep(0.01)
