@@ -998,7 +998,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)((npad + BOUNDS_SPAN - 1) / BOUNDS_SPAN)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
-                               2.0f * (float)s->fixed_s / (float)p);
+                               (getenv("SPKM_HINT_W") ? (float)atof(getenv("SPKM_HINT_W")) : 2.0f) * (float)s->fixed_s / (float)p);
         }
         if (skip_enabled) {
             skipping = true;
