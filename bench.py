@@ -154,6 +154,8 @@ def main():
     _lib.check(L.spkm_timing_read(ctx.handle, buf, cap, C.byref(cnt)))
     _lib.check(L.spkm_timing_log(ctx.handle, 0))
     kms = np.array(buf[:min(cnt.value, cap)])
+    if os.environ.get("SPKM_BENCH_DUMP") and rank == 0:   # per-call kernel times of the timed region (diagnostics)
+        print("per-call ms:", [round(float(v), 3) for v in kms], "last screen mode:", mode, file=sys.stderr)
     if path == 1 and kms.size == 2 * args.steps:
         screen_ms, acc_ms = float(kms[0::2].mean()), float(kms[1::2].mean())
     else:                                       # all-exact path (or a mix after a back-off): the tile kernel only

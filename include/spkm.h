@@ -181,7 +181,7 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * hinted form, 16-point steps skipped altogether on the bounds carried from the previous call (see
  * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context;
  * info[6] = of info[4], the steps skipped only because the centroids that moved most were bounded explicitly
- * (a narrow screen tile over the 8 largest movers; SPKM_NO_JUMPERS=1 disables it); info[7] = 0 (reserved).
+ * (a narrow screen tile over the 8 largest movers; opt-in with SPKM_JUMPERS=1); info[7] = 1 if that tile ran.
  * Blocks on the stream. */
 int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[8]);
 

@@ -42,6 +42,7 @@ struct spkm_ctx {
     bool ev_valid = false;
     // optional per-launch timing log of the dominant assignment kernel (bench.py)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tlog;
+    std::vector<std::pair<const void*, size_t>> lds_allowed; // see allow_lds
     size_t tlog_used = 0;
     bool tlog_on = false;
     // counting sort kept from the last screen call (perm / offs / items / nitems / nk describe THAT call's assignment):
@@ -112,6 +113,22 @@ struct spkm_shard {
             return (int)_e;                                                                             \
         }                                                                                               \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised at most once per kernel and size (the call is not free, and
+// the screen path needs it for two kernels per call)
+static hipError_t allow_lds(spkm_ctx* ctx, const void* kern, size_t bytes)
+{
+    for (auto& e : ctx->lds_allowed)
+        if (e.first == kern) {
+            if (e.second >= bytes) return hipSuccess;
+            hipError_t r = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (r == hipSuccess) e.second = bytes;
+            return r;
+        }
+    hipError_t r = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (r == hipSuccess) ctx->lds_allowed.emplace_back(kern, bytes);
+    return r;
+}
 
 static int ensure(spkm_ctx* ctx, devbuf& b, size_t bytes)
 {
@@ -1004,8 +1021,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             skipping = true;
             // while a few centres still jump and the rest have settled, bound the jumpers explicitly (screen.hip,
             // k_pick_jumpers): a narrow screen tile over them on the steps the plain test left, then a second test.
-            // On until the plain test alone skips most steps (lagging counters); SPKM_NO_JUMPERS=1: A/B switch.
-            jumpers = K >= 3 * NJUMP && sm->j_on && !getenv("SPKM_NO_JUMPERS") &&
+            // On until the plain test alone skips most steps (lagging counters).  OPT-IN (SPKM_JUMPERS=1): it brings
+            // the skipping forward by two or three iterations, but the points it settles keep their old, eroding
+            // lower bounds instead of fresh ones from the screen and come back later -- measured net gain 2 % of a
+            // run at N = 1e8, a loss on small shards.
+            jumpers = K >= 3 * NJUMP && sm->j_on && getenv("SPKM_JUMPERS") && !getenv("SPKM_NO_JUMPERS") &&
                       (size_t)(p + 1) * SCREEN_KT * 4 + 16 <= ctx->lds_max;
         }
         sm->hb_valid = false; // until this call has gone through
@@ -1026,7 +1046,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     {
         const size_t lds = (size_t)(p + 1) * (SCREEN_KT * 4 + (pl_last == 5 ? 16 : 0)) + 16;
         const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0) : (const void*)k_screen_tile<IR>;
-        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(allow_lds(ctx, kern, lds));
         HIP_TRY(timing_begin(ctx));
         const IR* a_ir = quad ? (const IR*)s->irs : (const IR*)s->ir;
         const float* a_xf = quad ? (const float*)s->xfs : (const float*)s->xf;
@@ -1037,7 +1057,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             unsigned* cn = (unsigned*)ctx->nlist.p;
             float* dl = sm->hb + 3 * npad;
             hipLaunchKernelGGL(k_pick_jumpers, dim3(1), dim3(256), 0, ctx->stream, dl, K, cn);
-            hipLaunchKernelGGL(k_jumper_list_length, dim3(1), dim3(1), 0, ctx->stream, cn, 28);
+            hipLaunchKernelGGL(k_jumper_list_length, dim3(1), dim3(1), 0, ctx->stream, cn, 28, (unsigned)((n + 15) / 16));
             const size_t jfloats = (size_t)(p + 1) * SCREEN_KT;
             if ((rc = ensure(ctx, ctx->t32j, jfloats * 4))) return rc;
             if ((rc = ensure(ctx, ctx->todo2, (size_t)(npad / 16 + 1) * 4))) return rc;
@@ -1047,7 +1067,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             if ((rc = build_blockmap_quad(ctx, 1, 1, q_rounds, true))) return rc;
             const void* kj = screen_quad_kernel<IR>(q_rounds, false);
             const size_t ldsj = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
-            HIP_TRY(hipFuncSetAttribute(kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, ldsj)));
+            HIP_TRY(allow_lds(ctx, kj, std::max(lds, ldsj)));
             const float* j_t = (const float*)ctx->t32j.p;
             int j_p = p, j_n = (int)n, j_s = s->fixed_s, j_K = NJUMP, j_chunk = (int)chunk, j_extra = 0;
             const spkm_blockmap* j_bm = (const spkm_blockmap*)ctx->bmapj.p;
@@ -1066,7 +1086,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                                (const double*)s->xn1, (const double*)s->xn2,
                                (const unsigned long long*)ctx->cmax.p + 1, s->fixed_s, (int*)d_assign);
             hipLaunchKernelGGL(k_commit_list, dim3(1), dim3(1), 0, ctx->stream, cn);
-            if (kj == kern) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         const float* a_t = (const float*)ctx->t32.p;
         int a_p = p, a_n = (int)n, a_s = s->fixed_s, a_K = K, a_chunk = (int)chunk;
@@ -1154,7 +1173,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     int per_cu = 1;
     if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
     auto k2 = threads == 512 ? k_exact_accumulate<IR, 16, 2> : k_exact_accumulate<IR, 16, 4>; // 16 points' loads in flight per wave, 4 waves per SIMD
-    HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    HIP_TRY(allow_lds(ctx, (const void*)k2, lds2));
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * per_cu);
     if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
@@ -1286,6 +1305,7 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         for (int j = 0; j < 4; j++) info[1 + j] = v[j];
         info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
         info[6] = v[6];
+        info[7] = v[7]; // the jumper tile ran in the last call
     }
     return SPKM_OK;
 }

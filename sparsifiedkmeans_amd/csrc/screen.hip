@@ -506,10 +506,14 @@ __global__ __launch_bounds__(256) void k_pick_jumpers(float* __restrict__ delta,
     }
 }
 
-// after k_bounds_steps: the jumper tile runs over the whole list of remaining steps, or over nothing
-__global__ void k_jumper_list_length(unsigned* __restrict__ counters, int to)
+// after k_bounds_steps: the jumper tile runs over the whole list of remaining steps, or -- when there are no
+// outliers among the drifts, or the first test left less than an eighth of the steps -- over nothing (decided here,
+// on the device: a host that queues many calls ahead sees the counters too late to decide)
+__global__ void k_jumper_list_length(unsigned* __restrict__ counters, int to, unsigned nsteps)
 {
-    counters[to] = counters[7] ? counters[4] : 0u;
+    const bool use = counters[7] != 0u && (unsigned long long)counters[4] * 8ull > nsteps;
+    counters[7] = use ? 1u : 0u;
+    counters[to] = use ? counters[4] : 0u;
 }
 __global__ void k_commit_list(unsigned* __restrict__ counters) { counters[4] = counters[20]; }
 
@@ -1268,6 +1272,7 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
     if (bm.tile < 0) return;
+    if (todo != nullptr && counters[4] == 0u) return; // an empty list: not even the tile is loaded
     const int tid = threadIdx.x;
     const int pl = (bm.pad >> 16) & 0xff; // centroid pairs per lane in this workgroup's tile (5: 4 + one extra centroid)
     const size_t tile_bytes = (size_t)(p + 1) * SCREEN_KT * 4;

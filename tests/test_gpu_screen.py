@@ -431,10 +431,12 @@ def test_kept_counting_sort_is_reused_only_when_it_is_still_this_call_s(gpu_ctx,
     call(eA, dA, cA)
 
 
-def test_largest_movers_are_bounded_explicitly(gpu_ctx, oracle):
+def test_largest_movers_are_bounded_explicitly(gpu_ctx, oracle, monkeypatch):
     """Most centres have settled, three still jump: the single largest drift would keep every point on the screen, so
-    the library bounds the 8 largest movers through a narrow screen tile of their own and tests again
-    (spkm_last_screen_mode()[6] counts the steps skipped that way).  Outputs equal the oracle's on every call."""
+    (opt-in, SPKM_JUMPERS=1) the library bounds the 8 largest movers through a narrow screen tile of their own and
+    tests again (spkm_last_screen_mode()[6] counts the steps skipped that way).  Outputs equal the oracle's on every
+    call."""
+    monkeypatch.setenv("SPKM_JUMPERS", "1")
     from sparsifiedkmeans_amd import synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
     K, n = 64, 9000
