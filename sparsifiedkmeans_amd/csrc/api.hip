@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <utility>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #define SPKM_VERSION 100
@@ -42,7 +44,6 @@ struct spkm_ctx {
     bool ev_valid = false;
     // optional per-launch timing log of the dominant assignment kernel (bench.py)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tlog;
-    std::vector<std::pair<const void*, size_t>> lds_allowed; // see allow_lds
     size_t tlog_used = 0;
     bool tlog_on = false;
     // counting sort kept from the last screen call (perm / offs / items / nitems / nk describe THAT call's assignment):
@@ -114,19 +115,23 @@ struct spkm_shard {
         }                                                                                               \
     } while (0)
 
-// hipFuncAttributeMaxDynamicSharedMemorySize, raised at most once per kernel and size (the call is not free, and
-// the screen path needs it for two kernels per call)
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised at most once per (device, kernel) and size: the call is not
+// free and the screen path needs it for two kernels per call.  The attribute belongs to the function, not to a
+// context, so the record is process-wide (several contexts may share a device).
 static hipError_t allow_lds(spkm_ctx* ctx, const void* kern, size_t bytes)
 {
-    for (auto& e : ctx->lds_allowed)
-        if (e.first == kern) {
-            if (e.second >= bytes) return hipSuccess;
+    static std::mutex mu;
+    static std::vector<std::tuple<int, const void*, size_t>> allowed;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : allowed)
+        if (std::get<0>(e) == ctx->device && std::get<1>(e) == kern) {
+            if (std::get<2>(e) >= bytes) return hipSuccess;
             hipError_t r = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            if (r == hipSuccess) e.second = bytes;
+            if (r == hipSuccess) std::get<2>(e) = bytes;
             return r;
         }
     hipError_t r = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (r == hipSuccess) ctx->lds_allowed.emplace_back(kern, bytes);
+    if (r == hipSuccess) allowed.emplace_back(ctx->device, kern, bytes);
     return r;
 }
 
