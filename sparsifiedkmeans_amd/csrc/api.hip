@@ -86,8 +86,8 @@ struct spkm_shard {
     // two-phase screen (screen.hip, phase B): rounds evaluated for ALL centroids in the call whose counters are
     // pending / in the next call (0 = all rounds, the plain screen), and calls left before pruning is retried
     int prune_pending_a = 0, prune_next_a = 0, prune_cooldown = 0;
-    // hinted two-phase screen: the d_mind buffer the previous fused call wrote (its contents are that call's
-    // min-distances as long as the caller reuses the buffer), whether the pending call used it, calls to wait
+    // hinted two-phase screen: the hints (written by k_bounds_steps from the carried bounds), whether the call whose
+    // counters are pending used them, calls to wait before the next hinted call
     float* hintu = nullptr;   // per-point hints of the two-phase screen (k_bounds_steps), npad floats
     long long hintu_len = 0;
     bool hint_pending = false;
