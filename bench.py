@@ -9,6 +9,16 @@ kmeans_sparsified.m:417-486) over the whole synthetic dataset, which is generate
 HBM before the timed region (FWHT-mixed, 5 %-sparsified Gaussian mixture).
 Workload: BASELINE.json's metric config -- N=1e8 points, d=1024, K=100 -- held by ONE GPU at
 --gpus 1 (≈62 GB of the 288 GB HBM) and sharded by points over N GPUs otherwise (strong scaling).
+
+What the timed steps are (so that `value` does not depend on --warmup / --steps): iterations of kmeans_sparsified's
+own loop -- runs from the start centres until norm(centersOld-centers,'fro') < Tol (kmeans_sparsified.m:476,
+Tol = 1e-6, MaxIter = 100), the host reading dff after every iteration as the driver does; when a run has
+converged the next one starts from the same start centres with the library's carried state dropped
+(spkm_shard_reset_policy: what a new replicate does).  The W warm-up steps run the same loop and are followed by
+such a reset, so the K timed steps always begin with a cold first iteration.  `regimes` reports one complete run
+iteration by iteration (cold first iteration / mean over the run / converged) on this dataset and on the same
+mixture in shuffled point order.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -27,12 +37,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md chip table: 8.0 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz (non-fused ops; 78.6 TFLOP/s counts FMA as 2)
+TOL, MAXITER = 1e-6, 100       # kmeans_sparsified.m:133,135 defaults
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-total", type=float, default=1e8)
     ap.add_argument("--dim", type=int, default=1024)
@@ -41,10 +52,14 @@ def main():
     ap.add_argument("--seed", type=int, default=234)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points timed on the CPU oracle (0 = skip)")
     ap.add_argument("--gen-chunk", type=int, default=131072)
+    ap.add_argument("--order", choices=["block", "shuffled"], default="block",
+                    help="point order of the dataset the headline value is measured on: cluster-contiguous blocks "
+                         "(example_sparseKMeans.m:19-22, SURVEY 8(d)) or arbitrary order; the other one is reported "
+                         "under `regimes` unless --no-regimes")
     ap.add_argument("--start", choices=["sample", "planted"], default="sample",
-                    help="initial centres: K mixture points drawn with replacement (default; what the headline number "
-                         "is quoted on: duplicate and uncovered clusters, half of the points ambiguous) or the K planted "
-                         "means + noise (a converged, separated iteration: the two-phase screen switches itself on)")
+                    help="initial centres: K mixture points drawn with replacement (default: duplicate and uncovered "
+                         "clusters, a run needs many iterations) or the K planted means + noise (converges at once)")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the traced runs to convergence (quick experiments)")
     args = ap.parse_args()
 
     import torch
@@ -68,36 +83,44 @@ def main():
             dist.init_process_group(backend)
 
     from sparsifiedkmeans_amd import _lib, synth
-    from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_device, torch_context
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_device, mix_sample_device, torch_context
 
     ctx = torch_context(local_rank)
+    L = _lib.lib()
     n_total = int(args.n_total)
     p, K = args.dim, args.clusters
     first = rank * n_total // world
     n_local = (rank + 1) * n_total // world - first
 
-    t_gen = time.time()
-    data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
-                                       chunk=args.gen_chunk)
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def make_dataset(order):
+        t = time.time()
+        data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
+                                           chunk=args.gen_chunk, order=order)
+        shard = Shard.from_device(ctx, data["p2"], data["jc"], data["ir"], data["x"], nnz=data["nnz"])
+        # initial centres: K mixture points in the ORIGINAL space passed through mix(), as the
+        # 'Start'-matrix path does (kmeans_sparsified.m:401-406); identical on every rank
+        g = torch.Generator(device="cuda")
+        g.manual_seed(args.seed + 17)
+        lab = torch.randint(0, K, (K,), generator=g, device="cuda")
+        if args.start == "planted":
+            lab = torch.arange(K, device="cuda")
+        start = data["means"][lab] + 0.1 * torch.randn((K, p), generator=g, device="cuda", dtype=torch.float64)
+        centers0 = mix_device(ctx, start.contiguous(), data["p2"], data["sign"], 1.0, float(np.sqrt(np.float64(data["p2"]))))
+        torch.cuda.synchronize()
+        return data, shard, centers0, time.time() - t
+
+    data, shard, centers0, t_gen = make_dataset(args.order)
     p2, s, gamma = data["p2"], data["s"], data["gamma"]
-    shard = Shard.from_device(ctx, p2, data["jc"], data["ir"], data["x"], nnz=data["nnz"])
-    # initial centres: K mixture points in the ORIGINAL space passed through mix(), as the
-    # 'Start'-matrix path does (kmeans_sparsified.m:401-406); identical on every rank
-    g = torch.Generator(device="cuda")
-    g.manual_seed(args.seed + 17)
-    lab = torch.randint(0, K, (K,), generator=g, device="cuda")
-    if args.start == "planted":
-        lab = torch.arange(K, device="cuda")
-    start = data["means"][lab] + 0.1 * torch.randn((K, p), generator=g, device="cuda", dtype=torch.float64)
-    centers0 = mix_device(ctx, start.contiguous(), p2, data["sign"], 1.0, float(np.sqrt(np.float64(p2))))
-    torch.cuda.synchronize()
-    t_gen = time.time() - t_gen
 
     # the one-off preconditioner, reported separately: dense mix() and the fused mix+sample on one chunk
     fw = None
     if rank == 0:
-        from sparsifiedkmeans_amd.engine import mix_sample_device
-
         mcols = min(131072, n_local)
         xd = torch.randn((mcols, p), device="cuda", dtype=torch.float64)
         irt = torch.zeros(mcols * s + 16, dtype=torch.int16 if p2 <= 65536 else torch.int32, device="cuda")
@@ -119,24 +142,61 @@ def main():
               "fused_mix_sample_columns_per_s": mcols / t_fused}
         del xd, irt, xt
 
-    eng = LloydEngine(shard, K, gamma)
-    centers = centers0.clone()
+    class Loop:
+        """kmeans_sparsified's iteration loop on the engine: iterate, read dff (one small D2H per iteration, as the
+        driver does), restart from the start centres when dff < Tol or MaxIter is reached."""
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def __init__(self, shard_, centers0_):
+            self.shard, self.c0 = shard_, centers0_
+            self.eng = LloydEngine(shard_, K, gamma)
+            self.centers = centers0_.clone()
+            self.restart()
+            self.runs_completed, self.run_lengths = 0, []
 
-    for _ in range(args.warmup):
-        eng.iterate(centers)
-    skipped0 = eng.last_screen_mode()[5] if args.warmup > 0 else 0   # running total of steps skipped so far
-    L = _lib.lib()
+        def restart(self):
+            self.centers.copy_(self.c0)
+            self.shard.reset_policy()
+            self.it = 0
+
+        def step(self):
+            """one Lloyd iteration; returns (dff, obj, converged_or_capped)"""
+            out = self.eng.iterate(self.centers).cpu().numpy()       # host sync: the driver needs dff to decide
+            self.it += 1
+            dff = float(np.sqrt(out[0]))
+            return dff, float(np.sqrt(out[1])), (dff < TOL or self.it >= MAXITER)
+
+        def steps(self, k):
+            for _ in range(k):
+                _, _, done = self.step()
+                if done:
+                    self.run_lengths.append(self.it)
+                    self.runs_completed += 1
+                    self.restart()
+
+    def read_tlog(cap):
+        buf = (C.c_double * cap)()
+        cnt = C.c_int()
+        _lib.check(L.spkm_timing_read(ctx.handle, buf, cap, C.byref(cnt)))
+        return np.array(buf[:min(cnt.value, cap)])
+
+    irb = 2 if p2 <= 65536 else 4
+    nnz_local = int(shard.nnz)
+    # algorithmic bytes of one Lloyd iteration over this GPU's points (SURVEY.md §8(d), DESIGN.md §Roofline) ...
+    b_iter = nnz_local * 12 + (n_local + 1) * 8 + n_local * 12 + 24 * p2 * K
+    # ... and of the exact accumulation pass alone: values + row ids once, the sort permutation in, the
+    # min-distances out, the per-cluster sums and counts out
+    b_acc = nnz_local * (8 + irb) + n_local * 12 + 16 * p2 * K
+    steps_per_tile = (n_local + 15) // 16
+
+    loop = Loop(shard, centers0)
+    loop.steps(args.warmup)
+    loop.restart()                                  # the timed steps start a run, whatever W was
+    loop.runs_completed, loop.run_lengths = 0, []
+    skipped0 = loop.eng.last_screen_mode()[5] if args.warmup > 0 else 0   # running total of steps skipped so far
     _lib.check(L.spkm_timing_log(ctx.handle, 2))   # screen path: two pairs per call (screen, exact accumulation)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.iterate(centers)
+    loop.steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -144,67 +204,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    eng = loop.eng
     path, listed = eng.last_path_info()
-    rounds_all, rounds = eng.last_screen_rounds()
     mode = eng.last_screen_mode()
-    # dominant kernel (tiled assignment) durations of exactly the timed launches, HIP events on our stream
-    cap = 2 * max(args.steps, 1)
-    buf = (C.c_double * cap)()
-    cnt = C.c_int()
-    _lib.check(L.spkm_timing_read(ctx.handle, buf, cap, C.byref(cnt)))
+    kms = read_tlog(2 * max(args.steps, 1))
     _lib.check(L.spkm_timing_log(ctx.handle, 0))
-    kms = np.array(buf[:min(cnt.value, cap)])
     if os.environ.get("SPKM_BENCH_DUMP") and rank == 0:   # per-call kernel times of the timed region (diagnostics)
         print("per-call ms:", [round(float(v), 3) for v in kms], "last screen mode:", mode, file=sys.stderr)
     if path == 1 and kms.size == 2 * args.steps:
         screen_ms, acc_ms = float(kms[0::2].mean()), float(kms[1::2].mean())
     else:                                       # all-exact path (or a mix after a back-off): the tile kernel only
         screen_ms, acc_ms = (float(kms.mean()) if kms.size else float("nan")), 0.0
-
-    out = eng.out.cpu().numpy()
-    nnz_local = int(shard.nnz)
-    irb = 2 if p2 <= 65536 else 4
-    # algorithmic bytes of one Lloyd iteration over this GPU's points ...
-    b_iter = nnz_local * 12 + (n_local + 1) * 8 + n_local * 12 + 24 * p2 * K
-    # ... and of the exact accumulation pass alone: values + row ids once, the sort permutation in, the
-    # min-distances out, the per-cluster sums and counts out
-    b_acc = nnz_local * (8 + irb) + n_local * 12 + 16 * p2 * K
     # share of the screen's 16-point steps that the timed launches actually processed (the others were skipped on the
     # bounds carried between calls): the screen is credited with that share of the algorithmic bytes only
-    steps_total = ((n_local + 15) // 16) * args.steps
-    done = 1.0 - (mode[5] - skipped0) / steps_total if path == 1 and steps_total else 1.0
-    # the roofline object describes whichever of the two kernels took longer over the timed iterations
-    if acc_ms > screen_ms:
-        kern, k_ms, b_kern = "k_exact_accumulate", acc_ms, b_acc
-        note = ("HBM bound: one pass over the f64 values and row ids in counting-sort order, reference arithmetic for "
-                "each point's distance to its centroid fused with the per-cluster sums; see DESIGN.md section 4.3")
-    else:
-        kern, k_ms, b_kern = dominant_kernel(path, s), screen_ms, int(b_iter * done)
-        note = (f"mean over launches that processed {done:.3f} of their steps (the rest skipped on carried bounds; "
-                "algorithmic bytes scaled by that share).  "
-                "VALU-issue / LDS bound at K=100, not HBM bound: the f32 screen spends 10 issue slots of 4 "
-                "cycles per stored entry for 16 points x 32 centroids (exact f64 tiles: 4 slots per entry "
-                "for 4 points x 16 centroids); see DESIGN.md section 4")
-    achieved = b_kern / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
+    done = 1.0 - (mode[5] - skipped0) / (steps_per_tile * args.steps) if path == 1 and steps_per_tile else 1.0
+    scr_name = dominant_kernel(path, s)
+    rl_screen = roofline_obj(scr_name, screen_ms, int(b_iter * done),
+                             f"assignment kernel; mean over the timed launches, which processed {done:.3f} of their 16-point "
+                             "steps (the rest skipped on carried bounds; SURVEY 8(d) bytes of an iteration scaled by that "
+                             "share).  VALU-issue / LDS bound at K=100, not HBM bound (DESIGN.md section 4)")
+    rl_acc = roofline_obj("k_exact_accumulate", acc_ms, b_acc,
+                          "HBM bound: one pass over the f64 values and row ids in counting-sort order, reference arithmetic "
+                          "for each point's distance to its centroid fused with the per-cluster sums (DESIGN.md section 4.2); "
+                          "bytes = nnz*(8+2) + n*12 + 16*p*K, all streamed in every launch") if acc_ms > 0 else None
+    # top-level roofline: the kernel that took more of the timed region (both are always listed under by_kernel, each
+    # with ONE byte model, so either can be followed from round to round)
+    top = rl_acc if (rl_acc and acc_ms > screen_ms) else rl_screen
+    roofline = dict(top)
+    roofline["traffic"] = pmc_traffic(top["kernel"], n_local, K, p2, args.start)
+    roofline["by_kernel"] = {scr_name: rl_screen, **({"k_exact_accumulate": rl_acc} if rl_acc else {})}
+    roofline["screen_steps_processed_share"] = done
     ops = 3.0 * nnz_local * K
-    traffic = None
-    valu_pmc = {}
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
-        try:
-            with open(pmc) as f:
-                recs = json.load(f)
-            for rec in (recs if isinstance(recs, list) else [recs]):
-                if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
-                        and (rec.get("start", "sample") == args.start or kern == "k_exact_accumulate")  # (its stream
-                        # is the same from any start; the screen's launches are not)
-                        and str(rec.get("kernel", "")).startswith(kern)):
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    if kern.startswith("k_screen"):
-                        valu_pmc = {"issue_utilization_pmc": rec.get("valu_issue_utilization"),
-                                    "effective_clock_ghz_pmc": rec.get("effective_clock_ghz")}
-        except Exception:
-            traffic = None
+    out = eng.out.cpu().numpy()
 
     result = {
         "metric": "Lloyd iters/sec + achieved HBM GB/s, N=1e8 d=1024 K=100",
@@ -219,42 +250,63 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"sparsified GMM N={n_total} d={p} (p2={p2}) K={K} s={s} nnz/point, "
-                               f"points sharded over {world} GPU(s), dense-centre Lloyd iteration",
+        "value_definition": "timed steps = consecutive iterations of kmeans_sparsified-style runs from the start centres "
+                            f"to dff < {TOL:g} (MaxIter {MAXITER}), host reads dff every iteration; a converged run is "
+                            "followed by the next one from the same start with the library's carried state reset; the timed "
+                            "region begins at a run's first (cold) iteration regardless of --warmup",
+        "config": {"workload": f"sparsified GMM N={n_total} d={p} (p2={p2}) K={K} s={s} nnz/point, {args.order} point order, "
+                               f"points sharded over {world} GPU(s), dense-centre Lloyd runs to convergence from a "
+                               f"'{args.start}' start",
                    "n_total": n_total, "n_per_gpu": n_local, "p2": p2, "K": K, "nnz_per_point": s, "start": args.start,
+                   "order": args.order, "tol": TOL, "maxiter": MAXITER,
                    "gamma": gamma, "parallelism": f"dp{world} (1 RCCL all-reduce/iter)" if world > 1 else "single GPU",
                    "datagen_s": round(t_gen, 1), "final_obj": float(np.sqrt(out[1])),
+                   "runs_completed_in_timed_region": loop.runs_completed, "run_lengths": loop.run_lengths,
                    "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "
                                   "bit-identical to the all-exact kernels)" if path == 1 else "exact f64 tiles",
                    "uncertified_points_last_iter": listed,
-                   # rounds (of 4 stored entries) evaluated for all centroids / per column in the last iteration:
-                   # equal = plain screen; fewer = the two-phase screen switched itself on (converged, separated data)
-                   "screen_rounds_last_iter": [rounds_all, rounds],
-                   # form of the last screen call (plain / two-phase / hinted: the previous iteration's
-                   # min-distances let 16-point steps stop after rounds_all rounds) and the number of
-                   # (16-point step, centroid tile) pairs it finished early
                    "screen_form_last_iter": {0: "plain", 1: "two-phase", 2: "hinted"}.get(mode[0], "none"),
-                   "early_finished_steps": mode[3] if mode[0] == 2 else None,
-                   # 16-point steps the screen skipped altogether in the last iteration: the bounds carried from the
-                   # previous call (triangle inequality under the centroids' drift) proved their assignments unchanged
                    "skipped_steps_last_iter": mode[4],
-                   "steps_per_centroid_tile": (n_local + 15) // 16},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "kernel": kern, "kernel_ms": k_ms,
-                     "algorithmic_bytes_per_launch": b_kern,
-                     "kernels_ms": {dominant_kernel(path, s): screen_ms, "k_exact_accumulate": acc_ms},
-                     "screen_steps_processed_share": done,
-                     "note": note},
+                   "steps_per_centroid_tile": steps_per_tile},
+        "roofline": roofline,
         "valu": {"distance_terms_per_s": (nnz_local * K) / (screen_ms * 1e-3) if screen_ms == screen_ms else None,
                  "exact_f64_op_equivalent_Tops": ops / (screen_ms * 1e-3) / 1e12 if screen_ms == screen_ms else None,
-                 "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS, **valu_pmc},
+                 "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS,
+                 "note": "op-equivalents of the exact f64 arithmetic the screen makes unnecessary; exceeds the f64 peak "
+                         "whenever steps are skipped or finished early -- not a utilisation figure"},
         "whole_iter_gbs": b_iter / (elapsed / args.steps) / 1e9,
         "fwht": fw,
     }
 
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        result["cpu_baseline"] = cpu_baseline(data, centers0, p2, K, gamma, s, min(args.cpu_sample, n_local), n_total)
+    # ---- regimes: one complete run to convergence, iteration by iteration, on this dataset and on the other order ----
+    if not args.no_regimes:
+        regimes = {args.order: traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)}
+        other = "shuffled" if args.order == "block" else "block"
+        cpu_data = None
+        if rank == 0 and world == 1 and args.cpu_sample > 0:
+            cpu_data = cpu_sample_arrays(data, centers0, s, min(max(args.cpu_sample, 4_000_000), n_local))
+        del loop, eng
+        shard.close()
+        del data, shard
+        torch.cuda.empty_cache()
+        data2, shard2, centers02, t_gen2 = make_dataset(other)
+        loop2 = Loop(shard2, centers02)
+        loop2.steps(1)                                     # set-up of the shard's screen copy happens on the first call
+        loop2.restart()
+        regimes[other] = traced_run(loop2, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)
+        regimes[other]["datagen_s"] = round(t_gen2, 1)
+        result["regimes"] = regimes
+        del loop2
+        shard2.close()
+        del data2, shard2
+        torch.cuda.empty_cache()
+    else:
+        cpu_data = None
+        if rank == 0 and world == 1 and args.cpu_sample > 0:
+            cpu_data = cpu_sample_arrays(data, centers0, s, min(max(args.cpu_sample, 4_000_000), n_local))
+
+    if cpu_data is not None:
+        result["cpu_baseline"] = cpu_baseline(cpu_data, p2, K, gamma, s, min(args.cpu_sample, n_local), n_total)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
@@ -263,36 +315,138 @@ def main():
         dist.destroy_process_group()
 
 
+def roofline_obj(kernel, ms, nbytes, note):
+    ok = ms == ms and ms > 0
+    ach = nbytes / (ms * 1e-3) / 1e9 if ok else None
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None, "kernel": kernel, "kernel_ms": ms if ok else None,
+            "algorithmic_bytes_per_launch": nbytes, "note": note}
+
+
+def pmc_traffic(kern, n_local, K, p2, start):
+    """HBM bytes per launch of ``kern`` from the committed PMC passes (profiles/pmc_latest.json: separate --pmc runs,
+    FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes), when a record for exactly this workload exists."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(pmc):
+        return None
+    try:
+        with open(pmc) as f:
+            recs = json.load(f)
+        for rec in (recs if isinstance(recs, list) else [recs]):
+            if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
+                    and (rec.get("start", "sample") == start or kern == "k_exact_accumulate")
+                    and str(rec.get("kernel", "")).startswith(kern)):
+                return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+    return None
+
+
+def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name):
+    """One complete run from the start centres to dff < Tol with a wall-clock stamp after every iteration's host read
+    (max over ranks per iteration) and the two hot kernels' HIP-event times per launch."""
+    loop.restart()
+    _lib.check(L.spkm_timing_log(ctx.handle, 2))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    stamps = [time.perf_counter()]
+    objs = []
+    form = []
+    while True:
+        dff, obj, done = loop.step()
+        stamps.append(time.perf_counter())
+        objs.append(obj)
+        if done:
+            break
+    its = loop.it
+    ms = np.diff(np.array(stamps)) * 1e3
+    if world > 1:
+        t = torch.tensor(ms, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = t.cpu().numpy()
+    kms = read_tlog(2 * its + 8)
+    _lib.check(L.spkm_timing_log(ctx.handle, 0))
+    scr = kms[0::2][:its] if kms.size >= 2 * its else np.array([])
+    acc = kms[1::2][:its] if kms.size >= 2 * its else np.array([])
+    total = float(ms.sum()) * 1e-3
+    tail = ms[-min(3, its):]
+    r = {"iterations": its, "converged": bool(dff < TOL), "final_dff": dff, "final_obj": objs[-1], "seconds": total,
+         "run_to_convergence_iters_per_s": its / total,
+         "run_to_convergence_mean_ms": float(ms.mean()),
+         "cold_no_carry_ms": float(ms[0]),
+         "converged_ms": float(tail.mean()), "converged_iters_per_s": 1e3 / float(tail.mean()),
+         "per_iter_ms": [round(float(v), 2) for v in ms],
+         "kernels_ms": {scr_name: [round(float(v), 2) for v in scr], "k_exact_accumulate": [round(float(v), 2) for v in acc]}}
+    if scr.size:
+        # one kernel per regime, one byte model each: the cold iteration is the assignment kernel over every step,
+        # the converged one the exact accumulation pass
+        r["roofline_cold_no_carry"] = roofline_obj(scr_name, float(scr[0]), b_iter,
+                                                   "plain screen, every 16-point step, SURVEY 8(d) bytes of an iteration")
+        r["roofline_converged"] = roofline_obj("k_exact_accumulate", float(acc[-min(3, its):].mean()), b_acc,
+                                               "exact confirmation + accumulation pass, nnz*(8+2) + n*12 + 16*p*K bytes")
+    loop.restart()
+    return r
+
+
 def dominant_kernel(path, s):
-    """Name of the kernel the roofline object describes: the f32 screen (4 lanes per point for columns of up to
+    """Name of the assignment kernel: the f32 screen (4 lanes per point for columns of up to
     64 entries, 16 lanes per point beyond) or, on the all-exact path, the f64 tile kernel."""
     if path != 1:
         return "k_assign_tile"
     return "k_screen_quad" if s <= 64 else "k_screen_tile"
 
 
-def cpu_baseline(data, centers0, p2, K, gamma, s, n_cpu, n_total):
-    """The CPU oracle (a port: the reference's own C cannot be built without MATLAB's mex.h) timed on
-    one host core -- the reference's distance mex is single-threaded
-    (private/SparseMatrixMinusCluster.c:117-184) -- on the first n_cpu points of the same workload."""
-    from oracle import oracle as O
+def host_cores():
+    """cores this process may run on (the container's share of the box, not the box's total)"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except Exception:
+        return max(1, os.cpu_count() or 1)
 
+
+def cpu_sample_arrays(data, centers0, s, n_cpu):
+    """host copies of the first n_cpu points (and the start centres) for the CPU legs, taken before the dataset is freed"""
     jc = np.arange(0, (n_cpu + 1) * s, s, dtype=np.uint64)
     ir = data["ir"][: n_cpu * s].cpu().numpy().astype(np.uint16).astype(np.uint64)
     x = data["x"][: n_cpu * s].cpu().numpy()
-    C0 = centers0.cpu().numpy().T.copy()
+    return dict(jc=jc, ir=ir, x=x, C0=centers0.cpu().numpy().T.copy(), n=n_cpu)
+
+
+def cpu_baseline(cd, p2, K, gamma, s, n_one, n_total):
+    """The CPU oracle (a port: the reference's own C cannot be built without MATLAB's mex.h) on the host's cores, on a
+    bounded sample of the same workload, scaled linearly to N:
+      * `value`, cores = 1: the faithful variant -- the reference's distance mex is single-threaded
+        (private/SparseMatrixMinusCluster.c:117-184) and so is its MATLAB update loop;
+      * `all_cores`: the same iteration with the points column-partitioned over every host core the way the reference's
+        one threaded mex partitions its columns (hadamard_pthreads.c:121-204) -- the box-level baseline."""
+    from oracle import oracle as O
+
     O.lib()
+    jc, ir, x, C0 = cd["jc"], cd["ir"], cd["x"], cd["C0"]
     t0 = time.perf_counter()
-    O.lloyd(p2, n_cpu, jc, ir, x, C0, gamma, maxiter=1, tol=0.0)
+    O.lloyd(p2, n_one, jc[: n_one + 1], ir[: n_one * s], x[: n_one * s], C0, gamma, maxiter=1, tol=0.0)
     dt = time.perf_counter() - t0
-    out = {"value": 1.0 / (dt * n_total / n_cpu), "unit": "Lloyd iters/sec", "cores": 1, "kind": "port",
+    out = {"value": 1.0 / (dt * n_total / n_one), "unit": "Lloyd iters/sec", "cores": 1, "kind": "port",
            "sample": f"1 Lloyd iteration of oracle/orc_sparse.c orc_lloyd (gcc -O, single thread) on the first "
-                     f"{n_cpu} points of the same dataset in {dt:.2f} s, scaled linearly to N={n_total}",
-           "host_cpus": os.cpu_count()}
+                     f"{n_one} points of the same dataset in {dt:.2f} s, scaled linearly to N={n_total}",
+           "host_cpus": os.cpu_count(), "host_cpus_usable": host_cores()}
+    try:
+        threads = host_cores()
+        n_all = cd["n"]
+        t0 = time.perf_counter()
+        O.lloyd_iter_threads(p2, n_all, jc[: n_all + 1], ir[: n_all * s], x[: n_all * s], C0, gamma, threads)
+        dta = time.perf_counter() - t0
+        out["all_cores"] = {"value": 1.0 / (dta * n_total / n_all), "unit": "Lloyd iters/sec", "cores": threads,
+                            "sample": f"1 Lloyd iteration of orc_lloyd_iter_threads (points column-partitioned over "
+                                      f"{threads} pthreads as hadamard_pthreads.c:121-204 partitions its columns) on the first "
+                                      f"{n_all} points in {dta:.2f} s, scaled linearly to N={n_total}"}
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        out["all_cores"] = {"error": str(e)}
     # the preconditioner's CPU path: the reference's one multi-threaded mex (private/hadamard_pthreads.c, static
     # column partition over NTHREADS = maxNumCompThreads(), setup_kmeans.m:45), restated in oracle/orc_fwht.c
     try:
-        threads = max(1, min(os.cpu_count() or 1, 64))
+        threads = max(1, min(host_cores(), 64))
         cols = 32768
         xin = np.random.default_rng(0).standard_normal(cols * p2)
         yout = np.zeros_like(xin)
@@ -302,7 +456,7 @@ def cpu_baseline(data, centers0, p2, K, gamma, s, n_cpu, n_total):
         dt = time.perf_counter() - t0
         out["fwht"] = {"columns_per_s": cols / dt, "threads": threads, "m": p2,
                        "sample": f"{cols} columns of length {p2}, oracle/orc_fwht.c orc_fwht_threads"}
-    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+    except Exception as e:
         out["fwht"] = {"error": str(e)}
     return out
 

@@ -54,6 +54,11 @@ def lib():
         L.orc_lloyd.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_double,
                                 _f64p, _i32p, _f64p, _f64p, _f64p]
         L.orc_lloyd.restype = C.c_int
+        L.orc_lloyd_ex.argtypes = [_sz, _sz, C.POINTER(C.c_size_t), _u64p, _u64p, _f64p, C.c_double, C.c_int, C.c_int,
+                                   C.c_double, C.c_int, _f64p, _i32p, _f64p, _f64p, _f64p, C.POINTER(C.c_int)]
+        L.orc_lloyd_ex.restype = C.c_int
+        L.orc_lloyd_iter_threads.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, C.c_double, C.c_int, _f64p, _i32p,
+                                             _f64p, C.c_uint]
         L.orc_fwht.argtypes = [C.c_uint, _sz, _f64p, _f64p]
         L.orc_fwht_threads.argtypes = [C.c_uint, _sz, _f64p, _f64p, C.c_uint]
         L.orc_check_pow2.argtypes = [C.c_uint]
@@ -147,18 +152,39 @@ def finalize_centers(sums, counts, nk, gamma, centers):
     return c.reshape(K, p).T.copy()
 
 
-def lloyd(p, n, jc, ir, x, centers, gamma, unbiased=True, maxiter=100, tol=1e-6):
-    """Dense-centre Lloyd loop (kmeans_sparsified.m:417-486).  Returns dict."""
+_EMPTY_ACTIONS = {"singleton": 0, "drop": 1, "error": 2}
+
+
+def lloyd(p, n, jc, ir, x, centers, gamma, unbiased=True, maxiter=100, tol=1e-6, empty_action="singleton"):
+    """Dense-centre Lloyd loop (kmeans_sparsified.m:417-486) with the reference's three EmptyAction choices
+    (:432-445,454-459).  Returns dict; under 'drop' ``centers`` has the surviving columns only and ``assign`` is
+    None when the last iteration dropped one (the reference leaves assignments = [] then, :457)."""
     jc, ir, x = _csc(jc, ir, x)
     centers = np.asarray(centers, np.float64).reshape(p, -1)
     K = centers.shape[1]
     c = _colmajor(centers).copy()
     a, mind = np.zeros(n, np.int32), np.zeros(n)
     dff, obj = np.zeros(maxiter), np.zeros(maxiter)
-    its = lib().orc_lloyd(p, n, K, jc, ir, x, float(gamma), int(bool(unbiased)), int(maxiter), float(tol),
-                          c, a, mind, dff, obj)
-    return dict(iterations=its, centers=c.reshape(K, p).T.copy(), assign=a, mind=mind,
-                dff=dff[:its], obj=obj[:its])
+    Kio, dropped = C.c_size_t(K), C.c_int(0)
+    its = lib().orc_lloyd_ex(p, n, C.byref(Kio), jc, ir, x, float(gamma), int(bool(unbiased)), int(maxiter),
+                             float(tol), _EMPTY_ACTIONS[empty_action], c, a, mind, dff, obj, C.byref(dropped))
+    if its < 0:
+        raise RuntimeError("One cluster lost all its members")       # kmeans_sparsified.m:439
+    Kf = int(Kio.value)
+    return dict(iterations=its, centers=c[: p * Kf].reshape(Kf, p).T.copy(), assign=None if dropped.value else a,
+                mind=mind, dff=dff[:its], obj=obj[:its], K=Kf)
+
+
+def lloyd_iter_threads(p, n, jc, ir, x, centers, gamma, threads, unbiased=True):
+    """ONE Lloyd iteration, points column-partitioned over ``threads`` workers as hadamard_pthreads partitions its
+    columns (hadamard_pthreads.c:121-204) -- the all-cores CPU baseline.  Returns dict(centers, assign, mind)."""
+    jc, ir, x = _csc(jc, ir, x)
+    centers = np.asarray(centers, np.float64).reshape(p, -1)
+    K = centers.shape[1]
+    c = _colmajor(centers).copy()
+    a, mind = np.zeros(n, np.int32), np.zeros(n)
+    lib().orc_lloyd_iter_threads(p, n, K, jc, ir, x, float(gamma), int(bool(unbiased)), c, a, mind, int(threads))
+    return dict(centers=c.reshape(K, p).T.copy(), assign=a, mind=mind)
 
 
 def fwht(x, threads: int = 0):

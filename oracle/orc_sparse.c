@@ -240,21 +240,31 @@ double orc_obj(size_t n, const double *mind)
     return sqrt(s);
 }
 
-/* kmeans_sparsified.m:417-486, the Lloyd loop with dense centres, MLcorrection,
- * EmptyAction='singleton' (:436-437: [~,iMax]=max(distances); centers(:,ki)=X(:,iMax)).
- * Used as the timed CPU baseline (bench.py cpu_baseline, kind "port") and as the
- * end-to-end checker.  Returns the number of iterations run; outputs the last
- * assignments / min distances, dff and obj per iteration (arrays of maxiter). */
-int orc_lloyd(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir, const double *x,
-              double gamma, int unbiased, int maxiter, double tol, double *centers /* p*K in/out */,
-              int32_t *assign, double *mind, double *dff_hist, double *obj_hist)
+/* kmeans_sparsified.m:417-486, the Lloyd loop with dense centres and MLcorrection.
+ * empty_action (kmeans_sparsified.m:432-445,454-459):
+ *   0 'singleton': [~,iMax]=max(distances); centers(:,ki)=X(:,iMax)   (:436-437; first index of the max, the
+ *                  same column for every empty cluster of that iteration)
+ *   1 'drop':      dropCenters(end+1)=ki (:441); after the loop over ki the dropped columns are removed from
+ *                  centers AND centersOld (:455-456), assignments=[] (:457), K=size(centers,2) (:458); dff is then
+ *                  taken over the kept columns (:470) and obj over this iteration's distances (:471)
+ *   2 'error':     error('One cluster lost all its members') (:439) -> returns -1
+ * K is in/out (*K_io shrinks under 'drop'); centers holds p*K_in doubles and is compacted in place.
+ * *dropped_last = 1 when the LAST iteration dropped a cluster (the reference then returns empty assignments).
+ * Returns the number of iterations run; assign / mind are those of the last iteration, dff and obj per iteration
+ * (arrays of maxiter). */
+int orc_lloyd_ex(size_t p, size_t n, size_t *K_io, const idx_t *jc, const idx_t *ir, const double *x,
+                 double gamma, int unbiased, int maxiter, double tol, int empty_action,
+                 double *centers /* p*K in/out */, int32_t *assign, double *mind, double *dff_hist,
+                 double *obj_hist, int *dropped_last)
 {
+    size_t K = *K_io;
     double *Cs = (double *)malloc(p * K * sizeof(double));
     double *old = (double *)malloc(p * K * sizeof(double));
     double *sums = (double *)malloc(p * K * sizeof(double));
     double *counts = (double *)malloc(p * K * sizeof(double));
     int64_t *nk = (int64_t *)malloc(K * sizeof(int64_t));
-    int its = 0;
+    int its = 0, rc = 0;
+    if (dropped_last) *dropped_last = 0;
     for (its = 1; its <= maxiter; its++) {
         orc_assign(p, n, K, jc, ir, x, centers, unbiased ? gamma : 0., Cs, assign, mind);
         memcpy(old, centers, p * K * sizeof(double));
@@ -263,13 +273,28 @@ int orc_lloyd(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir, co
         size_t imax = 0;
         int have_empty = 0;
         for (size_t k = 0; k < K; k++) if (nk[k] == 0) have_empty = 1;
-        if (have_empty) {
+        if (dropped_last) *dropped_last = 0;
+        if (have_empty && empty_action == 2) { rc = -1; break; }
+        if (have_empty && empty_action == 0) {
             for (size_t i = 1; i < n; i++) if (mind[i] > mind[imax]) imax = i;
             for (size_t k = 0; k < K; k++) {
                 if (nk[k] != 0) continue;
                 for (size_t r = 0; r < p; r++) centers[k * p + r] = 0.;
                 for (idx_t j = jc[imax]; j < jc[imax + 1]; j++) centers[k * p + ir[j]] = x[j];
             }
+        }
+        if (have_empty && empty_action == 1) {
+            size_t kk = 0;
+            for (size_t k = 0; k < K; k++) {
+                if (nk[k] == 0) continue;
+                if (kk != k) {
+                    memmove(centers + kk * p, centers + k * p, p * sizeof(double));
+                    memmove(old + kk * p, old + k * p, p * sizeof(double));
+                }
+                kk++;
+            }
+            K = kk;
+            if (dropped_last) *dropped_last = 1;
         }
         const double dff = orc_fro_diff(p * K, old, centers);
         const double obj = orc_obj(n, mind);
@@ -279,5 +304,86 @@ int orc_lloyd(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir, co
     }
     if (its > maxiter) its = maxiter;
     free(Cs); free(old); free(sums); free(counts); free(nk);
-    return its;
+    *K_io = K;
+    return rc ? rc : its;
+}
+
+/* EmptyAction='singleton' form kept under its round-1 name (bench.py's cpu_baseline, smoke(), the Lloyd tests). */
+int orc_lloyd(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir, const double *x,
+              double gamma, int unbiased, int maxiter, double tol, double *centers /* p*K in/out */,
+              int32_t *assign, double *mind, double *dff_hist, double *obj_hist)
+{
+    size_t Kv = K;
+    return orc_lloyd_ex(p, n, &Kv, jc, ir, x, gamma, unbiased, maxiter, tol, 0, centers, assign, mind, dff_hist,
+                        obj_hist, NULL);
+}
+
+/* ------------------------------------------------------------------------- */
+/* All-cores variant of ONE Lloyd iteration for bench.py's cpu_baseline: the reference's distance
+ * mex is single-threaded (SparseMatrixMinusCluster.c:117-184); the only threading pattern the reference has is
+ * hadamard_pthreads' static column partition (hadamard_pthreads.c:121-204: NTHREADS workers of floor(n/NTHREADS)
+ * columns plus one more for the remainder, joined before returning).  The same partition is applied here to the
+ * points: every worker runs orc_assign on its block and accumulates private sums / counts, the main thread adds
+ * the partials in worker order and finalises.  Assignments and min-distances are those of the single-thread code
+ * bit for bit (columns are independent); sums differ from it in summation order only. */
+#include <pthread.h>
+typedef struct {
+    size_t p, K, lo, hi;
+    const idx_t *jc, *ir;
+    const double *x, *C;
+    double gamma;
+    int32_t *assign;
+    double *mind, *sums, *counts;
+    int64_t *nk;
+} lloyd_job_t;
+
+static void *lloyd_worker(void *arg)
+{
+    lloyd_job_t *jb = (lloyd_job_t *)arg;
+    const size_t p = jb->p, K = jb->K;
+    double *Cs = (double *)malloc(p * K * sizeof(double));
+    /* jc is indexed absolutely: pass the block through shifted base pointers */
+    orc_assign(p, jb->hi - jb->lo, K, jb->jc + jb->lo, jb->ir, jb->x, jb->C, jb->gamma, Cs, jb->assign + jb->lo,
+               jb->mind + jb->lo);
+    orc_accumulate(p, jb->hi - jb->lo, K, jb->jc + jb->lo, jb->ir, jb->x, jb->assign + jb->lo, jb->sums, jb->counts,
+                   jb->nk);
+    free(Cs);
+    return NULL;
+}
+
+void orc_lloyd_iter_threads(size_t p, size_t n, size_t K, const idx_t *jc, const idx_t *ir, const double *x,
+                            double gamma, int unbiased, double *centers /* p*K in/out */, int32_t *assign,
+                            double *mind, unsigned nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    size_t nworkers, per;
+    if (n <= nthreads) { nworkers = n ? n : 1; per = n ? 1 : 0; }
+    else { per = n / nthreads; nworkers = nthreads + ((n % nthreads) ? 1 : 0); }
+    lloyd_job_t *jobs = (lloyd_job_t *)calloc(nworkers, sizeof(lloyd_job_t));
+    pthread_t *th = (pthread_t *)malloc(nworkers * sizeof(pthread_t));
+    size_t col = 0;
+    for (size_t t = 0; t < nworkers; t++) {
+        size_t cnt = per;
+        if (n > nthreads && t == nthreads) cnt = n - col; /* remainder worker */
+        lloyd_job_t *jb = &jobs[t];
+        jb->p = p; jb->K = K; jb->lo = col; jb->hi = col + cnt;
+        jb->jc = jc; jb->ir = ir; jb->x = x; jb->C = centers; jb->gamma = unbiased ? gamma : 0.;
+        jb->assign = assign; jb->mind = mind;
+        jb->sums = (double *)malloc(p * K * sizeof(double));
+        jb->counts = (double *)malloc(p * K * sizeof(double));
+        jb->nk = (int64_t *)malloc(K * sizeof(int64_t));
+        col += cnt;
+        pthread_create(&th[t], NULL, lloyd_worker, jb);
+    }
+    for (size_t t = 0; t < nworkers; t++) pthread_join(th[t], NULL);
+    double *sums = jobs[0].sums, *counts = jobs[0].counts;
+    int64_t *nk = jobs[0].nk;
+    for (size_t t = 1; t < nworkers; t++) {
+        for (size_t q = 0; q < p * K; q++) { sums[q] += jobs[t].sums[q]; counts[q] += jobs[t].counts[q]; }
+        for (size_t k = 0; k < K; k++) nk[k] += jobs[t].nk[k];
+    }
+    orc_finalize_centers(p, K, sums, counts, nk, gamma, centers);
+    for (size_t t = 0; t < nworkers; t++) { free(jobs[t].sums); free(jobs[t].counts); free(jobs[t].nk); }
+    free(jobs);
+    free(th);
 }

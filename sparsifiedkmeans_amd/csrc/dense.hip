@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_dense_assign(const double* __restrict__
         if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
     }
     if (kq == 0 && my_pt < n) {
+        if ((unsigned)bk >= (unsigned)K) bk = 0; // non-finite distances: index 1 as MATLAB's min(), never out of range
         assign[my_pt] = bk;
         dist[my_pt] = best;
     }

@@ -798,6 +798,7 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
             if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
         }
         if (lane == 0) {
+            if ((unsigned)bk >= (unsigned)K) bk = 0; // non-finite distances: MATLAB's min() gives index 1; never an out-of-range cluster
             assign[i] = bk;
             if (aprev && aprev[i] != bk) atomicAdd(changed, 1u);
         }

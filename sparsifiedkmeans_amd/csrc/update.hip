@@ -64,6 +64,10 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ part
             const double d = sqrt(part_acc[(size_t)g * n + i]);
             if (d < best) { best = d; bk = part_k[(size_t)g * n + i]; }
         }
+        // non-finite input (Inf / NaN distances to every centroid): no '<' ever held and the tile kernels left their
+        // sentinel.  MATLAB's min() returns index 1 there; what matters on this side of the ABI is that everything
+        // downstream (histogram, counting sort, accumulation) indexes with a valid cluster.
+        if ((unsigned)bk >= (unsigned)K) bk = 0;
         assign[i] = bk;
         mind[i] = best;
         obj2 += best * best;

@@ -242,15 +242,39 @@ def kmeans_sparsified(X, K, **options):
                 blk = X[:, c0:c0 + nn].T
             sp_.append(np.ascontiguousarray(blk))
         shard = sp_.finish()
+        vals_ = sp_.x[: n * small_p]
+        # one Inf / NaN entry makes its whole mixed column non-finite (every output of the transform is a signed sum
+        # of all inputs), so the sampled values tell.  The reference has no such check: its run ends in
+        # error('Found NaN in centers') (:480-484) a few iterations later; here the data is refused up front, because
+        # the argmin kernels are specified for finite distances only.
+        if not bool(torch.isfinite(vals_).all().item()):
+            raise ValueError("X must be finite (Inf / NaN entries found)")
+        nnz = n * small_p
+        nzm_ = vals_ != 0
+        if not bool(nzm_.all().item()):
+            # sparse(i,j,v) drops entries that are exactly 0 (randsample_fixedNumberEntries.m:62): they are absent from
+            # the masked distance and from spones(X) (the Cnt denominator, :352-355).  All-zero points, or exact +-
+            # cancellation in the transform of integer data.  Rebuild the shard as a ragged CSC without them.
+            cnt_ = nzm_.view(n, small_p).sum(dim=1)
+            jc_ = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            jc_[1:] = torch.cumsum(cnt_, 0)
+            nnz = int(jc_[-1].item())
+            x2_ = torch.zeros(nnz + 48, dtype=torch.float64, device=dev)
+            ir2_ = torch.zeros(nnz + 48, dtype=sp_.ir.dtype, device=dev)
+            x2_[:nnz] = vals_[nzm_]
+            ir2_[:nnz] = sp_.ir[: n * small_p][nzm_]
+            shard = Shard.from_device(ctx, p2, jc_, ir2_, x2_, nnz=nnz)
+        del nzm_
         torch.cuda.synchronize()
         OUTPUT["TimeToSketch"] = OUTPUT["TimeToSample"] = time.time() - t1       # fused: one number for both
-        nnz = n * small_p
     else:
         # DCT / no sketch: mix on the device (a GEMM or nothing), sample on the host (randsample_fixedNumberEntries,
         # :334), MB_limit columns at a time -- the same generator runs through all chunks, so a 'DataFile' run
         # draws exactly the samples of the in-memory run (sampleAndMixFromLargeFile.m:100-129)
         nn = max(1, min(n, int(o["MB_limit"] * 2**20 // (8 * p)))) if LoadFromDisk else n
-        srng = np.random.default_rng(sample_seed)
+        # the stream depends on (seed, offset of this rank's block): ranks of a distributed run draw different row
+        # patterns, a single process draws what it always drew
+        srng = np.random.default_rng(sample_seed if first == 0 else [sample_seed, first])
         t_mix = t_smp = 0.0
         parts_ = []
         for c0 in range(0, n, nn):
@@ -268,6 +292,8 @@ def kmeans_sparsified(X, K, **options):
             t_smp += time.time() - t1
         OUTPUT["TimeToSketch"], OUTPUT["TimeToSample"] = t_mix, t_smp
         Y = parts_[0] if len(parts_) == 1 else sp.hstack(parts_, format="csc")
+        if not np.all(np.isfinite(Y.data)):
+            raise ValueError("X must be finite (Inf / NaN entries found)")
         shard = Shard.from_scipy(ctx, Y)
         nnz = Y.nnz
     if Display in ("iter", "final"):
@@ -314,9 +340,10 @@ def kmeans_sparsified(X, K, **options):
 
     best = dict(obj=np.inf)
     distances = None
+    K_start = K                               # K of a 'Start' matrix
     for trial in range(Replicates):
         t1 = time.time()
-        Kc = K
+        Kc = K                                # (after an EmptyAction='drop' the reference keeps the smaller K, :458)
         sparse_mask = None                    # [K, p2] uint8 while the centres are sparse
         if isinstance(start, str):
             s = start.lower()
@@ -335,8 +362,9 @@ def kmeans_sparsified(X, K, **options):
             S = np.asarray(start, np.float64)
             if not o["ColumnSamples"]:
                 S = S.T                                                          # want p x K (:403-405)
-            if S.shape != (p, K):
+            if S.shape != (p, K_start):
                 raise ValueError("Start matrix must be K x p (or p x K with ColumnSamples)")
+            Kc = K_start
             centers_np = sketch.mix(torch.tensor(np.ascontiguousarray(S.T), device=dev)).cpu().numpy().T  # :406
             if Replicates > 1:
                 warnings.warn("initialization is specified, so running more than 1 replicate is not helpful")
@@ -347,27 +375,41 @@ def kmeans_sparsified(X, K, **options):
         shard.reset_policy()                                                     # new start: nothing learned carries over
         eng = LloydEngine(shard, Kc, gamma, unbiased=unbiased)
         centers = torch.tensor(np.ascontiguousarray(centers_np.T), device=dev)   # [K, p2]
+        if not bool(torch.isfinite(centers).all().item()):
+            raise ValueError("initial centers must be finite")                   # (see the check on X above)
         mask_t = None if sparse_mask is None else torch.tensor(np.ascontiguousarray(sparse_mask.T), device=dev)
         its = 0
         dff = obj = np.nan
         assignments = None
+        dist_t = eng.mind                     # min-distances of the latest iteration (survives a 'drop' re-build of eng)
+        fused_iters = 0
         for its in range(1, int(o["MaxIter"]) + 1):
+            # [assignments,distances] = findClusters(X,centers) (:420) and the per-cluster sums of :430-453
             if mask_t is not None:
                 eng.assign_sparse_step(centers, mask_t)                          # findClusterAssignments.m:63-75
+                eng.accumulate_step()
             else:
-                eng.assign_step(centers)                                         # findClusterAssignments.m:76-82
+                # dense centres: the fused call -- the library's fast path (certified screen, carried bounds) when the
+                # shard qualifies, the exact kernels otherwise; same outputs bit for bit (findClusterAssignments.m:76-82)
+                eng.assign_accumulate_step(centers)
+                fused_iters += 1
+            dist_t = eng.mind
             old = centers.clone()
-            eng.accumulate_step()
             eng.allreduce_step()
+            pk_ = p2 * Kc
             if MLcorrection:
                 eng.finalize_step(centers)                                       # gamma*S./(Cnt+1e-16)  (:447-448)
+                dff2_t = eng.out[0:1]
             else:
                 # centers(:,ki) = mean(full(X(:,ind)),2) (:449-451): plain mean of the sparse columns, zeros included
-                pk_ = p2 * Kc
                 nk_ = eng.reduce[2 * pk_: 2 * pk_ + Kc]
-                nz_ = nk_ > 0
-                centers[nz_] = eng.reduce[:pk_].view(Kc, p2)[nz_] / nk_[nz_, None]
-            nk = eng.global_nk().cpu().numpy()
+                mean_ = eng.reduce[:pk_].view(Kc, p2) / torch.clamp(nk_, min=1.0)[:, None]
+                centers.copy_(torch.where((nk_ > 0)[:, None], mean_, centers))
+                dff2_t = ((old - centers) ** 2).sum().reshape(1)
+            # ONE small device-to-host read per iteration: [dff^2 | obj^2 | cluster sizes]
+            host = torch.cat([dff2_t, eng.reduce[2 * pk_ + Kc: 2 * pk_ + Kc + 1], eng.reduce[2 * pk_: 2 * pk_ + Kc]]).cpu().numpy()
+            dff2, obj2, nk = float(host[0]), float(host[1]), host[2:]
+            obj = float(np.sqrt(obj2))                                           # sqrt(sum(distances.^2)) (:471)
             empty = np.flatnonzero(nk == 0)
             dropped = False
             if empty.size:
@@ -381,34 +423,43 @@ def kmeans_sparsified(X, K, **options):
                     col = torch.tensor(column(imax), device=dev)
                     for ki in empty:
                         centers[ki] = col                                        # centers(:,ki) = X(:,iMax) (:437)
+                    # the finalize kernel's dff covers the clusters it updated; the replaced columns come on top
+                    dff2 = float(((old - centers) ** 2).sum().item())
                 else:                                                            # 'drop' (:441,454-459)
                     keep = np.setdiff1d(np.arange(Kc), empty)
-                    centers = centers[keep].contiguous()
-                    old = old[keep].contiguous()
+                    keep_t = torch.tensor(keep, device=dev)
+                    centers = centers[keep_t].contiguous()
+                    old = old[keep_t].contiguous()
                     Kc = keep.size
+                    if isinstance(start, str):
+                        K = Kc    # the reference overwrites K itself (:458), so later replicates start with fewer clusters
+                    # distances / obj of THIS iteration stay what they are (dist_t, obj above: :471 reads `distances`);
+                    # only the engine's per-K buffers are rebuilt for the next one
                     eng = LloydEngine(shard, Kc, gamma, unbiased=unbiased)
                     dropped = True
+                    dff2 = float(((old - centers) ** 2).sum().item())            # over the kept columns (:455-456,470)
             if mask_t is not None:
                 # after the first ML update the columns are (almost) full: issparse && nnz > .99 -> full (:460-464)
                 filled = float((centers != 0).double().mean().item())
-                if filled > 0.99 or dropped:
+                if filled > 0.99:
                     mask_t = None
                 else:
                     mask_t = (centers != 0).to(torch.uint8).contiguous()
-                    if dropped:
-                        mask_t = mask_t[: Kc]
-            dff = float(torch.linalg.norm(old - centers).item())                 # norm(centersOld-centers,'fro') (:470)
-            obj = float(np.sqrt(eng.reduce[-1].item()))                          # sqrt(sum(distances.^2)) (:471)
+            dff = float(np.sqrt(dff2))                                           # norm(centersOld-centers,'fro') (:470)
             assignments = None if dropped else eng.assign
             if Display == "iter" and its % int(o["PrintEvery"]) == 0:
                 print(f"Iter: {its:3d}; change in cluster centers: {dff:.2e}; objective: {obj:.2e}")
             if dff < o["Tol"]:
                 break                                                            # :476-478
-            if bool(torch.isnan(centers).any().item()):
-                raise RuntimeError("Found NaN in centers")                       # :480-484
+            if not np.isfinite(dff2) and bool(torch.isnan(centers).any().item()):
+                raise RuntimeError("Found NaN in centers")                       # :480-484 (a NaN centre makes dff NaN)
         OUTPUT["replicateTimes"][trial] = time.time() - t1
         OUTPUT["stoppingDiff"][trial], OUTPUT["objectives"][trial], OUTPUT["iterations"][trial] = dff, obj, its
-        distances = eng.mind.cpu().numpy()
+        # (not reference fields) how many iterations went through the fused call, and which path the library took for
+        # the last of them: 1 = certified screen + exact confirmation, 0 = all-exact kernels
+        OUTPUT.setdefault("fusedIterations", np.zeros(Replicates, int))[trial] = fused_iters
+        OUTPUT.setdefault("lastPath", np.zeros(Replicates, int))[trial] = eng.last_path_info()[0] if fused_iters else 0
+        distances = dist_t.cpu().numpy()
         if obj < best["obj"]:                                                    # :493-503
             best = dict(obj=obj, K=Kc, centers=centers.clone(),
                         assign=None if assignments is None else assignments.cpu().numpy().astype(np.int64) + 1,
@@ -651,8 +702,13 @@ def _arthur(ctx, shard, column, n, K, gamma, rng, first=0, n_glob=None, dist_on=
     eng = LloydEngine(shard, 1, gamma if gamma else 1.0, unbiased=bool(gamma))
     dist = None
     for k in range(1, K):
-        c_new = torch.tensor(cols[-1][None, :], device=dev)                      # full(ref) (:31,39), newest centre only
-        eng.assign_step(c_new)
+        c_new = torch.tensor(cols[-1][None, :], device=dev)                      # newest centre only
+        if gamma:
+            eng.assign_step(c_new)                                               # findDist(X, full(ref), [], gamma) (:31)
+        else:
+            # gamma empty: findClusterAssignments(X, ref) with the SPARSE column (:29) -> sparse-centres branch,
+            # distance over supp(x) n supp(c), no scaling (findClusterAssignments.m:71-75)
+            eng.assign_sparse_step(c_new, (c_new != 0).to(torch.uint8).contiguous())
         dist = eng.mind.clone() if dist is None else torch.minimum(dist, eng.mind)
         cum = torch.cumsum(dist * dist, 0)
         local_total = float(cum[-1].item()) if n > 0 else 0.0

@@ -79,12 +79,15 @@ def sparsified_gmm_host(p: int, n: int, K: int, gamma: float, seed: int = 234, f
 # device-side generator for bench-scale workloads (torch only for RNG / sort; the transform is ours)
 # ---------------------------------------------------------------------------------------------
 def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K: int, gamma: float,
-                          seed: int = 234, chunk: int = 65536, noise: float = 0.1):
+                          seed: int = 234, chunk: int = 65536, noise: float = 0.1, order: str = "block"):
     """Generates points [first, first+n_local) of the n_total-point mixture directly into device
     CSC arrays (jc int64, ir int16/int32, x float64), chunk by chunk, never holding more than
     ``chunk`` dense columns.  Every rank generates the same global dataset: cluster means and the
     sign vector come from ``seed``; chunk c uses generator seed ^ (c+1) regardless of which rank
-    owns it (chunks are aligned to global multiples of ``chunk``)."""
+    owns it (chunks are aligned to global multiples of ``chunk``).
+    order = "block": point i belongs to cluster floor(i*K/n) -- contiguous equal blocks, as in
+    example_sparseKMeans.m:19-22; "shuffled": every point draws its cluster uniformly at random (data in
+    arbitrary order: consecutive points have nothing to do with each other)."""
     import torch
 
     from .engine import mix_sample_device
@@ -112,7 +115,10 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
         # generate the whole aligned chunk so the stream is rank-independent, then slice
         m = min((c + 1) * chunk, n_total) - c * chunk
         ids = torch.arange(c * chunk, c * chunk + m, device=dev)
-        lab = (ids * K) // n_total
+        if order == "shuffled":
+            lab = torch.randint(0, K, (m,), generator=gen, device=dev)
+        else:
+            lab = (ids * K) // n_total
         dense = means[lab] + noise * torch.randn((m, p), generator=gen, device=dev, dtype=torch.float32).double()
         a, b = lo - c * chunk, hi - c * chunk
         dense = dense[a:b].contiguous()

@@ -1,0 +1,189 @@
+"""-m gpu: kmeans_sparsified() runs its dense-centre iterations through the fused call
+(spkm_assign_accumulate_dev: certified screen + carried bounds) -- the path bench.py measures -- and stays
+the reference's loop: same iterations, assignments and distances as the all-exact kernels and as the oracle's
+restatement of kmeans_sparsified.m:417-486, including the empty-cluster actions."""
+import warnings
+
+import numpy as np
+import pytest
+
+from util import mix_start, parts, replay_driver_products
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(X, K, **kw):
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return kmeans_sparsified(X.T, K, Sparsify=True, SketchType="Hadamard", **kw)
+
+
+@pytest.mark.parametrize("K,p,gopt", [(20, 256, 0.1), (7, 128, 0.2), (33, 512, 0.05)])
+def test_driver_takes_the_fused_path_and_matches_exact_driver_and_oracle(gpu_ctx, oracle, monkeypatch, K, p, gopt):
+    from sparsifiedkmeans_amd import synth
+
+    n = 6000
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=5)
+    S = X[:, np.random.default_rng(1).choice(n, K, replace=False)].T          # K x p: dense centres from iteration 1
+    out = _run(X, K, SparsityLevel=gopt, Start=S, rng=3, MaxIter=60)
+    IDX, C, SUMD, D, OUT = out
+    assert OUT["lastPath"][0] == 1, "the driver did not reach the screen path"
+    assert OUT["fusedIterations"][0] == OUT["iterations"][0]
+    # (a) the driver on the all-exact kernels
+    monkeypatch.setenv("SPKM_NO_SCREEN", "1")
+    IDXe, Ce, SUMDe, De, OUTe = _run(X, K, SparsityLevel=gopt, Start=S, rng=3, MaxIter=60)
+    monkeypatch.delenv("SPKM_NO_SCREEN")
+    assert OUTe["lastPath"][0] == 0
+    assert OUT["iterations"][0] == OUTe["iterations"][0]
+    assert np.array_equal(IDX, IDXe)
+    # both paths compute every output in reference arithmetic; the per-cluster sums use different launch geometries
+    # (summation order), so centres / distances of a free-running loop agree to rounding
+    assert np.allclose(D, De, rtol=1e-9, atol=0) and np.abs(C - Ce).max() <= 1e-9 * np.abs(Ce).max()
+    # (b) the oracle's loop on the replayed random products
+    Y, d, s, p2, g = replay_driver_products(oracle, X, gopt, 3)
+    ref = oracle.lloyd(p2, n, *parts(Y), mix_start(oracle, S, d, p2), g, maxiter=60, tol=1e-6)
+    assert OUT["iterations"][0] == ref["iterations"]
+    assert np.array_equal(IDX - 1, ref["assign"])
+    assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
+    assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1]
+    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-6 * max(ref["dff"][-1], 1e-9)
+
+
+def _with_far_centre(X, K, seed):
+    """a Start matrix whose last centre sits far from every point: its cluster is empty in iteration 1"""
+    n = X.shape[1]
+    S = X[:, np.random.default_rng(seed).choice(n, K, replace=False)].T.copy()
+    S[-1] = 40.0
+    return S
+
+
+@pytest.mark.parametrize("maxiter", [1, 2, 25])
+def test_singleton_on_the_gpu_matches_the_oracle_loop(gpu_ctx, oracle, maxiter):
+    """EmptyAction='singleton' (kmeans_sparsified.m:436-437): the emptied centre becomes the point farthest from its
+    centre (first index of the max); checked against orc_lloyd, not only as a property."""
+    from sparsifiedkmeans_amd import synth
+
+    p, n, K, gopt = 128, 4000, 6, 0.25
+    X, _, _ = synth.gmm_dense(p, n, K - 1, seed=9)
+    S = _with_far_centre(X, K, 2)
+    with pytest.warns(UserWarning, match="lost all its members"):
+        from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+        IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, Sparsify=True, SketchType="Hadamard", SparsityLevel=gopt,
+                                                 Start=S, rng=11, MaxIter=maxiter, EmptyAction="singleton")
+    Y, d, s, p2, g = replay_driver_products(oracle, X, gopt, 11)
+    ref = oracle.lloyd(p2, n, *parts(Y), mix_start(oracle, S, d, p2), g, maxiter=maxiter, tol=1e-6)
+    assert OUT["iterations"][0] == ref["iterations"]
+    assert np.array_equal(IDX - 1, ref["assign"])
+    assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
+    assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1]
+    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-9 * max(ref["dff"][-1], 1e-12)
+    Cref = (oracle.fwht(ref["centers"]) / np.sqrt(np.float64(p2)) * d[:, None])[:p]   # unmix (:523)
+    assert np.abs(C.T - Cref).max() <= 1e-6 * np.abs(Cref).max()
+
+
+@pytest.mark.parametrize("maxiter", [1, 2, 25])
+def test_drop_on_the_gpu_matches_the_oracle_loop(gpu_ctx, oracle, maxiter):
+    """EmptyAction='drop' (:441,454-459).  maxiter=1: the drop happens in the LAST iteration -- the reference then
+    returns empty assignments, the objective and D of that iteration (round-1 bug: obj 0 and uninitialised D)."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    p, n, K, gopt = 128, 4000, 6, 0.25
+    X, _, _ = synth.gmm_dense(p, n, K - 1, seed=9)
+    S = _with_far_centre(X, K, 2)
+    with pytest.warns(UserWarning, match="lost all its members"):
+        IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, Sparsify=True, SketchType="Hadamard", SparsityLevel=gopt,
+                                                 Start=S, rng=11, MaxIter=maxiter, EmptyAction="drop")
+    Y, d, s, p2, g = replay_driver_products(oracle, X, gopt, 11)
+    ref = oracle.lloyd(p2, n, *parts(Y), mix_start(oracle, S, d, p2), g, maxiter=maxiter, tol=1e-6,
+                       empty_action="drop")
+    assert ref["K"] == K - 1 and C.shape == (K - 1, p)
+    assert OUT["iterations"][0] == ref["iterations"]
+    assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1] and OUT["objectives"][0] > 0
+    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-9 * max(ref["dff"][-1], 1e-12)
+    assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
+    if ref["assign"] is None:
+        assert IDX.size == 0                                 # assignments = [] (:457)
+    else:
+        assert np.array_equal(IDX - 1, ref["assign"])
+    Cref = (oracle.fwht(ref["centers"]) / np.sqrt(np.float64(p2)) * d[:, None])[:p]
+    assert np.abs(C.T - Cref).max() <= 1e-6 * np.abs(Cref).max()
+
+
+def test_drop_error_action_raises(gpu_ctx):
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    X, _, _ = synth.gmm_dense(64, 1500, 3, seed=1)
+    S = _with_far_centre(X, 4, 0)
+    with pytest.raises(RuntimeError, match="One cluster lost all its members"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kmeans_sparsified(X.T, 4, Sparsify=True, SketchType="Hadamard", SparsityLevel=0.5, Start=S, rng=0,
+                          EmptyAction="error")
+
+
+def test_exact_zero_samples_are_dropped_like_sparse_does(gpu_ctx, oracle):
+    """randsample_fixedNumberEntries.m:62 builds the sample with sparse(), which drops entries that are exactly 0:
+    an all-zero point has an EMPTY column (distance 0 to every centre -> cluster 1, no contribution to any count),
+    and integer data can cancel to exact zeros in the transform.  The device sparsifier writes s entries per
+    column; the driver has to compact them away."""
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    p, n, K, gopt = 64, 3000, 4, 0.25
+    rng = np.random.default_rng(4)
+    cen = rng.integers(-6, 7, size=(p, K)).astype(np.float64)
+    X = cen[:, rng.integers(0, K, n)] + rng.integers(-1, 2, size=(p, n))          # small integers: exact cancellations
+    X[:, [0, 17, 2999]] = 0.0                                                     # blank points
+    S = X[:, [5, 6, 7, 8]].T + 0.25
+    IDX, C, SUMD, D, OUT = kmeans_sparsified(X.T, K, Sparsify=True, SketchType="Hadamard", SparsityLevel=gopt,
+                                             Start=S, rng=21, MaxIter=30)
+    Y, d, s, p2, g = replay_driver_products(oracle, X, gopt, 21)
+    assert Y.nnz < n * s and np.diff(Y.indptr)[[0, 17, 2999]].tolist() == [0, 0, 0]
+    ref = oracle.lloyd(p2, n, *parts(Y), mix_start(oracle, S, d, p2), g, maxiter=30, tol=1e-6)
+    assert OUT["iterations"][0] == ref["iterations"]
+    assert np.array_equal(IDX - 1, ref["assign"]) and np.all(IDX[[0, 17, 2999]] == 1) and np.all(D[[0, 17, 2999]] == 0)
+    assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
+
+
+def test_non_finite_data_is_refused(gpu_ctx):
+    from sparsifiedkmeans_amd.kmeans import kmeans_sparsified
+
+    X = np.random.default_rng(0).standard_normal((500, 64))
+    for bad in (np.inf, np.nan):
+        Xb = X.copy()
+        Xb[123, 7] = bad
+        with pytest.raises(ValueError, match="must be finite"):
+            kmeans_sparsified(Xb, 3, Sparsify=True, SketchType="Hadamard", SparsityLevel=0.25, rng=0)
+    S = X[:3].copy()
+    S[1, 1] = np.nan
+    with pytest.raises(ValueError, match="must be finite"):
+        kmeans_sparsified(X, 3, Sparsify=True, SketchType="Hadamard", SparsityLevel=0.25, rng=0, Start=S)
+
+
+def test_non_finite_distances_never_index_out_of_range(gpu_ctx):
+    """C ABI level (no driver check in the way): a point with an Inf entry has distance Inf / NaN to every centroid;
+    no '<' ever holds in the argmin.  The assignment must still be a valid cluster (MATLAB's min() gives index 1)
+    on the exact path and on the fused path, and the accumulation that follows must not touch foreign memory."""
+    import torch
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    from util import random_csc
+
+    p, n, K = 128, 5000, 12
+    X = random_csc(p, n, 16, seed=3)
+    X.data[16 * 100 + 3] = np.inf
+    X.data[16 * 4000 + 5] = np.nan
+    shard = Shard.from_scipy(gpu_ctx, X)
+    Cm = torch.tensor(np.random.default_rng(0).standard_normal((K, p)), device="cuda")
+    for fused in (False, True):
+        eng = LloydEngine(shard, K, 16 / 128)
+        if fused:
+            eng.assign_accumulate_step(Cm)
+        else:
+            eng.assign_step(Cm)
+            eng.accumulate_step()
+        a = eng.assign.cpu().numpy()
+        assert a.min() >= 0 and a.max() < K
+        nk = eng.global_nk().cpu().numpy()
+        assert nk.sum() == n and np.array_equal(nk, np.bincount(a, minlength=K))

@@ -65,3 +65,34 @@ def sample_rows_reference(seed, col0, n, p2, s):
             taken[idx] += 1
     assert np.all(taken == s)
     return out
+
+
+def replay_driver_products(oracle, X, gamma_opt, seed, drop_zeros=True):
+    """The random products kmeans_sparsified(X.T, K, Sparsify=True, SketchType='Hadamard', rng=seed) draws, replayed
+    on the host with the oracle's transform: returns (Y scipy CSC p2 x n, sign vector d, s, p2, gamma_used).
+    X is p x n (points as columns); p must make 16 <= p2 <= 16384 (the fused device sparsifier's range)."""
+    from sparsifiedkmeans_amd import synth
+
+    p, n = X.shape
+    p2 = 1 << int(np.ceil(np.log2(p)))
+    rng = np.random.default_rng(seed)
+    d = np.sign(rng.standard_normal(p2))
+    d[d == 0] = 1
+    sample_seed = int(rng.integers(0, 2**63 - 1))
+    Xm = oracle.mix(X, d, p2)
+    s = synth.small_p_of(gamma_opt, p2)
+    rows = sample_rows_reference(sample_seed, 0, n, p2, s)
+    vals = Xm[rows, np.arange(n)[:, None]] / (np.float64(s) / np.float64(p2))
+    Y = sp.csc_matrix((vals.ravel(), rows.ravel(), np.arange(0, (n + 1) * s, s)), shape=(p2, n))
+    if drop_zeros:
+        Y.eliminate_zeros()                                  # sparse() drops exact zeros (randsample_fixedNumberEntries.m:62)
+    return Y, d, s, p2, s / p
+
+
+def mix_start(oracle, S, d, p2):
+    """centers = mix(start) (kmeans_sparsified.m:406): S is K x p in the original space -> p2 x K.  No (1+2eps)
+    pre-scale here (that belongs to the data, :292)."""
+    K, p = S.shape
+    Z = np.zeros((p2, K))
+    Z[:p] = S.T
+    return oracle.fwht(Z * d[:, None]) / np.sqrt(np.float64(p2))
