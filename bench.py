@@ -87,6 +87,19 @@ def main():
 
     ctx = torch_context(local_rank)
     L = _lib.lib()
+    # the per-iteration all-reduce: libspkm.so's own RCCL communicator on the context's stream (spkm_lloyd_iter: one
+    # library call per iteration); torch.distributed only carries the rendezvous token, the barriers and the timing max.
+    # If the communicator cannot be set up the exchange falls back to torch.distributed.all_reduce (also RCCL).
+    allreduce_via = "none (single GPU)"
+    if world > 1:
+        from sparsifiedkmeans_amd.engine import attach_rccl
+        try:
+            if os.environ.get("SPKM_BENCH_TORCH_ALLREDUCE") or os.environ.get("SPKM_BENCH_ONE_DEVICE"):
+                raise RuntimeError("switched off by environment")
+            attach_rccl(ctx)
+            allreduce_via = "libspkm.so RCCL communicator (ncclAllReduce f64 SUM inside spkm_lloyd_iter)"
+        except Exception as e:
+            allreduce_via = f"torch.distributed.all_reduce ({dist.get_backend()}); libspkm communicator unavailable: {e}"
     n_total = int(args.n_total)
     p, K = args.dim, args.clusters
     first = rank * n_total // world
@@ -260,6 +273,7 @@ def main():
                    "n_total": n_total, "n_per_gpu": n_local, "p2": p2, "K": K, "nnz_per_point": s, "start": args.start,
                    "order": args.order, "tol": TOL, "maxiter": MAXITER,
                    "gamma": gamma, "parallelism": f"dp{world} (1 RCCL all-reduce/iter)" if world > 1 else "single GPU",
+                   "allreduce": allreduce_via,
                    "datagen_s": round(t_gen, 1), "final_obj": float(np.sqrt(out[1])),
                    "runs_completed_in_timed_region": loop.runs_completed, "run_lengths": loop.run_lengths,
                    "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "

@@ -228,6 +228,44 @@ int spkm_dense_assign_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, const double *d
 int spkm_dense_accumulate_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, const double *d_X, uint64_t K,
                               const int32_t *d_assign, double *d_sums, double *d_counts);
 
+/* ------------------------------------------------------------------------------------------
+ * Part 3 -- one whole Lloyd iteration, and the data-parallel exchange
+ *
+ * The reference has no distributed code.  Points shard naturally over the GPUs of a node (one process per GPU);
+ * the only exchange of an iteration is ONE SUM all-reduce of the reduce buffer [sums | counts | nk | obj2]
+ * (kmeans_sparsified.m:447-448 needs sum X(:,ind) and sum spones(X)(:,ind) over ALL points of a cluster), after
+ * which every rank finalises identical centres.  The collective is RCCL (ncclAllReduce, ncclDouble, ncclSum) over
+ * xGMI, issued by the library on the context's stream -- no host round trip between the accumulation and the
+ * finalisation.  librccl is bound at run time (the copy already loaded in the process -- PyTorch's -- or
+ * $SPKM_RCCL_PATH, librccl.so, /opt/rocm/lib/librccl.so); a single-GPU user never loads it.
+ * ------------------------------------------------------------------------------------------ */
+#define SPKM_COMM_ID_BYTES 128
+#define SPKM_ERR_COMM (-10)          /* librccl not loadable, or an RCCL call failed (text via spkm_ctx_last_error) */
+
+/* Rendezvous token (ncclGetUniqueId): ONE rank creates it, the host ships the 128 bytes to the other ranks by
+ * whatever it has (torch.distributed broadcast, MPI, a file). */
+int spkm_comm_unique_id(uint8_t id[SPKM_COMM_ID_BYTES]);
+/* Attach this context (its device, its stream) to the communicator of `nranks` processes as rank `rank`
+ * (ncclCommInitRank; collective -- every rank must call it).  nranks == 1 is valid.  A context holds at most one
+ * communicator; SPKM_ERR_BAD_VALUE if one is attached already. */
+int spkm_comm_init(spkm_ctx *ctx, int nranks, int rank, const uint8_t id[SPKM_COMM_ID_BYTES]);
+int spkm_comm_destroy(spkm_ctx *ctx);                       /* no-op without a communicator */
+int spkm_comm_info(spkm_ctx *ctx, int *nranks, int *rank);  /* nranks = 0: none attached */
+/* In-place SUM all-reduce of `count` doubles over the attached communicator, on the context's stream.  What
+ * spkm_lloyd_iter issues; exported for the few other global sums of a run (SUMD, the two-pass means).  Without a
+ * communicator: returns SPKM_OK and leaves the buffer as it is (one rank). */
+int spkm_allreduce_f64_dev(spkm_ctx *ctx, double *d_buf, uint64_t count);
+/* One full Lloyd iteration with dense centres (kmeans_sparsified.m:417-471) in one call, nothing returned to the host:
+ *   spkm_assign_accumulate_dev  ->  all-reduce of d_reduce (if a communicator is attached)  ->  spkm_finalize_dev.
+ * gamma = SparsityLevel (the factor of :448); unbiased != 0: distances to centers/gamma (unbiasedDistance, the
+ * default, :369-370), else to the centres as they are.  d_centers is updated in place, d_out[2] =
+ * { ||old-new||_F^2, obj2 } (both global).  Same outputs, bit for bit, as the three calls.  Empty clusters keep their column (d_reduce's nk block tells; EmptyAction is the host's). */
+int spkm_lloyd_iter(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, double *d_centers, double gamma, int unbiased,
+                    int32_t *d_assign, double *d_mind, double *d_stats, uint64_t *d_nk_u64, double *d_reduce,
+                    double *d_out);
+/* Text of the last HIP / RCCL failure recorded on this context ("" if none). */
+const char *spkm_ctx_last_error(spkm_ctx *ctx);
+
 /* Timing hooks for bench.py: hipEvents recorded on the context's stream around the dominant
  * kernel of the last spkm_assign_dev call.  Returns its duration in milliseconds (blocks). */
 int spkm_last_assign_kernel_ms(spkm_ctx *ctx, double *ms);

@@ -17,7 +17,8 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "spkm.h")
 
 OK = 0
 ERR_NULL_ARG, ERR_CENTER_ROWS, ERR_BETA_K, ERR_LEN_LE_1, ERR_NOT_POW2 = -1, -2, -3, -4, -5
-ERR_BAD_CSC, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_BAD_VALUE = -6, -7, -8, -9
+ERR_BAD_CSC, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_BAD_VALUE, ERR_COMM = -6, -7, -8, -9, -10
+COMM_ID_BYTES = 128
 
 
 class SpkmError(RuntimeError):
@@ -46,6 +47,24 @@ def _preload_hip_runtime() -> str:
         except OSError as e:  # try the next candidate
             errs.append(f"{c}: {e}")
     raise ImportError("sparsifiedkmeans_amd: cannot load a HIP runtime (libamdhip64): " + "; ".join(errs))
+
+
+def preload_rccl() -> str | None:
+    """Make the RCCL that belongs to the process's HIP runtime visible to libspkm.so's run-time binding (PyTorch's
+    bundled librccl.so when torch is importable: its extension modules load it RTLD_LOCAL).  Returns the path used,
+    or None to let the library search by itself ($SPKM_RCCL_PATH, librccl.so, /opt/rocm/lib/librccl.so)."""
+    if os.environ.get("SPKM_RCCL_PATH"):
+        return None
+    try:
+        import torch
+
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return cand
+    except Exception:
+        pass
+    return None
 
 
 _lib = None
@@ -112,6 +131,14 @@ def lib():
     L.spkm_timing_log.argtypes = [_vp, C.c_int]
     L.spkm_timing_read.argtypes = [_vp, C.POINTER(_dbl), C.c_int, C.POINTER(C.c_int)]
     L.spkm_debug_block_times.argtypes = [_vp, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
+    L.spkm_comm_unique_id.argtypes = [_vp]
+    L.spkm_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
+    L.spkm_comm_destroy.argtypes = [_vp]
+    L.spkm_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.spkm_allreduce_f64_dev.argtypes = [_vp, _vp, _u64]
+    L.spkm_lloyd_iter.argtypes = [_vp, _vp, _u64, _vp, _dbl, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.spkm_ctx_last_error.argtypes = [_vp]
+    L.spkm_ctx_last_error.restype = C.c_char_p
     _lib = L
     return L
 

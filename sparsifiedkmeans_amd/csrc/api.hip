@@ -10,6 +10,8 @@
 
 #include "../../include/spkm.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -60,6 +62,9 @@ struct spkm_ctx {
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
     bool last_hinted = false;        // ... used the hinted two-phase form
     char errmsg[256] = {0};
+    // data-parallel exchange: an RCCL communicator bound to this context's device and stream (Part 3 of spkm.h)
+    void* comm = nullptr; // ncclComm_t
+    int comm_nranks = 0, comm_rank = 0;
 };
 
 struct spkm_shard {
@@ -78,6 +83,8 @@ struct spkm_shard {
     double* xn1 = nullptr; // per-point sum |x| and sum x^2 (screen error bound), built on first use
     double* xn2 = nullptr;
     float* xf = nullptr;   // f32 copy of x for the screen (with the same slack)
+    char* rec = nullptr;   // record layout of the exact entries (k_build_records): x | ir of a point side by side
+    int rec_R = 0;
     // screen bookkeeping of THIS data set (see spkm_assign_accumulate_dev)
     unsigned* h_nlist = nullptr; // pinned: uncertified count of the previous screen call, copied back asynchronously
     hipEvent_t ev_nlist = nullptr;
@@ -167,6 +174,7 @@ extern "C" const char* spkm_strerror(int status)
     case SPKM_ERR_UNSUPPORTED: return "shape not supported by this build";
     case SPKM_ERR_NO_DEVICE: return "no usable HIP device (gfx950) available";
     case SPKM_ERR_BAD_VALUE: return "scalar argument out of range";
+    case SPKM_ERR_COMM: return "RCCL is not available or an RCCL call failed (see spkm_ctx_last_error)";
     default: break;
     }
     if (status > 0) return hipGetErrorString((hipError_t)status);
@@ -207,6 +215,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)spkm_comm_destroy(ctx);
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
@@ -353,6 +362,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xn2) (void)hipFree(s->xn2);
     if (s->xf) (void)hipFree(s->xf);
     if (s->xfs) (void)hipFree(s->xfs);
+    if (s->rec) (void)hipFree(s->rec);
     if (s->irs) (void)hipFree(s->irs);
     if (s->hb) (void)hipFree(s->hb);
     if (s->hintu) (void)hipFree(s->hintu);
@@ -1177,18 +1187,46 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
     int per_cu = 1;
     if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
-    auto k2 = threads == 512 ? k_exact_accumulate<IR, 16, 2> : k_exact_accumulate<IR, 16, 4>; // 16 points' loads in flight per wave, 4 waves per SIMD
+    const bool nt = getenv("SPKM_ACC_NT") != nullptr;
+    if (getenv("SPKM_REC") && !sm->rec) {
+        const int R = (int)(((size_t)s->fixed_s * (8 + sizeof(IR)) + 15) / 16 * 16);
+        HIP_TRY(hipMalloc((void**)&sm->rec, (size_t)n * R + 256));
+        hipLaunchKernelGGL((k_build_records<IR>), dim3((unsigned)std::min<long long>((n + 3) / 4, 65536)), dim3(256), 0,
+                           ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, R, sm->rec);
+        sm->rec_R = R;
+    }
+    const bool use_rec = sm->rec != nullptr;
+    // 16 points' loads in flight per wave; 4 waves per SIMD (2 with 512-thread workgroups)
+    const void* k2 = threads == 512
+        ? (use_rec ? (nt ? (const void*)k_exact_accumulate<IR, 16, 2, true, true> : (const void*)k_exact_accumulate<IR, 16, 2, false, true>)
+                   : (nt ? (const void*)k_exact_accumulate<IR, 16, 2, true, false> : (const void*)k_exact_accumulate<IR, 16, 2, false, false>))
+        : (use_rec ? (nt ? (const void*)k_exact_accumulate<IR, 16, 4, true, true> : (const void*)k_exact_accumulate<IR, 16, 4, false, true>)
+                   : (nt ? (const void*)k_exact_accumulate<IR, 16, 4, true, false> : (const void*)k_exact_accumulate<IR, 16, 4, false, false>));
     HIP_TRY(allow_lds(ctx, (const void*)k2, lds2));
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * per_cu);
     if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;
     if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
-    hipLaunchKernelGGL(k2, dim3(ab), dim3(threads), lds2, ctx->stream, (const IR*)s->ir, (const double*)s->x,
-                       (const int*)ctx->perm.p, (const long long*)ctx->offs.p, (const int4*)ctx->items.p,
-                       (const int*)ctx->nitems.p, d_centers, gamma, p, s->fixed_s, pts, d_mind,
-                       quad ? sm->hb : (float*)nullptr, sums, counts,
-                       (double*)ctx->blk_obj.p, (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p);
+    {
+        const char* a_rec = sm->rec;
+        int a_R = sm->rec_R, a_p = p, a_s = s->fixed_s, a_pts = pts;
+        const IR* a_ir = (const IR*)s->ir;
+        const double* a_x = (const double*)s->x;
+        const int* a_perm = (const int*)ctx->perm.p;
+        const long long* a_offs = (const long long*)ctx->offs.p;
+        const int4* a_items = (const int4*)ctx->items.p;
+        const int* a_nitems = (const int*)ctx->nitems.p;
+        const double* a_C = d_centers;
+        double a_gamma = gamma;
+        double* a_mind = d_mind;
+        float* a_ub = quad ? sm->hb : (float*)nullptr;
+        double *a_sums = sums, *a_counts = counts, *a_bo = (double*)ctx->blk_obj.p, *a_bm = (double*)ctx->blk_max.p;
+        long long* a_bi = (long long*)ctx->blk_imax.p;
+        void* args[] = {&a_rec, &a_R, &a_ir, &a_x, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s, &a_pts,
+                        &a_mind, &a_ub, &a_sums, &a_counts, &a_bo, &a_bm, &a_bi};
+        HIP_TRY(hipLaunchKernel(k2, dim3(ab), dim3(threads), args, lds2, ctx->stream));
+    }
     if (ctx->tlog_both) HIP_TRY(timing_end(ctx));
     hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
                        (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, ab, (double*)ctx->stats.p);
@@ -1349,6 +1387,138 @@ extern "C" int spkm_finalize_dev(spkm_ctx* ctx, uint64_t p, uint64_t K, const do
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(d_out + 1, d_reduce + 2 * pk + K, 8, hipMemcpyDeviceToDevice, ctx->stream));
     return SPKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Part 3: RCCL inside the library, and the whole iteration in one call
+// ------------------------------------------------------------------------------------------
+// librccl is bound at run time: a single-GPU process never loads it, and a PyTorch process must use the copy PyTorch
+// already loaded (one RCCL, one HIP runtime per process).  Only the five entry points used are resolved; their
+// signatures are RCCL's public C API (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllReduce,
+// ncclGetErrorString; ncclDouble = 8, ncclSum = 0, NCCL_UNIQUE_ID_BYTES = 128).
+namespace {
+struct rccl_id { char internal[SPKM_COMM_ID_BYTES]; };
+struct rccl_api {
+    int (*GetUniqueId)(rccl_id*) = nullptr;
+    int (*CommInitRank)(void**, int, rccl_id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    char why[200] = {0};
+};
+rccl_api& rccl()
+{
+    static rccl_api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        // 1. already in the process (PyTorch's bundled librccl.so, or whatever the host linked)
+        if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = RTLD_DEFAULT;
+        const char* cands[] = {getenv("SPKM_RCCL_PATH"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* c : cands) {
+            if (h) break;
+            if (!c || !*c) continue;
+            h = dlopen(c, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); // loaded under this name but not exported globally
+            if (!h) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!h) { snprintf(api.why, sizeof(api.why), "librccl not found (set SPKM_RCCL_PATH): %s", dlerror()); return; }
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
+        if (!api.ok) snprintf(api.why, sizeof(api.why), "librccl lacks an expected entry point");
+    });
+    return api;
+}
+int rccl_fail(spkm_ctx* ctx, const char* what, int r)
+{
+    if (ctx) {
+        rccl_api& a = rccl();
+        snprintf(ctx->errmsg, sizeof(ctx->errmsg), "%s: %s", what,
+                 r < 0 ? a.why : (a.GetErrorString ? a.GetErrorString(r) : "RCCL error"));
+    }
+    return SPKM_ERR_COMM;
+}
+} // namespace
+
+extern "C" const char* spkm_ctx_last_error(spkm_ctx* ctx) { return ctx ? ctx->errmsg : ""; }
+
+extern "C" int spkm_comm_unique_id(uint8_t id[SPKM_COMM_ID_BYTES])
+{
+    if (!id) return SPKM_ERR_NULL_ARG;
+    rccl_api& a = rccl();
+    if (!a.ok) return SPKM_ERR_COMM;
+    rccl_id u;
+    memset(&u, 0, sizeof(u));
+    const int r = a.GetUniqueId(&u);
+    if (r != 0) return SPKM_ERR_COMM;
+    memcpy(id, u.internal, SPKM_COMM_ID_BYTES);
+    return SPKM_OK;
+}
+
+extern "C" int spkm_comm_init(spkm_ctx* ctx, int nranks, int rank, const uint8_t id[SPKM_COMM_ID_BYTES])
+{
+    if (!ctx || !id) return SPKM_ERR_NULL_ARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks || ctx->comm) return SPKM_ERR_BAD_VALUE;
+    rccl_api& a = rccl();
+    if (!a.ok) return rccl_fail(ctx, "spkm_comm_init", -1);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rccl_id u;
+    memcpy(u.internal, id, SPKM_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int r = a.CommInitRank(&comm, nranks, u, rank);
+    if (r != 0 || !comm) return rccl_fail(ctx, "ncclCommInitRank", r ? r : 1);
+    ctx->comm = comm;
+    ctx->comm_nranks = nranks;
+    ctx->comm_rank = rank;
+    return SPKM_OK;
+}
+
+extern "C" int spkm_comm_destroy(spkm_ctx* ctx)
+{
+    if (!ctx) return SPKM_ERR_NULL_ARG;
+    if (!ctx->comm) return SPKM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    const int r = rccl().CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_nranks = 0;
+    ctx->comm_rank = 0;
+    return r == 0 ? SPKM_OK : rccl_fail(ctx, "ncclCommDestroy", r);
+}
+
+extern "C" int spkm_comm_info(spkm_ctx* ctx, int* nranks, int* rank)
+{
+    if (!ctx) return SPKM_ERR_NULL_ARG;
+    if (nranks) *nranks = ctx->comm ? ctx->comm_nranks : 0;
+    if (rank) *rank = ctx->comm ? ctx->comm_rank : 0;
+    return SPKM_OK;
+}
+
+extern "C" int spkm_allreduce_f64_dev(spkm_ctx* ctx, double* d_buf, uint64_t count)
+{
+    if (!ctx || (count && !d_buf)) return SPKM_ERR_NULL_ARG;
+    if (!ctx->comm || count == 0) return SPKM_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int r = rccl().AllReduce(d_buf, d_buf, (size_t)count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    return r == 0 ? SPKM_OK : rccl_fail(ctx, "ncclAllReduce", r);
+}
+
+extern "C" int spkm_lloyd_iter(spkm_ctx* ctx, const spkm_shard* s, uint64_t K, double* d_centers, double gamma,
+                               int unbiased, int32_t* d_assign, double* d_mind, double* d_stats, uint64_t* d_nk_u64,
+                               double* d_reduce, double* d_out)
+{
+    if (!ctx || !s || !d_centers || !d_assign || !d_mind || !d_reduce || !d_out) return SPKM_ERR_NULL_ARG;
+    // findClusters = findClusterAssignments(X, centers, [], SparsityLevel) or (X, centers) (kmeans_sparsified.m:369-373)
+    int rc = spkm_assign_accumulate_dev(ctx, s, K, d_centers, unbiased ? gamma : 0.0, d_assign, d_mind, d_stats,
+                                        d_nk_u64, d_reduce);
+    if (rc) return rc;
+    // the ONE exchange of an iteration: 2 p K + K + 1 doubles (1.64 MB at p = 1024, K = 100), latency bound on xGMI
+    if ((rc = spkm_allreduce_f64_dev(ctx, d_reduce, spkm_reduce_len(s->p, K)))) return rc;
+    return spkm_finalize_dev(ctx, s->p, K, d_reduce, gamma, d_centers, d_out); // :448 scales by SparsityLevel either way
 }
 
 // ------------------------------------------------------------------------------------------

@@ -839,8 +839,34 @@ __global__ __launch_bounds__(256) void k_hist(const int* __restrict__ assign, lo
 //      mind[i] = sqrt(acc) is exactly the value the reference's min() returns for this point.
 // LDS: negc f64[p] | ssum f64[p] | scnt u32[p] | per wave: ms f64[PTS*S1]   (S1 = s|1: odd stride, conflict-free)
 // Also per-block partial statistics: sum mind^2, max mind and its first index.
-template <typename IR, int U, int WPE>
+// Record layout (optional, `rec` != nullptr): the library's private copy of a fixed-stride shard with each point's
+// values and row ids side by side in ONE record of R = align16(s * (8 + sizeof(IR))) bytes -- x[0..s) then ir[0..s) --
+// so that a point is a whole number of aligned 16-B pieces in one place (s = 51, 16-bit ids: exactly 512 B = four
+// 128-B lines; in the two separate arrays the same point straddles 5 + 2 lines of two DRAM pages).  In cluster order
+// the points of a segment are gathered through `perm`: with data in arbitrary order every point is a random access,
+// and the record halves the pages and removes the partially used lines.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_build_records(const IR* __restrict__ ir, const double* __restrict__ x,
+                                                       long long n, int s, int R, char* __restrict__ rec)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long i = wave; i < n; i += nwaves) {
+        char* dst = rec + (size_t)i * R;
+        double* dx = reinterpret_cast<double*>(dst);
+        IR* dr = reinterpret_cast<IR*>(dst + (size_t)s * 8);
+        for (int j = lane; j < s; j += 64) {
+            dx[j] = x[(size_t)i * s + j];
+            dr[j] = ir[(size_t)i * s + j];
+        }
+        // (the few pad bytes behind the row ids are never read)
+    }
+}
+
+template <typename IR, int U, int WPE, bool NT, bool REC>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_exact_accumulate(
+                                                          const char* __restrict__ rec, int R,
                                                           const IR* __restrict__ ir, const double* __restrict__ x,
                                                           const int* __restrict__ perm,
                                                           const long long* __restrict__ offs,
@@ -893,21 +919,49 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             }
             // (a) U points' loads in flight per lane
             const int lanec = lane < fixed_s ? lane : fixed_s - 1;
+            const unsigned offx = (unsigned)lanec * 8u;                                              // record path: byte offsets
+            const unsigned offr = (unsigned)fixed_s * 8u + (unsigned)lanec * (unsigned)sizeof(IR);   // inside a point's record
             for (int u = 0; u < have; u += U) {
                 double xv[U];
                 int rv[U];
+                if constexpr (REC) {
+                    // one uniform base per point (an SGPR pair), two loop-invariant lane offsets
 #pragma unroll
-                for (int v = 0; v < U; v++) {
-                    // unconditional loads through a uniform per-point base + a clamped 32-bit lane offset (no
-                    // divergent control flow around the loads); validity is applied to the row id afterwards
-                    const int src = (u + v < have) ? u + v : u;
-                    const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, src);
-                    const bool ok = (u + v < have) && lane < fixed_s;
-                    const double* xb = x + i * fixed_s;
-                    const IR* rb = ir + i * fixed_s;
-                    xv[v] = xb[lanec];
-                    const int r = (int)rb[lanec];
-                    rv[v] = ok ? r : -1;
+                    for (int v = 0; v < U; v++) {
+                        const int src = (u + v < have) ? u + v : u;
+                        const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, src);
+                        const bool ok = (u + v < have) && lane < fixed_s;
+                        const char* b = rec + (size_t)i * (size_t)R;
+                        int r;
+                        if constexpr (NT) { // streamed once per launch
+                            xv[v] = __builtin_nontemporal_load(reinterpret_cast<const double*>(b + offx));
+                            r = (int)__builtin_nontemporal_load(reinterpret_cast<const IR*>(b + offr));
+                        } else {
+                            xv[v] = *reinterpret_cast<const double*>(b + offx);
+                            r = (int)*reinterpret_cast<const IR*>(b + offr);
+                        }
+                        rv[v] = ok ? r : -1;
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < U; v++) {
+                        // unconditional loads through a uniform per-point base + a clamped 32-bit lane offset (no
+                        // divergent control flow around the loads); validity is applied to the row id afterwards
+                        const int src = (u + v < have) ? u + v : u;
+                        const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, src);
+                        const bool ok = (u + v < have) && lane < fixed_s;
+                        const double* xb = x + i * fixed_s;
+                        const IR* rb = ir + i * fixed_s;
+                        int r;
+                        if constexpr (NT) {
+                            xv[v] = __builtin_nontemporal_load(xb + lanec);
+                            r = (int)__builtin_nontemporal_load(rb + lanec);
+                        } else {
+                            xv[v] = xb[lanec];
+                            r = (int)rb[lanec];
+                        }
+                        rv[v] = ok ? r : -1;
+                    }
                 }
 #pragma unroll
                 for (int v = 0; v < U; v++) {
@@ -922,8 +976,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                     if (fixed_s > 64 && u + v < have) { // columns longer than one wave
                         const long long i = (long long)(unsigned)__builtin_amdgcn_readlane((int)my_i, u + v);
                         for (int e = 64 + lane; e < fixed_s; e += 64) {
-                            const double xe = x[i * fixed_s + e];
-                            const int re = (int)ir[i * fixed_s + e];
+                            const double xe = REC ? reinterpret_cast<const double*>(rec + (size_t)i * R)[e] : x[i * fixed_s + e];
+                            const int re = REC ? (int)reinterpret_cast<const IR*>(rec + (size_t)i * R + (size_t)fixed_s * 8)[e]
+                                               : (int)ir[i * fixed_s + e];
                             const double d = xe + negc[re];
                             ms[(size_t)(u + v) * S1 + e] = d * d;
                             unsafeAtomicAdd(&ssum[re], xe);

@@ -85,6 +85,44 @@ def torch_context(device: int | None = None) -> Context:
     return Context(device, torch.cuda.current_stream(device).cuda_stream)
 
 
+def comm_size(ctx: Context) -> int:
+    """ranks of the RCCL communicator attached to ``ctx`` inside libspkm.so (0 = none)."""
+    n, r = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().spkm_comm_info(ctx.handle, C.byref(n), C.byref(r)))
+    return n.value
+
+
+def attach_rccl(ctx: Context, group=None) -> int:
+    """Attach ``ctx`` to an RCCL communicator owned by libspkm.so, spanning the ranks of ``group`` (default: the
+    world of torch.distributed, which only carries the 128-byte rendezvous token here -- any backend).  From then on
+    LloydEngine.iterate() is ONE library call per iteration, the all-reduce issued by the library on the context's
+    stream (spkm_lloyd_iter).  Collective: every rank calls it.  Returns the communicator size."""
+    import torch.distributed as dist
+
+    if comm_size(ctx):
+        return comm_size(ctx)
+    _lib.preload_rccl()
+    if not (dist.is_available() and dist.is_initialized()):
+        world, rank = 1, 0
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    if rank == 0:
+        _lib.check(_lib.lib().spkm_comm_unique_id(ident), "spkm_comm_unique_id")
+    if world > 1:
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
+    st = _lib.lib().spkm_comm_init(ctx.handle, world, rank, ident)
+    if st != 0:
+        raise _lib.SpkmError(st, "spkm_comm_init: " + _lib.lib().spkm_ctx_last_error(ctx.handle).decode())
+    return world
+
+
+def detach_rccl(ctx: Context) -> None:
+    _lib.check(_lib.lib().spkm_comm_destroy(ctx.handle), "spkm_comm_destroy")
+
+
 class LloydEngine:
     """State of one Lloyd run over one local shard (one process per GPU).
 
@@ -132,6 +170,12 @@ class LloydEngine:
                                                   _p(self.reduce)), "spkm_accumulate_dev")
 
     def allreduce_step(self):
+        """the one exchange of an iteration: through the library's own RCCL communicator when one is attached to the
+        context (attach_rccl), else torch.distributed (RCCL under backend "nccl", gloo in the CPU tests)"""
+        if comm_size(self.ctx) > 0:
+            _lib.check(_lib.lib().spkm_allreduce_f64_dev(self.ctx.handle, _p(self.reduce), self.reduce.numel()),
+                       "spkm_allreduce_f64_dev")
+            return
         from .distributed import allreduce_
 
         allreduce_(self.reduce, self.group)
@@ -172,10 +216,20 @@ class LloydEngine:
 
     def iterate(self, centers: torch.Tensor):
         """One full Lloyd iteration in place on ``centers``; returns the device tensor
-        [dff^2, obj^2] (no host sync)."""
-        self.assign_accumulate_step(centers)
-        self.allreduce_step()
-        self.finalize_step(centers)
+        [dff^2, obj^2] (no host sync).  One library call (spkm_lloyd_iter: fused assignment + accumulation, the
+        all-reduce over the library's RCCL communicator if one is attached, finalisation) unless the exchange has to
+        go through torch.distributed (a process group without attach_rccl)."""
+        from .distributed import is_distributed
+
+        if is_distributed() and comm_size(self.ctx) == 0:
+            self.assign_accumulate_step(centers)
+            self.allreduce_step()
+            self.finalize_step(centers)
+            return self.out
+        assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)
+        _lib.check(_lib.lib().spkm_lloyd_iter(self.ctx.handle, self.shard.handle, self.K, _p(centers), self.gamma,
+                                              1 if self.unbiased else 0, _p(self.assign), _p(self.mind), _p(self.stats),
+                                              _p(self.nk), _p(self.reduce), _p(self.out)), "spkm_lloyd_iter")
         return self.out
 
     # -- helpers -------------------------------------------------------------------------

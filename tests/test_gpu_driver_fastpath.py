@@ -48,7 +48,9 @@ def test_driver_takes_the_fused_path_and_matches_exact_driver_and_oracle(gpu_ctx
     assert np.array_equal(IDX - 1, ref["assign"])
     assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
     assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1]
-    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-6 * max(ref["dff"][-1], 1e-9)
+    # (a converged loop: the oracle's sequential sums repeat bit for bit and give dff = 0; the device sums are
+    #  atomics in no fixed order and move the centres by an ulp or two)
+    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-9 * max(ref["dff"][-1], np.linalg.norm(ref["centers"]))
 
 
 def _with_far_centre(X, K, seed):
@@ -78,7 +80,7 @@ def test_singleton_on_the_gpu_matches_the_oracle_loop(gpu_ctx, oracle, maxiter):
     assert np.array_equal(IDX - 1, ref["assign"])
     assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
     assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1]
-    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-9 * max(ref["dff"][-1], 1e-12)
+    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-9 * max(ref["dff"][-1], np.linalg.norm(ref["centers"]))
     Cref = (oracle.fwht(ref["centers"]) / np.sqrt(np.float64(p2)) * d[:, None])[:p]   # unmix (:523)
     assert np.abs(C.T - Cref).max() <= 1e-6 * np.abs(Cref).max()
 
@@ -102,7 +104,7 @@ def test_drop_on_the_gpu_matches_the_oracle_loop(gpu_ctx, oracle, maxiter):
     assert ref["K"] == K - 1 and C.shape == (K - 1, p)
     assert OUT["iterations"][0] == ref["iterations"]
     assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1] and OUT["objectives"][0] > 0
-    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-9 * max(ref["dff"][-1], 1e-12)
+    assert abs(OUT["stoppingDiff"][0] - ref["dff"][-1]) <= 1e-9 * max(ref["dff"][-1], np.linalg.norm(ref["centers"]))
     assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
     if ref["assign"] is None:
         assert IDX.size == 0                                 # assignments = [] (:457)
