@@ -60,7 +60,16 @@ def main():
                     help="initial centres: K mixture points drawn with replacement (default: duplicate and uncovered "
                          "clusters, a run needs many iterations) or the K planted means + noise (converges at once)")
     ap.add_argument("--no-regimes", action="store_true", help="skip the traced runs to convergence (quick experiments)")
+    ap.add_argument("--workload", choices=["headline", "config3", "config5"], default="headline",
+                    help="headline: BASELINE.json's metric config (N=1e8, d=1024, K=100).  config3: MNIST-shaped "
+                         "60000 x 784 -> 1024, K=10.  config5: one GPU's shard of the 1e9 x 784 one-pass config "
+                         "(1.25e8 points per GPU, K=10), 8-bit points streamed from pinned host memory through the "
+                         "sparsifier; reports the ingest rate beside the Lloyd rate")
     args = ap.parse_args()
+    if args.workload == "config3":
+        args.n_total, args.dim, args.clusters = 6e4, 784, 10
+    elif args.workload == "config5":
+        args.n_total, args.dim, args.clusters, args.order = 1.25e8 * args.gpus, 784, 10, "shuffled"
 
     import torch
     import torch.distributed as dist
@@ -113,8 +122,11 @@ def main():
 
     def make_dataset(order):
         t = time.time()
-        data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
-                                           chunk=args.gen_chunk, order=order)
+        if args.workload == "config5":
+            data = synth.streamed_pixel_dataset(ctx, p, n_local, first, K, args.sparsity, seed=args.seed, chunk=args.gen_chunk)
+        else:
+            data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
+                                               chunk=args.gen_chunk, order=order)
         shard = Shard.from_device(ctx, data["p2"], data["jc"], data["ir"], data["x"], nnz=data["nnz"])
         # initial centres: K mixture points in the ORIGINAL space passed through mix(), as the
         # 'Start'-matrix path does (kmeans_sparsified.m:401-406); identical on every rank
@@ -123,7 +135,8 @@ def main():
         lab = torch.randint(0, K, (K,), generator=g, device="cuda")
         if args.start == "planted":
             lab = torch.arange(K, device="cuda")
-        start = data["means"][lab] + 0.1 * torch.randn((K, p), generator=g, device="cuda", dtype=torch.float64)
+        noise = 10.0 if args.workload == "config5" else 0.1
+        start = data["means"][lab] + noise * torch.randn((K, p), generator=g, device="cuda", dtype=torch.float64)
         centers0 = mix_device(ctx, start.contiguous(), data["p2"], data["sign"], 1.0, float(np.sqrt(np.float64(data["p2"]))))
         torch.cuda.synchronize()
         return data, shard, centers0, time.time() - t
@@ -251,7 +264,8 @@ def main():
     out = eng.out.cpu().numpy()
 
     result = {
-        "metric": "Lloyd iters/sec + achieved HBM GB/s, N=1e8 d=1024 K=100",
+        "metric": "Lloyd iters/sec + achieved HBM GB/s, N=1e8 d=1024 K=100" if args.workload == "headline"
+                  else f"Lloyd iters/sec + achieved HBM GB/s, {args.workload}: N={n_total} d={p} K={K}",
         "value": args.steps / elapsed,
         "unit": "Lloyd iters/sec",
         "n_gpus": world,
@@ -293,7 +307,18 @@ def main():
     }
 
     # ---- regimes: one complete run to convergence, iteration by iteration, on this dataset and on the other order ----
-    if not args.no_regimes:
+    if args.workload == "config5":
+        ing = data["ingest"]
+        result["config"]["ingest"] = {"points": ing["points"], "bytes_over_pcie": ing["bytes"], "seconds": ing["seconds"],
+                                      "GBs": ing["GBs"], "pcie_gen5_x16_spec_GBs": 63.0,
+                                      "source": f"uint8 points in pinned host memory ({data['pool_points']} distinct, cycled), "
+                                                f"{args.gen_chunk}-point chunks, copy stream + two staging buffers -> "
+                                                "spkm_widen_f64_dev -> spkm_mix_sample_dev -> resident sparse shard"}
+    if not args.no_regimes and args.workload == "config5":
+        regimes = {args.order: traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)}
+        result["regimes"] = regimes
+        cpu_data = None
+    elif not args.no_regimes:
         regimes = {args.order: traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)}
         other = "shuffled" if args.order == "block" else "block"
         cpu_data = None

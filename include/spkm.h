@@ -211,6 +211,11 @@ int spkm_mix_sample_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, cons
                         const double *d_sign, double premul, double postdiv, uint64_t s, uint64_t seed,
                         uint64_t col0, void *d_ir_out, int ir_bits, double *d_x_out);
 
+/* Widening copy in front of the sparsifier for streamed ingest (private/sampleAndMixFromLargeFile.m:100-113 reads a
+ * chunk as doubles; a dataset of 1e9 points is stored narrower): d_dst[i] = (double) d_src[i], exact for every kind.
+ * kind: 1 float32, 2 uint8, 3 int16, 4 int32.  Both buffers on the device, `count` elements. */
+int spkm_widen_f64_dev(spkm_ctx *ctx, int kind, uint64_t count, const void *d_src, double *d_dst);
+
 /* Dense (unsampled) data behind the reference's two-pass outputs.
  * d_X: n x p, point i at d_X + i*p (= column-major p x n); d_centers: K x p, centre k at d_centers + k*p.
  *

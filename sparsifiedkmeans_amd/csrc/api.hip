@@ -85,6 +85,7 @@ struct spkm_shard {
     float* xf = nullptr;   // f32 copy of x for the screen (with the same slack)
     char* rec = nullptr;   // record layout of the exact entries (k_build_records): x | ir of a point side by side
     int rec_R = 0;
+    bool rec_tried = false; // one attempt per shard (no retry every call when memory is short)
     // screen bookkeeping of THIS data set (see spkm_assign_accumulate_dev)
     unsigned* h_nlist = nullptr; // pinned: uncertified count of the previous screen call, copied back asynchronously
     hipEvent_t ev_nlist = nullptr;
@@ -1188,12 +1189,23 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     int per_cu = 1;
     if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
     const bool nt = getenv("SPKM_ACC_NT") != nullptr;
-    if (getenv("SPKM_REC") && !sm->rec) {
+    // Record layout of the exact entries (screen.hip, k_build_records): built once per shard on the first screen call,
+    // when the device has room for it (n * R bytes: 51 GB at N = 1e8, s = 51).  With the points of a cluster scattered
+    // over the shard (data in arbitrary order) it takes a third off this pass; in cluster-contiguous order it is
+    // neutral.  SPKM_NO_REC=1: the two separate arrays (A/B switch, and what runs when memory is short).
+    if (!sm->rec && !sm->rec_tried && !getenv("SPKM_NO_REC")) {
+        sm->rec_tried = true;
         const int R = (int)(((size_t)s->fixed_s * (8 + sizeof(IR)) + 15) / 16 * 16);
-        HIP_TRY(hipMalloc((void**)&sm->rec, (size_t)n * R + 256));
-        hipLaunchKernelGGL((k_build_records<IR>), dim3((unsigned)std::min<long long>((n + 3) / 4, 65536)), dim3(256), 0,
-                           ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, R, sm->rec);
-        sm->rec_R = R;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (size_t)n * R + ((size_t)4 << 30) &&
+            hipMalloc((void**)&sm->rec, (size_t)n * R + 256) == hipSuccess) {
+            hipLaunchKernelGGL((k_build_records<IR>), dim3((unsigned)std::min<long long>((n + 3) / 4, 65536)), dim3(256), 0,
+                               ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, R, sm->rec);
+            sm->rec_R = R;
+        } else {
+            (void)hipGetLastError();
+            sm->rec = nullptr;
+        }
     }
     const bool use_rec = sm->rec != nullptr;
     // 16 points' loads in flight per wave; 4 waves per SIMD (2 with 512-thread workgroups)
@@ -1208,7 +1220,30 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
     if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;
     if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
-    {
+    // software-pipelined record kernel (k_exact_accumulate_rec): batches of exactly 16 points per wave, columns of up
+    // to 64 entries; SPKM_NO_REC_PIPE=1 keeps k_exact_accumulate on the records (A/B switch)
+    const bool pipe = use_rec && !getenv("SPKM_NO_REC_PIPE") && threads == 1024 && s->fixed_s <= 64 &&
+                      fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
+    if (pipe) {
+        const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4>;
+        const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
+        HIP_TRY(allow_lds(ctx, k3, lds3));
+        const char* a_rec = sm->rec;
+        int a_R = sm->rec_R, a_p = p, a_s = s->fixed_s;
+        const int* a_perm = (const int*)ctx->perm.p;
+        const long long* a_offs = (const long long*)ctx->offs.p;
+        const int4* a_items = (const int4*)ctx->items.p;
+        const int* a_nitems = (const int*)ctx->nitems.p;
+        const double* a_C = d_centers;
+        double a_gamma = gamma;
+        double* a_mind = d_mind;
+        float* a_ub = quad ? sm->hb : (float*)nullptr;
+        double *a_sums = sums, *a_counts = counts, *a_bo = (double*)ctx->blk_obj.p, *a_bm = (double*)ctx->blk_max.p;
+        long long* a_bi = (long long*)ctx->blk_imax.p;
+        void* args[] = {&a_rec, &a_R, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s,
+                        &a_mind, &a_ub, &a_sums, &a_counts, &a_bo, &a_bm, &a_bi};
+        HIP_TRY(hipLaunchKernel(k3, dim3(ab), dim3(threads), args, lds3, ctx->stream));
+    } else {
         const char* a_rec = sm->rec;
         int a_R = sm->rec_R, a_p = p, a_s = s->fixed_s, a_pts = pts;
         const IR* a_ir = (const IR*)s->ir;
@@ -1604,6 +1639,18 @@ extern "C" int spkm_mix_sample_dev(spkm_ctx* ctx, uint64_t p, uint64_t p2, uint6
     // SparsityLevel = small_p / p with p the row count of the mixed matrix (randsample_fixedNumberEntries.m:30-31)
     const double level = (double)s / (double)p2;
     return fwht_launch(ctx, p, p2, n, d_x, d_sign, premul, postdiv, d_x_out, d_ir_out, ir_bits, (int)s, level);
+}
+
+extern "C" int spkm_widen_f64_dev(spkm_ctx* ctx, int kind, uint64_t count, const void* d_src, double* d_dst)
+{
+    if (!ctx || (count && (!d_src || !d_dst))) return SPKM_ERR_NULL_ARG;
+    if (kind < 1 || kind > 4) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (count == 0) return SPKM_OK;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((count / 2 + 255) / 256 + 1, (uint64_t)std::max(1, ctx->num_cus) * 32);
+    hipLaunchKernelGGL(k_widen_f64, dim3(blocks), dim3(256), 0, ctx->stream, d_src, kind, (long long)count, d_dst);
+    HIP_TRY(hipGetLastError());
+    return SPKM_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -60,3 +60,26 @@ __global__ __launch_bounds__(256) void k_sample_rows(unsigned long long seed, lo
         }
     }
 }
+
+// Widening copy in front of the sparsifier: a streamed chunk arrives in the source's own element type (8-bit pixels,
+// float32 features -- what a 1e9-point dataset is stored as) and is widened to the double
+// the reference's pipeline works in (sampleAndMixFromLargeFile.m:104-113 reads doubles).  Every uint8 / int16 /
+// float32 value is exactly representable: the copy is exact.  16 B stored per lane and iteration.
+//   kind: 1 float32, 2 uint8, 3 int16, 4 int32
+__global__ __launch_bounds__(256) void k_widen_f64(const void* __restrict__ src, int kind, long long count,
+                                                   double* __restrict__ dst)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x * 2;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < count; i += stride) {
+        double a, b = 0.0;
+        const bool two = i + 1 < count;
+        switch (kind) {
+        case 1: a = (double)static_cast<const float*>(src)[i]; if (two) b = (double)static_cast<const float*>(src)[i + 1]; break;
+        case 2: a = (double)static_cast<const unsigned char*>(src)[i]; if (two) b = (double)static_cast<const unsigned char*>(src)[i + 1]; break;
+        case 3: a = (double)static_cast<const short*>(src)[i]; if (two) b = (double)static_cast<const short*>(src)[i + 1]; break;
+        default: a = (double)static_cast<const int*>(src)[i]; if (two) b = (double)static_cast<const int*>(src)[i + 1]; break;
+        }
+        dst[i] = a;
+        if (two) dst[i + 1] = b;
+    }
+}

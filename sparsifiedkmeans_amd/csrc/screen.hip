@@ -1042,6 +1042,174 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     }
 }
 
+// The same pass over the record layout, software-pipelined: a wave's batch is P = 16 points whose loads (one 8-B and
+// one id load per lane and point, 48 VGPRs) are issued BEFORE the storage-order sums of the previous batch, so that a
+// wave has its next 8 KB in flight while it works through phase (b) -- in k_exact_accumulate a wave's loads are only
+// in flight while it waits for them.  (a2) consumes the registers, then the next batch is issued into the same
+// registers, then (b) runs on what (a2) staged in LDS.  Columns of up to 64 entries; outputs bit-identical to
+// k_exact_accumulate (same arithmetic, same order).
+template <typename IR, int WPE, int EXP = 0> // EXP != 0: timing experiments only, never instantiated in the library (bit 0 no count atomics, 1 no sum
+                                             // atomics, 2 no phase (b), 3 no staging writes; results in DESIGN.md section 4.2)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_exact_accumulate_rec(
+    const char* __restrict__ rec, int R, const int* __restrict__ perm, const long long* __restrict__ offs,
+    const int4* __restrict__ items, const int* __restrict__ nitems, const double* __restrict__ C, double gamma, int p,
+    int fixed_s, double* __restrict__ mind, float* __restrict__ ubv, double* __restrict__ sums,
+    double* __restrict__ counts, double* __restrict__ blk_obj2, double* __restrict__ blk_max,
+    long long* __restrict__ blk_imax)
+{
+    constexpr int P = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* negc = reinterpret_cast<double*>(smem);
+    double* ssum = negc + p;
+    unsigned int* scnt = reinterpret_cast<unsigned int*>(ssum + p);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int S1 = fixed_s | 1;
+    char* wbase = smem + (size_t)p * 20 + (size_t)((p & 1) ? 4 : 0);
+    double* ms = reinterpret_cast<double*>(wbase) + (size_t)wave * P * S1;
+    __shared__ double s_obj[16], s_max[16];
+    __shared__ long long s_imax[16];
+    const int lanec = lane < fixed_s ? lane : fixed_s - 1;
+    const unsigned offx = (unsigned)lanec * 8u;
+    const unsigned offr = (unsigned)fixed_s * 8u + (unsigned)lanec * (unsigned)sizeof(IR);
+    const bool lane_ok = lane < fixed_s;
+
+    double obj2 = 0.0, dmax = -1.0;
+    long long imax = 0x7fffffffffffffffLL;
+    double xv[P];
+    int rv[P];
+    for (int item = blockIdx.x; item < *nitems; item += gridDim.x) {
+        const int4 it = items[item];
+        const int k = it.x;
+        const long long start = offs[k] + it.y;
+        const int len = it.z;
+        for (int r = tid; r < p; r += blockDim.x) {
+            double c = C[(size_t)k * p + r];
+            if (gamma > 0.0) c = c / gamma;
+            negc[r] = -c;
+            ssum[r] = 0.0;
+            scnt[r] = 0u;
+        }
+        const int stride = nwaves * P;
+        int qb = wave * P;
+        // point ids of a wave's batches are fetched two batches ahead, UNCONDITIONALLY from a clamped position (a load
+        // inside a divergent branch is waited for at the end of the branch -- together with every load issued before it)
+        const int lane_p = lane < P ? lane : P - 1;
+        int my_i = perm[start + min(qb + lane_p, len - 1)];
+        int my_next = perm[start + min(qb + stride + lane_p, len - 1)];
+        // prologue: the first batch's loads
+        if (qb < len) {
+            const int have = (len - qb < P) ? len - qb : P;
+#pragma unroll
+            for (int v = 0; v < P; v++) {
+                const int src = (v < have) ? v : 0;
+                const long long i = (long long)(unsigned)__builtin_amdgcn_readlane(my_i, src);
+                const char* b = rec + (size_t)i * (size_t)R;
+                xv[v] = __builtin_nontemporal_load(reinterpret_cast<const double*>(b + offx));
+                rv[v] = (int)__builtin_nontemporal_load(reinterpret_cast<const IR*>(b + offr));
+            }
+        }
+        __syncthreads(); // slab ready
+        for (; qb < len; qb += stride) {
+            const int have = (len - qb < P) ? len - qb : P;
+            // (a2) squared terms to LDS in lanes <-> entries order; per-cluster sums / counts with LDS atomics
+            // The centroid reads run one group of four points AHEAD of the group being processed, unconditionally (every
+            // lane holds a valid row id, clamped lanes and slots past `have` included): LDS operations complete in
+            // order, so a read issued behind a group's staging writes and atomics would wait for all of them; issued in
+            // front of them it is only ever waited for together with older reads.
+            double cg[2][4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) cg[0][t] = negc[rv[t]];
+#pragma unroll
+            for (int g = 0; g < P; g += 4) {
+                if (g + 4 < P) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) cg[((g >> 2) + 1) & 1][t] = negc[rv[g + 4 + t]];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int v = g + t;
+                    if (v < have && lane_ok) {
+                        const int r = rv[v];
+                        const double d = xv[v] + cg[(g >> 2) & 1][t]; // RN(x - c): the reference's subtraction
+                        if constexpr (!(EXP & 8)) ms[(size_t)v * S1 + lane] = d * d;
+                        else if (d * d == 1.2345) ms[0] = d;
+                        if constexpr (!(EXP & 2)) unsafeAtomicAdd(&ssum[r], xv[v]);
+                        if constexpr (!(EXP & 1)) atomicAdd(&scnt[r], 1u);
+                    }
+                }
+            }
+            // the next batch: ids were fetched one batch ahead; its loads fly during (b)
+            const long long ids_done = (long long)(unsigned)my_i;
+            const int qn = qb + stride;
+            my_i = my_next;
+            if (qn < len) {
+                const int have_n = (len - qn < P) ? len - qn : P;
+#pragma unroll
+                for (int v = 0; v < P; v++) {
+                    const int src = (v < have_n) ? v : 0;
+                    const long long i = (long long)(unsigned)__builtin_amdgcn_readlane(my_i, src);
+                    const char* b = rec + (size_t)i * (size_t)R;
+                    xv[v] = __builtin_nontemporal_load(reinterpret_cast<const double*>(b + offx));
+                    rv[v] = (int)__builtin_nontemporal_load(reinterpret_cast<const IR*>(b + offr));
+                }
+                my_next = perm[start + min(qn + stride + lane_p, len - 1)];
+            }
+            // (b) one lane per point, squared terms added in storage order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < have) {
+                double acc = 0.0;
+                const double* mq = ms + (size_t)lane * S1;
+                int j = 0;
+                if constexpr (!(EXP & 4)) {
+                for (; j + 8 <= fixed_s; j += 8) {
+                    const double m0 = mq[j], m1 = mq[j + 1], m2 = mq[j + 2], m3 = mq[j + 3], m4 = mq[j + 4],
+                                 m5 = mq[j + 5], m6 = mq[j + 6], m7 = mq[j + 7];
+                    acc = acc + m0; acc = acc + m1; acc = acc + m2; acc = acc + m3;
+                    acc = acc + m4; acc = acc + m5; acc = acc + m6; acc = acc + m7;
+                }
+                for (; j < fixed_s; j++) acc = acc + mq[j];
+                }
+                const double dist = sqrt(acc);
+                mind[ids_done] = dist;
+                if (ubv) ubv[ids_done] = __double2float_ru(dist * (1.0 + 1e-12));
+                obj2 += dist * dist;
+                if (dist > dmax || (dist == dmax && ids_done < imax)) { dmax = dist; imax = ids_done; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        for (int r = tid; r < p; r += blockDim.x) {
+            const unsigned int c = scnt[r];
+            if (c) {
+                unsafeAtomicAdd(&sums[(size_t)k * p + r], ssum[r]);
+                unsafeAtomicAdd(&counts[(size_t)k * p + r], (double)c);
+            }
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        obj2 += __shfl_down(obj2, off);
+        const double om = __shfl_down(dmax, off);
+        const long long oi = __shfl_down(imax, off);
+        if (om > dmax || (om == dmax && oi < imax)) { dmax = om; imax = oi; }
+    }
+    if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, m = -1.0;
+        long long im = 0x7fffffffffffffffLL;
+        for (int w = 0; w < nwaves; w++) {
+            o += s_obj[w];
+            if (s_max[w] > m || (s_max[w] == m && s_imax[w] < im)) { m = s_max[w]; im = s_imax[w]; }
+        }
+        blk_obj2[blockIdx.x] = o;
+        blk_max[blockIdx.x] = m;
+        blk_imax[blockIdx.x] = im;
+    }
+}
+
 template __global__ void k_screen_tile<unsigned short>(const unsigned short*, const float*, const float*, int, int,
     int, int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const float*, const float*, int, int, int,

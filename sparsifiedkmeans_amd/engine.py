@@ -303,11 +303,20 @@ def dense_accumulate_device(ctx: Context, x: torch.Tensor, assign: torch.Tensor,
                                                     _p(counts)), "spkm_dense_accumulate_dev")
 
 
+_WIDEN_KIND = {torch.float32: 1, torch.uint8: 2, torch.int16: 3, torch.int32: 4}
+
+
 class StreamingSparsifier:
     """One-pass ingest of a dense dataset that never fits in HBM at once: chunk -> X*(1+2eps) -> mix ->
     sample -> append to the resident sparse shard (private/sampleAndMixFromLargeFile.m:79-129).  Only the
     sparse form (10 B per kept entry) stays on the device; the dense intermediate of a chunk lives in one
     reusable buffer and the mixed chunk never leaves LDS.
+
+    Chunks may arrive as float64 / float32 / uint8 / int16 / int32 (a 1e9-point dataset is not stored as doubles);
+    narrower types cross PCIe as they are and are widened on the device (spkm_widen_f64_dev, exact).  Host chunks go
+    through PINNED memory and a copy stream with two device staging buffers: the transfer of chunk c+1 overlaps the
+    transform + sampling of chunk c.  A chunk that already is a pinned torch tensor is sent from where it lies; numpy
+    arrays and pageable tensors are first copied into one of two pinned staging buffers (that copy is the "read").
 
     ``first`` is the global index of this rank's first point (the sample of a point depends on
     (seed, global index) only, so any chunking / sharding yields the same dataset)."""
@@ -323,28 +332,78 @@ class StreamingSparsifier:
         self.ir = torch.zeros(self.n * self.s + 48, dtype=torch.int16 if self.p2 <= 65536 else torch.int32, device=dev)
         self.x = torch.zeros(self.n * self.s + 48, dtype=torch.float64, device=dev)
         self.filled = 0
-        self._buf = None
+        self._buf = None                       # float64 chunk on the device (input of the transform)
+        self._stage = [None, None]             # device staging buffers in the source's dtype
+        self._pin = [None, None]               # pinned host staging buffers (for pageable sources)
+        self._ev_copied = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_free = [None, None]           # recorded on the main stream when a staging buffer has been consumed
+        self._ev_pin_free = [None, None]       # recorded on the copy stream when a pinned buffer has been sent
+        self._turn = 0
+        self._copy_stream = torch.cuda.Stream(device=dev)
+        self.bytes_in = 0                      # bytes that crossed PCIe (for the ingest-rate report)
 
     def append(self, chunk) -> None:
-        """chunk: [m, p] points as rows (numpy or torch, any float / integer dtype; converted to float64)."""
+        """chunk: [m, p] points as rows (numpy array or torch tensor, host or device; float64 / float32 / uint8 /
+        int16 / int32)."""
         dev = self.x.device
-        if isinstance(chunk, np.ndarray):
-            t = torch.from_numpy(np.ascontiguousarray(chunk))
-        else:
-            t = chunk
+        t = torch.from_numpy(np.ascontiguousarray(chunk)) if isinstance(chunk, np.ndarray) else chunk
+        if t.dtype not in _WIDEN_KIND and t.dtype != torch.float64:
+            t = t.to(torch.float64)
+        t = t.contiguous()
         m = t.shape[0]
-        assert t.shape[1] == self.p and self.filled + m <= self.n
+        assert t.dim() == 2 and t.shape[1] == self.p and self.filled + m <= self.n
+        # the stream the library launches on (the context's), not whatever torch's current stream happens to be now
+        main = torch.cuda.ExternalStream(self.ctx.stream, device=dev) if self.ctx.stream else torch.cuda.default_stream(dev)
         if self._buf is None or self._buf.shape[0] < m:
             self._buf = torch.empty((m, self.p), dtype=torch.float64, device=dev)
         buf = self._buf[:m]
-        buf.copy_(t, non_blocking=True)        # H2D (+ dtype conversion on device)
+        if t.is_cuda:
+            src = t
+        else:
+            b = self._turn
+            self._turn ^= 1
+            if self._stage[b] is None or self._stage[b].shape[0] < m or self._stage[b].dtype != t.dtype:
+                self._stage[b] = torch.empty((m, self.p), dtype=t.dtype, device=dev)
+                self._ev_free[b] = None
+            host = t
+            if not t.is_pinned():
+                if self._pin[b] is None or self._pin[b].shape[0] < m or self._pin[b].dtype != t.dtype:
+                    self._pin[b] = torch.empty((m, self.p), dtype=t.dtype, pin_memory=True)
+                    self._ev_pin_free[b] = None
+                if self._ev_pin_free[b] is not None:
+                    self._ev_pin_free[b].synchronize()       # the previous transfer out of this pinned buffer is done
+                self._pin[b][:m].copy_(t)                     # the host-side "read" of the chunk
+                host = self._pin[b][:m]
+            with torch.cuda.stream(self._copy_stream):
+                if self._ev_free[b] is not None:
+                    self._copy_stream.wait_event(self._ev_free[b])   # the kernels that read this staging buffer are done
+                self._stage[b][:m].copy_(host, non_blocking=True)
+                self._ev_copied[b].record(self._copy_stream)
+                if not t.is_pinned():
+                    self._ev_pin_free[b] = torch.cuda.Event()
+                    self._ev_pin_free[b].record(self._copy_stream)
+            main.wait_event(self._ev_copied[b])
+            src = self._stage[b][:m]
+            self.bytes_in += m * self.p * t.element_size()
+        if src.dtype == torch.float64:
+            fin = src if src.is_contiguous() else src.contiguous()
+        else:
+            _lib.check(_lib.lib().spkm_widen_f64_dev(self.ctx.handle, _WIDEN_KIND[src.dtype], m * self.p, _p(src), _p(buf)),
+                       "spkm_widen_f64_dev")
+            fin = buf
         o = self.filled * self.s
-        mix_sample_device(self.ctx, buf, self.p2, self.sign, 1.0 + 2.0 * float(np.finfo(np.float64).eps),
+        mix_sample_device(self.ctx, fin, self.p2, self.sign, 1.0 + 2.0 * float(np.finfo(np.float64).eps),
                           float(np.sqrt(np.float64(self.p2))), self.s, self.seed, self.first + self.filled,
                           self.ir[o:], self.x[o:])
+        if not t.is_cuda:
+            self._ev_free[b] = torch.cuda.Event()
+            self._ev_free[b].record(main)
         self.filled += m
 
     def finish(self) -> Shard:
         assert self.filled == self.n, f"expected {self.n} points, got {self.filled}"
         jc = torch.arange(0, (self.n + 1) * self.s, self.s, dtype=torch.int64, device=self.x.device)
+        self._stage = [None, None]
+        self._pin = [None, None]
+        self._buf = None
         return Shard.from_device(self.ctx, self.p2, jc, self.ir, self.x, nnz=self.n * self.s)

@@ -24,6 +24,7 @@ class Context:
         _lib.check(_lib.lib().spkm_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h)), "spkm_ctx_create")
         self.handle = h
         self.device = int(device)
+        self.stream = int(stream or 0)          # the hipStream_t the library enqueues on (0 = the default stream)
 
     def sync(self):
         _lib.check(_lib.lib().spkm_ctx_sync(self.handle), "spkm_ctx_sync")

@@ -128,3 +128,57 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
         c += 1
     jc = torch.arange(0, (n_local + 1) * s, s, dtype=torch.int64, device=dev)
     return dict(jc=jc, ir=ir, x=x, nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means)
+
+
+def streamed_pixel_dataset(ctx, p: int, n_local: int, first: int, K: int, gamma: float, seed: int = 234,
+                           chunk: int = 131072, pool_points: int = 1 << 20, sign=None):
+    """Config-5-shaped ingest (BASELINE.json: "1e9 x 784 chunk-streamed from host DRAM, K=10"; shape of
+    private/sampleAndMixFromLargeFile.m:79-129): 8-bit "pixel" points held in PINNED host memory are streamed chunk
+    by chunk over PCIe through engine.StreamingSparsifier (copy stream + two staging buffers -> widen -> mix -> sample
+    -> resident sparse shard).  The host pool holds ``pool_points`` mixture points (K cluster means in [48, 208],
+    noise sigma 10, rounded and clipped to uint8) and is cycled: point i of the dataset is pool point i mod pool_points
+    -- its SAMPLE depends on the global index i, so repeated pool points still give distinct sparse columns.
+    Returns the dict of sparsified_gmm_device plus ``labels_pool`` (cluster of each pool point), ``pool`` (the pinned
+    uint8 tensor) and ``ingest`` = dict(points, bytes, seconds, GBs)."""
+    import time
+
+    import torch
+
+    from .engine import StreamingSparsifier
+
+    dev = torch.device("cuda", ctx.device)
+    p2 = 1 << int(np.ceil(np.log2(p))) if p > 1 else 2
+    s = small_p_of(gamma, p2)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(seed)
+    means = 48.0 + 160.0 * torch.rand((K, p), generator=g0, device=dev, dtype=torch.float64)
+    if sign is None:
+        sign = torch.sign(torch.randn(p2, generator=g0, device=dev, dtype=torch.float64))
+        sign[sign == 0] = 1.0
+    pool_points = int(min(pool_points, max(n_local, 1)))
+    pool = torch.empty((pool_points, p), dtype=torch.uint8, pin_memory=True)
+    labels_pool = torch.empty(pool_points, dtype=torch.int64)
+    for c0 in range(0, pool_points, chunk):                      # generated on the device, parked in pinned host memory
+        m = min(chunk, pool_points - c0)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed((seed * 1000003) ^ (c0 + 1))
+        lab = torch.randint(0, K, (m,), generator=gen, device=dev)
+        px = means[lab] + 10.0 * torch.randn((m, p), generator=gen, device=dev, dtype=torch.float32).double()
+        pool[c0:c0 + m].copy_(px.round().clamp_(0, 255).to(torch.uint8))
+        labels_pool[c0:c0 + m].copy_(lab)
+    torch.cuda.synchronize()
+    sp_ = StreamingSparsifier(ctx, p, n_local, s, seed, sign, first=first)
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_local:
+        o = (first + done) % pool_points                         # pool position of the next point
+        m = min(chunk, n_local - done, pool_points - o)
+        sp_.append(pool[o:o + m])                                # a pinned slice: sent from where it lies
+        done += m
+    shard_arrays = (sp_.ir, sp_.x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    jc = torch.arange(0, (n_local + 1) * s, s, dtype=torch.int64, device=dev)
+    return dict(jc=jc, ir=shard_arrays[0], x=shard_arrays[1], nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means,
+                pool=pool, labels_pool=labels_pool, pool_points=pool_points,
+                ingest=dict(points=n_local, bytes=sp_.bytes_in, seconds=dt, GBs=sp_.bytes_in / dt / 1e9))
