@@ -176,6 +176,7 @@ def main():
             self.shard, self.c0 = shard_, centers0_
             self.eng = LloydEngine(shard_, K, gamma)
             self.centers = centers0_.clone()
+            self.prev = centers0_.clone()           # the centres the latest assignment was computed with
             self.restart()
             self.runs_completed, self.run_lengths = 0, []
 
@@ -186,10 +187,16 @@ def main():
 
         def step(self):
             """one Lloyd iteration; returns (dff, obj, converged_or_capped)"""
-            out = self.eng.iterate(self.centers).cpu().numpy()       # host sync: the driver needs dff to decide
+            self.prev.copy_(self.centers)
+            out = self.eng.iterate(self.centers, want_mind=False).cpu().numpy()   # host sync: the driver needs dff to decide
             self.it += 1
             dff = float(np.sqrt(out[0]))
-            return dff, float(np.sqrt(out[1])), (dff < TOL or self.it >= MAXITER)
+            done = dff < TOL or self.it >= MAXITER
+            if done:
+                # what the run returns besides the centres: IDX (eng.assign, written every iteration) and D, the
+                # distances of the LAST iteration -- materialised once per run, as kmeans_sparsified() does
+                self.eng.distances(self.prev)
+            return dff, float(np.sqrt(out[1])), done
 
         def steps(self, k):
             for _ in range(k):

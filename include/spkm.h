@@ -165,6 +165,19 @@ int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const in
 int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers,
                                double gamma, int32_t *d_assign, double *d_mind, double *d_stats,
                                uint64_t *d_nk_u64, double *d_reduce);
+/* d_mind == NULL in spkm_assign_accumulate_dev / spkm_lloyd_iter: the caller does not need the per-point distances of
+ * THIS call.  Everything is computed as before -- every distance in reference arithmetic, obj2, the largest distance and
+ * its index for EmptyAction='singleton', the library's bounds -- only the n doubles are not written (on this part a
+ * gigabyte of stores costs as much as eight of loads: 1.1 ms of a 13 ms iteration at N = 1e8).  A driver wants the
+ * distances of its LAST iteration only (kmeans_sparsified.m:493-503,514-518 use `distances` after the loop); it gets them
+ * from spkm_distances_dev:
+ *   d_mind[i] = distance of point i to centroid d_assign[i] under d_centers / gamma -- the value findClusterAssignments
+ *   returned for that point (private/findClusterAssignments.m:78,169), squared terms added in storage order.
+ * d_centers must be the centres the assignment was computed WITH (the ones passed to the call that returned d_assign,
+ * before its update).  Right after a fused call on the same shard this is one more streaming pass; otherwise a generic
+ * kernel.  Blocks on the stream once. */
+int spkm_distances_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers, double gamma,
+                       const int32_t *d_assign, double *d_mind);
 /* info[0] = path taken by the last spkm_assign_accumulate_dev (0 = exact tiles, 1 = screen + exact
  * confirmation), info[1] = points the screen could not certify.  Blocks on the stream. */
 int spkm_last_path_info(spkm_ctx *ctx, int64_t info[2]);

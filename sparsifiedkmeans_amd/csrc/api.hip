@@ -37,7 +37,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, todo2, bmapj, t32j;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, todo2, bmapj, t32j;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
@@ -219,7 +219,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     (void)spkm_comm_destroy(ctx);
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
-                     &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
+                     &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->mscr, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
                      &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->todo2, &ctx->bmapj, &ctx->t32j};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -567,6 +567,7 @@ static int launch_tile(spkm_ctx* ctx, const spkm_shard* s, int K, int G, int chu
 }
 
 static constexpr int COMBINE_BLOCKS = 1024;
+static constexpr int FIN_BLOCKS_MAX = 256;
 
 static int combine_partials(spkm_ctx* ctx, long long n, int G, int K, int32_t* d_assign, double* d_mind,
                             double* d_stats, uint64_t* d_nk_u64)
@@ -1283,7 +1284,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
                                           double gamma, int32_t* d_assign, double* d_mind, double* d_stats,
                                           uint64_t* d_nk_u64, double* d_reduce)
 {
-    if (!ctx || !s || !d_centers || !d_assign || !d_mind || !d_reduce) return SPKM_ERR_NULL_ARG;
+    if (!ctx || !s || !d_centers || !d_assign || !d_reduce) return SPKM_ERR_NULL_ARG; // d_mind may be NULL (spkm.h)
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
@@ -1355,9 +1356,85 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     }
     ctx->last_path = 0;
     sm->hb_valid = false; // the carried bounds describe the previous SCREEN call only
+    if (!d_mind) { // the exact kernels produce the distances on their way to the argmin: park them in scratch
+        if ((rc = ensure(ctx, ctx->mscr, (size_t)std::max<uint64_t>(s->n, 1) * 8))) return rc;
+        d_mind = (double*)ctx->mscr.p;
+    }
     rc = spkm_assign_dev(ctx, s, K64, d_centers, gamma, d_assign, d_mind, d_stats, d_nk_u64);
     if (rc) return rc;
     return spkm_accumulate_dev(ctx, s, K64, d_assign, d_reduce);
+}
+
+template <typename IR>
+static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d_centers, double gamma,
+                         const int32_t* d_assign, double* d_mind)
+{
+    const int p = (int)s->p;
+    const long long n = (long long)s->n;
+    int rc;
+    // fast path: the counting sort kept from this shard's last fused call still describes d_assign (checked against
+    // the library's own copy of that assignment) and the record layout exists -> the pipelined exact pass without its
+    // sums (the same loads, the same storage-order additions)
+    const long long npad = (n + 63) / 64 * 64;
+    const int threads = 1024, nw = threads / 64;
+    const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
+    const size_t fixed_lds = (size_t)p * 20 + 16;
+    bool fast = ctx->sort_owner == (const void*)s && ctx->sort_K == K && ctx->sort_n == n && s->rec && s->hb && s->hb_valid &&
+                s->hb_npad == npad && s->fixed_s > 0 && s->fixed_s <= 64 && fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
+    if (fast) {
+        if ((rc = ensure(ctx, ctx->nlist, 256))) return rc;
+        unsigned* cnt = (unsigned*)ctx->nlist.p + 20;
+        HIP_TRY(hipMemsetAsync(cnt, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_count_diff_i32, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const int*)d_assign, (const int*)(s->hb + 2 * npad), n, cnt);
+        unsigned diff = 1;
+        HIP_TRY(hipMemcpyAsync(&diff, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); // an end-of-run call, not the hot path
+        fast = diff == 0;
+    }
+    if (fast) {
+        const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4, 3>; // (EXP 3: the sums / counts atomics compiled out)
+        const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
+        HIP_TRY(allow_lds(ctx, k3, lds3));
+        const int max_items = (int)(n / ctx->sort_seg) + K + 1;
+        const int ab = std::min(max_items, std::max(1, ctx->num_cus));
+        if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(ab, FIN_BLOCKS_MAX) * 24))) return rc; // scratch for the per-block statistics
+        const char* a_rec = s->rec;
+        int a_R = s->rec_R, a_p = p, a_s = s->fixed_s;
+        const int* a_perm = (const int*)ctx->perm.p;
+        const long long* a_offs = (const long long*)ctx->offs.p;
+        const int4* a_items = (const int4*)ctx->items.p;
+        const int* a_nitems = (const int*)ctx->nitems.p;
+        const double* a_C = d_centers;
+        double a_gamma = gamma;
+        double* a_mind = d_mind;
+        float* a_ub = nullptr;
+        double *a_sums = nullptr, *a_counts = nullptr, *a_bo = (double*)ctx->blk_dff.p, *a_bm = a_bo + ab;
+        long long* a_bi = (long long*)(a_bm + ab);
+        void* args[] = {&a_rec, &a_R, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s,
+                        &a_mind, &a_ub, &a_sums, &a_counts, &a_bo, &a_bm, &a_bi};
+        HIP_TRY(hipLaunchKernel(k3, dim3(ab), dim3(threads), args, lds3, ctx->stream));
+        return SPKM_OK;
+    }
+    if ((rc = ensure(ctx, ctx->ct, (size_t)p * K * 8))) return rc;
+    hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>(((size_t)p * K + 255) / 256, 2048)), dim3(256), 0,
+                       ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
+    hipLaunchKernelGGL((k_point_distances<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
+                       (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K, n,
+                       s->fixed_s, (const int*)d_assign, d_mind);
+    HIP_TRY(hipGetLastError());
+    return SPKM_OK;
+}
+
+extern "C" int spkm_distances_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const double* d_centers, double gamma,
+                                  const int32_t* d_assign, double* d_mind)
+{
+    if (!ctx || !s || !d_centers || !d_assign || !d_mind) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (s->n == 0) return SPKM_OK;
+    return s->ir_bits == 16 ? run_distances<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind)
+                            : run_distances<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind);
 }
 
 extern "C" int spkm_last_screen_rounds(spkm_ctx* ctx, int64_t info[2])
@@ -1546,7 +1623,7 @@ extern "C" int spkm_lloyd_iter(spkm_ctx* ctx, const spkm_shard* s, uint64_t K, d
                                int unbiased, int32_t* d_assign, double* d_mind, double* d_stats, uint64_t* d_nk_u64,
                                double* d_reduce, double* d_out)
 {
-    if (!ctx || !s || !d_centers || !d_assign || !d_mind || !d_reduce || !d_out) return SPKM_ERR_NULL_ARG;
+    if (!ctx || !s || !d_centers || !d_assign || !d_reduce || !d_out) return SPKM_ERR_NULL_ARG; // d_mind may be NULL
     // findClusters = findClusterAssignments(X, centers, [], SparsityLevel) or (X, centers) (kmeans_sparsified.m:369-373)
     int rc = spkm_assign_accumulate_dev(ctx, s, K, d_centers, unbiased ? gamma : 0.0, d_assign, d_mind, d_stats,
                                         d_nk_u64, d_reduce);

@@ -864,6 +864,53 @@ __global__ __launch_bounds__(256) void k_build_records(const IR* __restrict__ ir
     }
 }
 
+// distances(i) = the reference's distance of point i to centroid assign[i], squared terms added in storage order
+// (SparseMatrixMinusCluster.c:173-180 for that one centroid): what spkm_distances_dev returns when the library's kept
+// counting sort does not describe `assign`.  One wave per point, any column length; Cs = row-major scaled centres.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_point_distances(const long long* __restrict__ jc, const IR* __restrict__ ir,
+                                                         const double* __restrict__ xval, const double* __restrict__ Cs,
+                                                         int K, long long n, int fixed_s, const int* __restrict__ assign,
+                                                         double* __restrict__ mind)
+{
+    __shared__ double stage[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long i = wave; i < n; i += nwaves) {
+        const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
+        const long long j1 = fixed_s > 0 ? j0 + fixed_s : jc[i + 1];
+        int k = assign[i];
+        if ((unsigned)k >= (unsigned)K) k = 0;
+        double acc = 0.0;
+        for (long long jb = j0; jb < j1; jb += 64) {
+            const long long j = jb + lane;
+            if (j < j1) {
+                const double d = xval[j] - Cs[(size_t)ir[j] * K + k];
+                stage[w][lane] = d * d;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                const int cnt = (int)((j1 - jb < 64) ? j1 - jb : 64);
+                for (int t = 0; t < cnt; t++) acc = acc + stage[w][t];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) mind[i] = sqrt(acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_diff_i32(const int* __restrict__ a, const int* __restrict__ b, long long n,
+                                                        unsigned* __restrict__ out)
+{
+    unsigned c = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        c += a[i] != b[i];
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 template <typename IR, int U, int WPE, bool NT, bool REC>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_exact_accumulate(
                                                           const char* __restrict__ rec, int R,
@@ -1004,7 +1051,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 }
                 for (; j < fixed_s; j++) acc = acc + mq[j];
                 const double dist = sqrt(acc);
-                mind[my_i] = dist;
+                if (mind) mind[my_i] = dist; // (null: the caller does not need per-point distances from this call)
                 if (ubv) ubv[my_i] = __double2float_ru(dist * (1.0 + 1e-12)); // the reference value is within 2^-45 of the true one
                 obj2 += dist * dist;
                 if (dist > dmax || (dist == dmax && my_i < imax)) { dmax = dist; imax = my_i; }
@@ -1172,7 +1219,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 for (; j < fixed_s; j++) acc = acc + mq[j];
                 }
                 const double dist = sqrt(acc);
-                mind[ids_done] = dist;
+                if (mind) mind[ids_done] = dist; // (null: the caller does not need per-point distances from this call)
                 if (ubv) ubv[ids_done] = __double2float_ru(dist * (1.0 + 1e-12));
                 obj2 += dist * dist;
                 if (dist > dmax || (dist == dmax && ids_done < imax)) { dmax = dist; imax = ids_done; }

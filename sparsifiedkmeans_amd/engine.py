@@ -184,14 +184,25 @@ class LloydEngine:
         _lib.check(_lib.lib().spkm_finalize_dev(self.ctx.handle, self.p, self.K, _p(self.reduce), self.gamma,
                                                 _p(centers), _p(self.out)), "spkm_finalize_dev")
 
-    def assign_accumulate_step(self, centers: torch.Tensor):
+    def assign_accumulate_step(self, centers: torch.Tensor, want_mind: bool = True):
         """assign_step + accumulate_step in one call (same outputs bit for bit; lets the library take its
-        certified-screen fast path when the shard qualifies)."""
+        certified-screen fast path when the shard qualifies).  want_mind=False: the per-point distances of this call
+        are not written (self.mind keeps whatever it held); ``distances(centers_used)`` produces them on demand."""
         assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)
         g = self.gamma if self.unbiased else 0.0
         _lib.check(_lib.lib().spkm_assign_accumulate_dev(self.ctx.handle, self.shard.handle, self.K, _p(centers), g,
-                                                         _p(self.assign), _p(self.mind), _p(self.stats), _p(self.nk),
-                                                         _p(self.reduce)), "spkm_assign_accumulate_dev")
+                                                         _p(self.assign), _p(self.mind) if want_mind else None,
+                                                         _p(self.stats), _p(self.nk), _p(self.reduce)),
+                   "spkm_assign_accumulate_dev")
+
+    def distances(self, centers_used: torch.Tensor) -> torch.Tensor:
+        """self.mind <- the reference's distance of every point to centroid self.assign[i] under ``centers_used``
+        (the centres the last assignment was computed with, i.e. BEFORE their update) -- spkm_distances_dev."""
+        assert centers_used.dtype == torch.float64 and centers_used.is_contiguous() and tuple(centers_used.shape) == (self.K, self.p)
+        g = self.gamma if self.unbiased else 0.0
+        _lib.check(_lib.lib().spkm_distances_dev(self.ctx.handle, self.shard.handle, self.K, _p(centers_used), g,
+                                                 _p(self.assign), _p(self.mind)), "spkm_distances_dev")
+        return self.mind
 
     def last_path_info(self) -> tuple[int, int]:
         a = (C.c_int64 * 2)()
@@ -214,7 +225,7 @@ class LloydEngine:
         _lib.check(_lib.lib().spkm_last_screen_mode(self.ctx.handle, a))
         return tuple(int(v) for v in a)
 
-    def iterate(self, centers: torch.Tensor):
+    def iterate(self, centers: torch.Tensor, want_mind: bool = True):
         """One full Lloyd iteration in place on ``centers``; returns the device tensor
         [dff^2, obj^2] (no host sync).  One library call (spkm_lloyd_iter: fused assignment + accumulation, the
         all-reduce over the library's RCCL communicator if one is attached, finalisation) unless the exchange has to
@@ -222,13 +233,14 @@ class LloydEngine:
         from .distributed import is_distributed
 
         if is_distributed() and comm_size(self.ctx) == 0:
-            self.assign_accumulate_step(centers)
+            self.assign_accumulate_step(centers, want_mind)
             self.allreduce_step()
             self.finalize_step(centers)
             return self.out
         assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)
         _lib.check(_lib.lib().spkm_lloyd_iter(self.ctx.handle, self.shard.handle, self.K, _p(centers), self.gamma,
-                                              1 if self.unbiased else 0, _p(self.assign), _p(self.mind), _p(self.stats),
+                                              1 if self.unbiased else 0, _p(self.assign),
+                                              _p(self.mind) if want_mind else None, _p(self.stats),
                                               _p(self.nk), _p(self.reduce), _p(self.out)), "spkm_lloyd_iter")
         return self.out
 

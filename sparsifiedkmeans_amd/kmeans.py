@@ -382,6 +382,7 @@ def kmeans_sparsified(X, K, **options):
         dff = obj = np.nan
         assignments = None
         dist_t = eng.mind                     # min-distances of the latest iteration (survives a 'drop' re-build of eng)
+        mind_pending, eng_used, centers_used = False, eng, centers
         fused_iters = 0
         for its in range(1, int(o["MaxIter"]) + 1):
             # [assignments,distances] = findClusters(X,centers) (:420) and the per-cluster sums of :430-453
@@ -391,10 +392,14 @@ def kmeans_sparsified(X, K, **options):
             else:
                 # dense centres: the fused call -- the library's fast path (certified screen, carried bounds) when the
                 # shard qualifies, the exact kernels otherwise; same outputs bit for bit (findClusterAssignments.m:76-82)
-                eng.assign_accumulate_step(centers)
+                # (per-point distances are not stored per iteration -- a gigabyte of stores per 1e8 points -- but
+                #  produced once after the loop for the iteration that turned out to be the last: spkm_distances_dev)
+                eng.assign_accumulate_step(centers, want_mind=False)
                 fused_iters += 1
-            dist_t = eng.mind
             old = centers.clone()
+            mind_pending = mask_t is None          # the distances of THIS iteration still have to be materialised
+            eng_used, centers_used = eng, old      # ... by this engine, under these centres (kept across a 'drop')
+            dist_t = eng.mind
             eng.allreduce_step()
             pk_ = p2 * Kc
             if MLcorrection:
@@ -459,6 +464,9 @@ def kmeans_sparsified(X, K, **options):
         # the last of them: 1 = certified screen + exact confirmation, 0 = all-exact kernels
         OUTPUT.setdefault("fusedIterations", np.zeros(Replicates, int))[trial] = fused_iters
         OUTPUT.setdefault("lastPath", np.zeros(Replicates, int))[trial] = eng.last_path_info()[0] if fused_iters else 0
+        if its > 0 and mind_pending:
+            eng_used.distances(centers_used)                                     # `distances` of the last iteration (:420)
+            dist_t = eng_used.mind
         distances = dist_t.cpu().numpy()
         if obj < best["obj"]:                                                    # :493-503
             best = dict(obj=obj, K=Kc, centers=centers.clone(),
