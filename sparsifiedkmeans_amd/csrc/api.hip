@@ -60,6 +60,7 @@ struct spkm_ctx {
     int last_rounds_all = 0, last_rounds = 0; // rounds for all centroids / total rounds of the last 4-lane screen call
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
+    bool last_pt_mode = false;       // ... and listed points instead of 16-point steps
     bool last_hinted = false;        // ... used the hinted two-phase form
     char errmsg[256] = {0};
     // data-parallel exchange: an RCCL communicator bound to this context's device and stream (Part 3 of spkm.h)
@@ -112,6 +113,7 @@ struct spkm_shard {
     bool hb_valid = false;
     bool skip_pending = false; // the call whose counters are pending ran the bounds test
     bool j_on = true;          // explicit bounds for the largest movers (k_pick_jumpers): on until the plain test suffices
+    bool pt_next = false;      // the next bounds test lists POINTS, not 16-point steps (the last one passed >= 90 % of the points)
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -390,6 +392,7 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->hint_pending = false;
     s->skip_pending = false;
     s->j_on = true;
+    s->pt_next = false;
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
     return SPKM_OK;
@@ -994,7 +997,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
-    bool skipping = false, jumpers = false, hinted = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
+    bool skipping = false, jumpers = false, hinted = false, pt_mode = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
             if (sm->hb) (void)hipFree(sm->hb);
@@ -1023,16 +1026,23 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             }
         }
         const bool skip_enabled = bounds_ok && !getenv("SPKM_NO_BOUNDS");
+        const bool want_jump = K >= 3 * NJUMP && sm->j_on && getenv("SPKM_JUMPERS") && !getenv("SPKM_NO_JUMPERS") &&
+                               (size_t)(p + 1) * SCREEN_KT * 4 + 16 <= ctx->lds_max;
+        // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 90 % of the points
+        // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
+        pt_mode = skip_enabled && !want_jump && sm->pt_next && !getenv("SPKM_NO_POINT_LIST");
         if (skip_enabled || hinted) {
             HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
                                d_centers, K, p, gamma, sm->hb + 3 * npad);
-            // settle the steps the bounds certify, list the others for the screen; write the hints
-            if ((rc = ensure(ctx, ctx->todo, (size_t)(npad / 16 + 1) * 4))) return rc;
-            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)((npad + BOUNDS_SPAN - 1) / BOUNDS_SPAN)), dim3(256), 0,
+            // settle the steps (points) the bounds certify, list the others for the screen; write the hints
+            if ((rc = ensure(ctx, ctx->todo, pt_mode ? (size_t)(npad + 64) * 4 : (size_t)(npad / 16 + 1) * 4))) return rc;
+            const long long span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
+            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)((npad + span - 1) / span)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
-                               (getenv("SPKM_HINT_W") ? (float)atof(getenv("SPKM_HINT_W")) : 2.0f) * (float)s->fixed_s / (float)p);
+                               (getenv("SPKM_HINT_W") ? (float)atof(getenv("SPKM_HINT_W")) : 2.0f) * (float)s->fixed_s / (float)p,
+                               pt_mode ? 1 : 0);
         }
         if (skip_enabled) {
             skipping = true;
@@ -1042,8 +1052,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             // the skipping forward by two or three iterations, but the points it settles keep their old, eroding
             // lower bounds instead of fresh ones from the screen and come back later -- measured net gain 2 % of a
             // run at N = 1e8, a loss on small shards.
-            jumpers = K >= 3 * NJUMP && sm->j_on && getenv("SPKM_JUMPERS") && !getenv("SPKM_NO_JUMPERS") &&
-                      (size_t)(p + 1) * SCREEN_KT * 4 + 16 <= ctx->lds_max;
+            jumpers = want_jump;
         }
         sm->hb_valid = false; // until this call has gone through
     } else
@@ -1095,8 +1104,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             float j_hc = 0.f;
             unsigned* j_cnt = cn + 24; // its list length sits at [24 + 4]
             const int* j_todo = (const int*)ctx->todo.p;
+            int j_tp = 0;
             void* jargs[] = {&a_ir, &a_xf, &j_t, &j_p, &j_n, &j_s, &j_K, &j_bm, &j_chunk, &j_m1, &j_m2, &j_k, &j_extra,
-                             &j_hint, &j_hc, &j_cnt, &j_todo};
+                             &j_hint, &j_hc, &j_cnt, &j_todo, &j_tp};
             HIP_TRY(hipLaunchKernel(kj, dim3(ctx->bmapj_blocks), dim3(1024), jargs, ldsj, ctx->stream));
             hipLaunchKernelGGL(k_bounds_steps2, dim3(2048), dim3(256), 0, ctx->stream, sm->hb, npad, n, K,
                                (const int*)ctx->todo.p, (int*)ctx->todo2.p, cn, (const float*)ctx->scr_m1.p,
@@ -1122,20 +1132,22 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
         const int* a_todo = skipping ? (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p) : nullptr;
+        int a_tp = pt_mode ? 1 : 0;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
-                        &a_hint, &a_hc, &a_cnt, &a_todo};
+                        &a_hint, &a_hc, &a_cnt, &a_todo, &a_tp};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(timing_end(ctx));
     ctx->last_skipping = skipping;
+    ctx->last_pt_mode = pt_mode;
     // 2. certification, 3. exact evaluation of the uncertified points
     const int cb = (int)std::min<long long>(4096, (n + 255) / 256);
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), 0, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
-                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p));
+                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p), pt_mode ? 1 : 0);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1302,6 +1314,10 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         if (listed > 0.05 * nn) sm->exact_cooldown = 8;
         // explicit bounds for the largest movers: worth their pass until the plain test alone skips most steps
         if (sm->skip_pending) sm->j_on = ((double)sm->h_nlist[3] - (double)sm->h_nlist[6]) < 0.5 * (nn / 16.0);
+        // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed
+        // (in cluster-contiguous order the failing points sit together and whole steps are as good)
+        sm->pt_next = sm->skip_pending && (double)sm->h_nlist[12] >= 0.9 * nn &&
+                      (std::ceil(nn / 16.0) - (double)sm->h_nlist[3]) * 16.0 > 1.5 * (nn - (double)sm->h_nlist[12]);
         const int nr = (s->fixed_s + 3) / 4;
         const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
         if (sm->hint_pending) {
@@ -1343,7 +1359,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
         }
         if (!sm->nlist_pending) {
-            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 64, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
             sm->nlist_pending = true;
             sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
@@ -1460,7 +1476,7 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         for (int j = 0; j < 4; j++) info[1 + j] = v[j];
         info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
         info[6] = v[6];
-        info[7] = v[7]; // the jumper tile ran in the last call
+        info[7] = v[7] ? 1 : (ctx->last_pt_mode ? 2 : 0); // 1: the jumper tile ran in the last call; 2: point-granular list
     }
     return SPKM_OK;
 }

@@ -592,11 +592,21 @@ __global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, 
     }
 }
 
-#define BOUNDS_SPAN 16384 // points per workgroup of k_bounds_steps (1024 steps)
+#define BOUNDS_SPAN 16384   // points per workgroup of k_bounds_steps (1024 steps)
+#define BOUNDS_SPAN_PT 4096 // ... when it lists points
+// pt_mode: the bounds are applied POINT BY POINT -- a point that passes keeps its assignment (and gets its lower
+// bound moved) whatever its 15 neighbours do, the others are listed one by one, and k_screen_quad / k_combine_screen
+// run over the listed points only.  With the points of a cluster scattered over the shard (data in arbitrary order)
+// a 16-point step is settled only if all 16 pass: 98 % certifiable points leave 28 % of the steps on the screen;
+// point by point it is 2 %.  The host selects it from the previous call's counters (both modes count the points that
+// passed, counters[12], and the steps whose 16 points all passed, counters[3]): >= 90 % of the points passed and the
+// steps left over hold more than 1.5x as many points as failed.  The screen then fetches 16 B per quad instead of
+// 256 B per wave, which only pays while few points are listed.
 __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
                                                       int* __restrict__ assign,
                                                       int* __restrict__ todo, unsigned* __restrict__ counters,
-                                                      float* __restrict__ hintu, int skip_enabled, float hint_w)
+                                                      float* __restrict__ hintu, int skip_enabled, float hint_w,
+                                                      int pt_mode)
 {
     // hintu != nullptr: every point's ESTIMATE of its distance to its previous centroid under the NEW centroids --
     // the hint of the two-phase screen (k_screen_quad), what the competition's partial sums are compared with.  Not
@@ -605,16 +615,17 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     // they prove nothing.  skip_enabled == 0: that is all this kernel does (SPKM_NO_BOUNDS).
     // the steps that stay are collected per workgroup in LDS and appended with ONE global atomic, the skipped ones
     // counted per workgroup (wave-level atomics on one address cost ~8 ms at N = 1e8 when nothing can be skipped)
-    __shared__ int s_todo[BOUNDS_SPAN / 16];
-    __shared__ unsigned s_cnt, s_pos, s_skip;
+    __shared__ int s_todo[BOUNDS_SPAN_PT]; // >= BOUNDS_SPAN / 16
+    __shared__ unsigned s_cnt, s_pos, s_skip, s_kept;
     const float dmx = bnd[3 * npad + K];
     const int lane = threadIdx.x & 63;
-    unsigned nskip = 0;
-    if (threadIdx.x == 0) { s_cnt = 0; s_skip = 0; }
+    unsigned nskip = 0, nkept = 0;
+    if (threadIdx.x == 0) { s_cnt = 0; s_skip = 0; s_kept = 0; }
     __syncthreads();
-    const long long span0 = (long long)blockIdx.x * BOUNDS_SPAN;
+    const int span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
+    const long long span0 = (long long)blockIdx.x * span;
     constexpr int UN = 4; // rounds whose (dependent) loads are in flight together
-    for (int it0 = 0; it0 < BOUNDS_SPAN / 256; it0 += UN) {
+    for (int it0 = 0; it0 < span / 256; it0 += UN) {
         if (span0 + it0 * 256 >= npad) break; // npad: whole waves
         float ubv[UN], lbv[UN], dav[UN];
         int apv[UN];
@@ -642,6 +653,24 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             if (span0 + (it0 + u) * 256 >= npad) break;
             const bool keep = !(i < n) || (ubv[u] + dav[u]) * 1.000001f < (lbv[u] - dmx) * 0.999999f; // false for NaN
             const unsigned long long b = __ballot(keep);
+            nkept += (unsigned)__popcll(__ballot(keep && i < n));
+            if (pt_mode) {
+                if (keep && i < n) {
+                    assign[i] = apv[u];
+                    bnd[npad + i] = __double2float_rd(((double)lbv[u] - (double)dmx) * (1.0 - 0x1p-20));
+                }
+                const unsigned long long lm = ~b; // (lanes past n count as kept)
+                if (lm) {
+                    unsigned basepos = 0;
+                    if (lane == 0) basepos = atomicAdd(&s_cnt, (unsigned)__popcll(lm));
+                    basepos = __builtin_amdgcn_readfirstlane(basepos);
+                    if (!keep) s_todo[basepos + __popcll(lm & ((1ull << lane) - 1ull))] = (int)i;
+                }
+                // (statistics in the same unit as the other mode: steps whose 16 points all passed)
+                const bool whole = ((unsigned)(b >> (lane & 48)) & 0xffffu) == 0xffffu;
+                nskip += (unsigned)__popcll(__ballot((lane & 15) == 0 && (i - (lane & 15)) < n && whole));
+                continue;
+            }
             const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
             const bool skip = grp == 0xffffu;
             const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
@@ -661,9 +690,11 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
         }
     }
     if (lane == 0 && nskip) atomicAdd(&s_skip, nskip);
+    if (lane == 0 && nkept) atomicAdd(&s_kept, nkept);
     __syncthreads();
     if (threadIdx.x == 0) {
         s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
+        if (s_kept) atomicAdd(counters + 12, s_kept); // points that passed the test (either mode)
         if (s_skip) {
             atomicAdd(counters + 3, s_skip);
             atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)s_skip); // never reset: running total
@@ -700,7 +731,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         int* __restrict__ assign, int* __restrict__ list,
                                                         unsigned int* __restrict__ nlist,
                                                         float* __restrict__ bnd, long long npad, int skipping,
-                                                        const int* __restrict__ todo)
+                                                        const int* __restrict__ todo, int pt_mode)
 {
     // nlist[5]: points whose (tentative) assignment differs from the previous call's (the library's copy in bnd)
     const int* aprev = bnd ? reinterpret_cast<const int*>(bnd + 2 * npad) : nullptr;
@@ -714,10 +745,10 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     const double nu = 0x1p-45;
     unsigned nambig = 0;
     // skipping: k_bounds_steps has settled the skipped steps; only the listed ones (nlist[4] of them) are looked at
-    const long long total = skipping ? (long long)nlist[4] * 16 : n;
+    const long long total = skipping ? (pt_mode ? (long long)nlist[4] : (long long)nlist[4] * 16) : n;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
          q += (long long)gridDim.x * blockDim.x) {
-        const long long i = skipping ? (long long)todo[q >> 4] * 16 + (q & 15) : q;
+        const long long i = skipping ? (pt_mode ? (long long)todo[q] : (long long)todo[q >> 4] * 16 + (q & 15)) : q;
         if (i >= n) continue;
         float b1 = __builtin_inff(), b2 = __builtin_inff();
         int bk = -1;
@@ -1326,7 +1357,8 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int* __restrict__ ko, char* smem, unsigned* ticket, int extra_base,
                                                  int extra_k0,
                                                  const float* __restrict__ hint, float hint_c,
-                                                 unsigned* __restrict__ counters, const int* __restrict__ todo)
+                                                 unsigned* __restrict__ counters, const int* __restrict__ todo,
+                                                 int todo_pts)
 {
     constexpr int PPS = 16;
     const int lane = threadIdx.x & 63;
@@ -1367,11 +1399,27 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     for (int t = draw(); t < Tn; t = draw()) {
         const int vbase = point_of(t);
         if (vbase < nv) {
-            const int base = todo != nullptr ? todo[vbase >> 4] << 4 : vbase;
-            const int i = base + ps;
-            // step-major screen copy (k_screen_reorder): round r of this step is 64 consecutive elements
-            const float* xp = xval + (size_t)(base >> 4) * (NR * 64) + lane;
-            const IR* rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
+            // step-major screen copy (k_screen_reorder): round r of a step is 64 consecutive elements, element
+            // 4 * slot + l4 belongs to the step's point `slot`
+            int i;
+            const float* xp;
+            const IR* rp;
+            if (todo_pts > 0) {
+                // the list names POINTS (k_bounds_steps, point mode): 16 unrelated points share this wave's step, each
+                // quad fetches its own point's elements (16 B per quad and round instead of one 256-B row per wave --
+                // affordable only while few points are listed, which is when the host selects this mode)
+                const int slot = vbase + ps;
+                const int q = slot < todo_pts ? todo[slot] : n;       // n: an empty slot (no output)
+                const int qc = q < n ? q : n - 1;
+                i = q;
+                xp = xval + (size_t)(qc >> 4) * (NR * 64) + ((qc & 15) << 2) + l4;
+                rp = ir + (size_t)(qc >> 4) * (NR * 64) + ((qc & 15) << 2) + l4;
+            } else {
+                const int base = todo != nullptr ? todo[vbase >> 4] << 4 : vbase;
+                i = base + ps;
+                xp = xval + (size_t)(base >> 4) * (NR * 64) + lane;
+                rp = ir + (size_t)(base >> 4) * (NR * 64) + lane;
+            }
             // the hint is needed only after the first evaluation, but its load must not wait until then (a second
             // exposed memory latency per step): issued first, pinned in a register before the rounds
             float hraw = 0.f;
@@ -1538,7 +1586,8 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile,
-    const float* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const int* __restrict__ todo)
+    const float* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const int* __restrict__ todo,
+    int todo_points) // todo_points != 0: the list holds point ids (counters[4] of them), not 16-point steps
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -1566,15 +1615,16 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
     constexpr int A = TWO ? quad_split(NR) : NR;
-    int nv = n, chunk_v = chunk_points;
+    int nv = n, chunk_v = chunk_points, tp = 0;
     if (todo != nullptr) { // counters[4] = length of the list; chunks small enough that every workgroup gets several
-        nv = (int)counters[4] * 16;
+        if (todo_points) { tp = (int)counters[4]; nv = (tp + 15) & ~15; }
+        else nv = (int)counters[4] * 16;
         chunk_v = max(256, min(chunk_points, (nv / (int)(gridDim.x * 2)) & ~255));
     }
-    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
-    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
-    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
-    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo);
+    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
+    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
+    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
+    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)

@@ -464,3 +464,41 @@ def test_largest_movers_are_bounded_explicitly(gpu_ctx, oracle, monkeypatch):
             cur[:, k] = cen[:, k] + 0.4 * np.abs(cen).mean() * rng.standard_normal(p2)
         call(cur)
     assert max(via_movers) > 0.3 * (n // 16), via_movers
+
+
+def test_point_granular_bounds_list_on_data_in_arbitrary_order(gpu_ctx, oracle, monkeypatch):
+    """Points of a cluster scattered over the shard: a 16-point step is rarely settled as a whole, so once most points
+    pass the bounds test the library lists POINTS (spkm_last_screen_mode info[7] == 2) and the screen runs on them
+    alone.  Outputs stay the oracle's, call after call; the A/B switch SPKM_NO_POINT_LIST=1 gives the same."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 256, 40000, 24, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=31, noise=0.3)
+    X = X[:, np.random.default_rng(0).permutation(n)]                # arbitrary order
+    rng = np.random.default_rng(2)
+    d = np.sign(rng.standard_normal(p))
+    Xm = oracle.mix(X, d, p)
+    Y = synth.sparsify_dense(Xm, synth.small_p_of(gopt, p), rng)
+    gam = synth.small_p_of(gopt, p) / p
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    C0 = oracle.mix(X[:, rng.choice(n, K, replace=False)], d, p)     # K mixture points: a run that takes a while
+    seen = {}
+    for nolist in (False, True):
+        if nolist:
+            monkeypatch.setenv("SPKM_NO_POINT_LIST", "1")
+        shard.reset_policy()
+        eng = LloydEngine(shard, K, gam)
+        c = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
+        modes = []
+        for it in range(16):
+            used = c.cpu().numpy().T.copy()
+            eng.iterate(c)
+            torch.cuda.synchronize()                                 # (lets the library's asynchronous counters land)
+            modes.append(eng.last_screen_mode()[7])
+            ra, rd = oracle.assign(p, n, *parts(Y), used, gam)
+            assert np.array_equal(eng.assign.cpu().numpy(), ra), (nolist, it)
+            assert np.array_equal(eng.mind.cpu().numpy(), rd), (nolist, it)
+        seen[nolist] = modes
+    assert 2 in seen[False], seen                                    # the point list was used ...
+    assert 2 not in seen[True], seen                                 # ... and not when switched off
