@@ -216,9 +216,9 @@ def main():
     nnz_local = int(shard.nnz)
     # algorithmic bytes of one Lloyd iteration over this GPU's points ...
     b_iter = nnz_local * 12 + (n_local + 1) * 8 + n_local * 12 + 24 * p2 * K
-    # ... and of the exact accumulation pass alone: values + row ids once, the sort permutation in, the
-    # min-distances out, the per-cluster sums and counts out
-    b_acc = nnz_local * (8 + irb) + n_local * 12 + 16 * p2 * K
+    # ... and of the exact accumulation pass alone: values + row ids once, the sort permutation in (4 B), the library's
+    # upper bound out (4 B; the 8-B min-distance is stored on demand only, once per run), the per-cluster sums and counts out
+    b_acc = nnz_local * (8 + irb) + n_local * 8 + 16 * p2 * K
     steps_per_tile = (n_local + 15) // 16
 
     loop = Loop(shard, centers0)
@@ -259,7 +259,7 @@ def main():
     rl_acc = roofline_obj("k_exact_accumulate", acc_ms, b_acc,
                           "HBM bound: one pass over the f64 values and row ids in counting-sort order, reference arithmetic "
                           "for each point's distance to its centroid fused with the per-cluster sums (DESIGN.md section 4.2); "
-                          "bytes = nnz*(8+2) + n*12 + 16*p*K, all streamed in every launch") if acc_ms > 0 else None
+                          "bytes = nnz*(8+2) + n*8 + 16*p*K, all streamed in every launch") if acc_ms > 0 else None
     # top-level roofline: the kernel that took more of the timed region (both are always listed under by_kernel, each
     # with ONE byte model, so either can be followed from round to round)
     top = rl_acc if (rl_acc and acc_ms > screen_ms) else rl_screen
@@ -430,7 +430,7 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
         r["roofline_cold_no_carry"] = roofline_obj(scr_name, float(scr[0]), b_iter,
                                                    "plain screen, every 16-point step, SURVEY 8(d) bytes of an iteration")
         r["roofline_converged"] = roofline_obj("k_exact_accumulate", float(acc[-min(3, its):].mean()), b_acc,
-                                               "exact confirmation + accumulation pass, nnz*(8+2) + n*12 + 16*p*K bytes")
+                                               "exact confirmation + accumulation pass, nnz*(8+2) + n*8 + 16*p*K bytes")
     loop.restart()
     return r
 
