@@ -316,6 +316,25 @@ def dense_accumulate_device(ctx: Context, x: torch.Tensor, assign: torch.Tensor,
 
 
 _WIDEN_KIND = {torch.float32: 1, torch.uint8: 2, torch.int16: 3, torch.int32: 4}
+_copy_pool = None
+
+
+def _parallel_host_copy(dst: torch.Tensor, src: torch.Tensor, threads: int = 8) -> None:
+    """dst.copy_(src) for large host tensors, row blocks in parallel: one thread's memcpy moves ~6 GB/s, a fraction of
+    what PCIe takes from the pinned buffer afterwards (torch's copy releases the GIL)."""
+    global _copy_pool
+    m = dst.shape[0]
+    if m * dst.shape[1] * dst.element_size() < (8 << 20) or threads <= 1:
+        dst.copy_(src)
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _copy_pool = ThreadPoolExecutor(max_workers=threads)
+    step = -(-m // threads)
+    futs = [_copy_pool.submit(lambda a=a: dst[a:a + step].copy_(src[a:a + step])) for a in range(0, m, step)]
+    for f in futs:
+        f.result()
 
 
 class StreamingSparsifier:
@@ -384,7 +403,7 @@ class StreamingSparsifier:
                     self._ev_pin_free[b] = None
                 if self._ev_pin_free[b] is not None:
                     self._ev_pin_free[b].synchronize()       # the previous transfer out of this pinned buffer is done
-                self._pin[b][:m].copy_(t)                     # the host-side "read" of the chunk
+                _parallel_host_copy(self._pin[b][:m], t)      # the host-side "read" of the chunk
                 host = self._pin[b][:m]
             with torch.cuda.stream(self._copy_stream):
                 if self._ev_free[b] is not None:

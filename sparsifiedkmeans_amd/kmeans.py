@@ -183,9 +183,14 @@ def kmeans_sparsified(X, K, **options):
         OUTPUT["TimeToReadSizeOfFile"] = time.time() - t1
         X = None
     else:
-        X = np.asarray(X, np.float64)
         if np.iscomplexobj(X):
             raise ValueError("Code and distance computations require real data")   # :312-314
+        X = np.asarray(X)
+        # float32 / uint8 / int16 data stays as it is on the host (it crosses PCIe narrow and is widened on the device,
+        # exactly); everything else becomes float64 as in MATLAB
+        keep_narrow = X.dtype in (np.float32, np.uint8, np.int16) and str(o["SketchType"]).lower() in ("auto", "hadamard")
+        if not keep_narrow:
+            X = np.asarray(X, np.float64)
         if not o["ColumnSamples"]:
             X = X.T                                                                 # :214-216 (points become columns)
         p, n = X.shape
@@ -394,18 +399,28 @@ def kmeans_sparsified(X, K, **options):
                 # shard qualifies, the exact kernels otherwise; same outputs bit for bit (findClusterAssignments.m:76-82)
                 # (per-point distances are not stored per iteration -- a gigabyte of stores per 1e8 points -- but
                 #  produced once after the loop for the iteration that turned out to be the last: spkm_distances_dev)
-                eng.assign_accumulate_step(centers, want_mind=False)
+                old = centers.clone()
+                if MLcorrection:
+                    # assignment + accumulation + all-reduce + gamma*S./(Cnt+1e-16) + dff + obj: ONE library call
+                    # (spkm_lloyd_iter; kmeans_sparsified.m:420-471)
+                    eng.iterate(centers, want_mind=False)
+                else:
+                    eng.assign_accumulate_step(centers, want_mind=False)
                 fused_iters += 1
-            old = centers.clone()
+            if mask_t is not None:
+                old = centers.clone()
             mind_pending = mask_t is None          # the distances of THIS iteration still have to be materialised
             eng_used, centers_used = eng, old      # ... by this engine, under these centres (kept across a 'drop')
             dist_t = eng.mind
-            eng.allreduce_step()
             pk_ = p2 * Kc
-            if MLcorrection:
+            if MLcorrection and mask_t is None:
+                dff2_t = eng.out[0:1]                                            # (finalised inside the call above)
+            elif MLcorrection:
+                eng.allreduce_step()
                 eng.finalize_step(centers)                                       # gamma*S./(Cnt+1e-16)  (:447-448)
                 dff2_t = eng.out[0:1]
             else:
+                eng.allreduce_step()
                 # centers(:,ki) = mean(full(X(:,ind)),2) (:449-451): plain mean of the sparse columns, zeros included
                 nk_ = eng.reduce[2 * pk_: 2 * pk_ + Kc]
                 mean_ = eng.reduce[:pk_].view(Kc, p2) / torch.clamp(nk_, min=1.0)[:, None]
