@@ -422,6 +422,8 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
          "run_to_convergence_mean_ms": float(ms.mean()),
          "cold_no_carry_ms": float(ms[0]),
          "converged_ms": float(tail.mean()), "converged_iters_per_s": 1e3 / float(tail.mean()),
+         # for comparison across rounds only: round 1 timed iterations W+1 .. W+K of ONE run (its --warmup 5 --steps 20 window)
+         "r01_window_iters_6_to_25_per_s": (20.0 / (float(ms[5:25].sum()) * 1e-3)) if its >= 25 else None,
          "per_iter_ms": [round(float(v), 2) for v in ms],
          "kernels_ms": {scr_name: [round(float(v), 2) for v in scr], "k_exact_accumulate": [round(float(v), 2) for v in acc]}}
     if scr.size:
