@@ -1235,7 +1235,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
     // software-pipelined record kernel (k_exact_accumulate_rec): batches of exactly 16 points per wave, columns of up
     // to 64 entries; SPKM_NO_REC_PIPE=1 keeps k_exact_accumulate on the records (A/B switch)
-    const bool pipe = use_rec && !getenv("SPKM_NO_REC_PIPE") && threads == 1024 && s->fixed_s <= 64 &&
+    const bool pipe = use_rec && !getenv("SPKM_NO_REC_PIPE") && s->fixed_s <= 64 &&
                       fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
     if (pipe) {
         const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4>;

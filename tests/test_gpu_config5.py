@@ -18,6 +18,7 @@ def test_config5_shard_streamed_ingest_and_lloyd(gpu_ctx, oracle, capsys):
     from sparsifiedkmeans_amd import synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_device
 
+    torch.cuda.empty_cache()                                       # (blocks cached by earlier tests are not "used")
     free, _ = torch.cuda.mem_get_info()
     if free < 200e9:
         pytest.skip("needs ~190 GB of free HBM (shard 64 GB + record layout 64 GB + screen copy 38 GB)")
