@@ -226,6 +226,7 @@ def main():
     loop.restart()                                  # the timed steps start a run, whatever W was
     loop.runs_completed, loop.run_lengths = 0, []
     skipped0 = loop.eng.last_screen_mode()[5] if args.warmup > 0 else 0   # running total of steps skipped so far
+    acc_pts0 = loop.eng.exact_pass_points()[0]                             # ... and of points the exact pass streamed
     _lib.check(L.spkm_timing_log(ctx.handle, 2))   # screen path: two pairs per call (screen, exact accumulation)
     sync_all()
     t0 = time.perf_counter()
@@ -251,12 +252,17 @@ def main():
     # share of the screen's 16-point steps that the timed launches actually processed (the others were skipped on the
     # bounds carried between calls): the screen is credited with that share of the algorithmic bytes only
     done = 1.0 - (mode[5] - skipped0) / (steps_per_tile * args.steps) if path == 1 and steps_per_tile else 1.0
+    # share of the points the exact pass streamed in the timed launches (clusters that no point left or entered and whose
+    # centroid did not move are not streamed again): it is credited with that share of its bytes only
+    acc_share = (eng.exact_pass_points()[0] - acc_pts0) / (n_local * args.steps) if path == 1 and n_local else 1.0
     scr_name = dominant_kernel(path, s)
     rl_screen = roofline_obj(scr_name, screen_ms, int(b_iter * done),
                              f"assignment kernel; mean over the timed launches, which processed {done:.3f} of their 16-point "
                              "steps (the rest skipped on carried bounds; SURVEY 8(d) bytes of an iteration scaled by that "
                              "share).  VALU-issue / LDS bound at K=100, not HBM bound (DESIGN.md section 4)")
-    rl_acc = roofline_obj("k_exact_accumulate", acc_ms, b_acc,
+    rl_acc = roofline_obj("k_exact_accumulate", acc_ms, int(b_acc * acc_share),
+                          f"mean over the timed launches, which streamed {acc_share:.3f} of the points (settled clusters are not "
+                          "streamed again; bytes scaled by that share).  "
                           "HBM bound: one pass over the f64 values and row ids in counting-sort order, reference arithmetic "
                           "for each point's distance to its centroid fused with the per-cluster sums (DESIGN.md section 4.2); "
                           "bytes = nnz*(8+2) + n*8 + 16*p*K, all streamed in every launch") if acc_ms > 0 else None
@@ -267,6 +273,7 @@ def main():
     roofline["traffic"] = pmc_traffic(top["kernel"], n_local, K, p2, args.start)
     roofline["by_kernel"] = {scr_name: rl_screen, **({"k_exact_accumulate": rl_acc} if rl_acc else {})}
     roofline["screen_steps_processed_share"] = done
+    roofline["exact_pass_points_share"] = acc_share
     ops = 3.0 * nnz_local * K
     out = eng.out.cpu().numpy()
 
@@ -431,8 +438,12 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
         # the converged one the exact accumulation pass
         r["roofline_cold_no_carry"] = roofline_obj(scr_name, float(scr[0]), b_iter,
                                                    "plain screen, every 16-point step, SURVEY 8(d) bytes of an iteration")
-        r["roofline_converged"] = roofline_obj("k_exact_accumulate", float(acc[-min(3, its):].mean()), b_acc,
-                                               "exact confirmation + accumulation pass, nnz*(8+2) + n*8 + 16*p*K bytes")
+        last_pts = loop.eng.exact_pass_points()[1]
+        share = last_pts / max(loop.shard.n, 1)
+        r["exact_pass_points_share_last_iter"] = share
+        r["roofline_converged"] = roofline_obj("k_exact_accumulate", float(acc[-min(3, its):].mean()), int(b_acc * share),
+                                               f"exact confirmation + accumulation pass over the {share:.3f} of the points in clusters "
+                                               "that changed; (nnz*(8+2) + n*8 + 16*p*K) bytes scaled by that share")
     loop.restart()
     return r
 

@@ -113,6 +113,13 @@ struct spkm_shard {
     bool hb_valid = false;
     bool skip_pending = false; // the call whose counters are pending ran the bounds test
     bool j_on = true;          // explicit bounds for the largest movers (k_pick_jumpers): on until the plain test suffices
+    // unchanged-cluster shortcut of the exact pass (screen.hip, k_cluster_need): per-cluster cache of the LOCAL sums and
+    // counts (2 p K doubles), obj2 / max distance / its index (3 K), flags need | touched | same | ibeg | icnt (5 K ints)
+    double* cl_cache = nullptr;
+    int* cl_flags = nullptr;
+    size_t cl_pk = 0;
+    int cl_K = 0;
+    bool cl_valid = false;     // the cache describes this shard's previous screen call completely
     bool pt_next = false;      // the next bounds test lists POINTS, not 16-point steps (the last one passed >= 90 % of the points)
 };
 
@@ -366,6 +373,8 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xf) (void)hipFree(s->xf);
     if (s->xfs) (void)hipFree(s->xfs);
     if (s->rec) (void)hipFree(s->rec);
+    if (s->cl_cache) (void)hipFree(s->cl_cache);
+    if (s->cl_flags) (void)hipFree(s->cl_flags);
     if (s->irs) (void)hipFree(s->irs);
     if (s->hb) (void)hipFree(s->hb);
     if (s->hintu) (void)hipFree(s->hintu);
@@ -393,6 +402,7 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->skip_pending = false;
     s->j_on = true;
     s->pt_next = false;
+    s->cl_valid = false;
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
     return SPKM_OK;
@@ -997,6 +1007,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
+    bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
     bool skipping = false, jumpers = false, hinted = false, pt_mode = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
@@ -1031,10 +1042,20 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 90 % of the points
         // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
         pt_mode = skip_enabled && !want_jump && sm->pt_next && !getenv("SPKM_NO_POINT_LIST");
+        // per-cluster cache / flags of the unchanged-cluster shortcut
+        if (!sm->cl_cache || sm->cl_pk != pk || sm->cl_K != K) {
+            if (sm->cl_cache) (void)hipFree(sm->cl_cache);
+            if (sm->cl_flags) (void)hipFree(sm->cl_flags);
+            sm->cl_cache = nullptr; sm->cl_flags = nullptr; sm->cl_valid = false;
+            HIP_TRY(hipMalloc((void**)&sm->cl_cache, (2 * pk + 3 * (size_t)K) * 8));
+            HIP_TRY(hipMalloc((void**)&sm->cl_flags, (size_t)5 * K * 4));
+            sm->cl_pk = pk; sm->cl_K = K;
+        }
         if (skip_enabled || hinted) {
             HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
+            drift_ran = true;
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
-                               d_centers, K, p, gamma, sm->hb + 3 * npad);
+                               d_centers, K, p, gamma, sm->hb + 3 * npad, sm->cl_flags + 2 * K);
             // settle the steps (points) the bounds certify, list the others for the screen; write the hints
             if ((rc = ensure(ctx, ctx->todo, pt_mode ? (size_t)(npad + 64) * 4 : (size_t)(npad / 16 + 1) * 4))) return rc;
             const long long span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
@@ -1164,44 +1185,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
     if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
-    const bool reuse = quad && bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n &&
-                       ctx->sort_seg == seg && !getenv("SPKM_NO_SORT_REUSE");
-    const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
-    ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
-    if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls)
-        hipLaunchKernelGGL(k_copy_i32_gated, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0,
-                           ctx->stream, (int*)(sm->hb + 2 * npad), (const int*)d_assign, n, gate);
-    hipLaunchKernelGGL(k_zero_u64_gated, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
-                       (unsigned long long*)ctx->nk.p, K, gate);
-    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
-                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p, gate);
-    hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
-                       seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
-                       (int*)ctx->nitems.p, gate);
-    const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
-    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
-    hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
-                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate);
-    if (quad) {
-        ctx->sort_owner = sm;
-        ctx->sort_K = K;
-        ctx->sort_n = n;
-        ctx->sort_seg = seg;
-    }
-    // 5. exact distance to the assigned centroid + per-cluster accumulation
+    // (the exact pass's geometry is needed here already: the plan below depends on which kernel runs)
     int threads = 1024;
     if (const char* ev = getenv("SPKM_ACC_THREADS")) threads = atoi(ev) == 512 ? 512 : 1024; // A/B aid
     const int nw = threads / 64;
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     const size_t fixed_lds = (size_t)p * 20 + 16;
-    // 1 KB headroom: the kernel also has 384 B of static LDS (per-wave partial statistics)
-    int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 1024) / nw / per_pt);
-    pts = std::max(8, pts & ~7);
-    if (const char* ev = getenv("SPKM_PTS")) pts = std::max(8, atoi(ev) & ~7);
-    const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
-    int per_cu = 1;
-    if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
-    const bool nt = getenv("SPKM_ACC_NT") != nullptr;
     // Record layout of the exact entries (screen.hip, k_build_records): built once per shard on the first screen call,
     // when the device has room for it (n * R bytes: 51 GB at N = 1e8, s = 51).  With the points of a cluster scattered
     // over the shard (data in arbitrary order) it takes a third off this pass; in cluster-contiguous order it is
@@ -1221,6 +1210,62 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         }
     }
     const bool use_rec = sm->rec != nullptr;
+    // software-pipelined record kernel (k_exact_accumulate_rec): batches of exactly 16 points per wave, columns of up
+    // to 64 entries; SPKM_NO_REC_PIPE=1 keeps k_exact_accumulate on the records (A/B switch)
+    const bool pipe = use_rec && !getenv("SPKM_NO_REC_PIPE") && s->fixed_s <= 64 &&
+                      fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
+    // Unchanged-cluster shortcut (screen.hip, k_cluster_need): clusters whose centroid is bitwise the previous call's and
+    // that no point left or entered are not streamed again -- their sums, counts, distances, bounds and statistics are
+    // what the previous call produced.  Needs the per-item statistics of the pipelined kernel, the library's copy of
+    // the previous assignment (bounds_ok) and a complete cache; not when the caller wants the distances written.
+    // SPKM_NO_CLUSTER_SKIP=1: A/B switch.
+    const bool cl_on = quad && pipe && sm->cl_cache != nullptr;
+    const bool cl_skip = cl_on && bounds_ok && drift_ran && sm->cl_valid && d_mind == nullptr && !getenv("SPKM_NO_CLUSTER_SKIP");
+    int* cl_need = cl_on ? sm->cl_flags : nullptr;
+    int* cl_touched = cl_on ? sm->cl_flags + K : nullptr;
+    int* cl_same = cl_on ? sm->cl_flags + 2 * K : nullptr;
+    int* cl_ibeg = cl_on ? sm->cl_flags + 3 * K : nullptr;
+    int* cl_icnt = cl_on ? sm->cl_flags + 4 * K : nullptr;
+    const bool reuse = quad && bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n &&
+                       ctx->sort_seg == seg && !getenv("SPKM_NO_SORT_REUSE");
+    const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
+    ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
+    if (cl_on) HIP_TRY(hipMemsetAsync(cl_touched, 0, (size_t)K * 4, ctx->stream));
+    if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls); marks the
+              // clusters a point left or entered on the way
+        hipLaunchKernelGGL(k_copy_i32_gated, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0,
+                           ctx->stream, (int*)(sm->hb + 2 * npad), (const int*)d_assign, n, gate,
+                           cl_skip ? cl_touched : (int*)nullptr, K);
+    hipLaunchKernelGGL(k_zero_u64_gated, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                       (unsigned long long*)ctx->nk.p, K, gate);
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
+                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p, gate);
+    if (cl_on)
+        hipLaunchKernelGGL(k_cluster_need, dim3(1), dim3(256), 0, ctx->stream, (const int*)cl_touched, (const int*)cl_same,
+                           cl_skip ? 0 : 1, K, (const unsigned long long*)ctx->nk.p, cl_need, (unsigned*)ctx->nlist.p);
+    // (with the shortcut on the plan is never gated: which clusters need work changes even when no assignment does)
+    hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
+                       seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                       (int*)ctx->nitems.p, cl_on ? (const unsigned*)nullptr : gate, (const int*)cl_need, cl_ibeg, cl_icnt);
+    const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
+    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+    hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
+                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate);
+    if (quad) {
+        ctx->sort_owner = sm;
+        ctx->sort_K = K;
+        ctx->sort_n = n;
+        ctx->sort_seg = seg;
+    }
+    // 5. exact distance to the assigned centroid + per-cluster accumulation
+    // 1 KB headroom: the kernel also has 384 B of static LDS (per-wave partial statistics)
+    int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 1024) / nw / per_pt);
+    pts = std::max(8, pts & ~7);
+    if (const char* ev = getenv("SPKM_PTS")) pts = std::max(8, atoi(ev) & ~7);
+    const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
+    int per_cu = 1;
+    if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
+    const bool nt = getenv("SPKM_ACC_NT") != nullptr;
     // 16 points' loads in flight per wave; 4 waves per SIMD (2 with 512-thread workgroups)
     const void* k2 = threads == 512
         ? (use_rec ? (nt ? (const void*)k_exact_accumulate<IR, 16, 2, true, true> : (const void*)k_exact_accumulate<IR, 16, 2, false, true>)
@@ -1229,14 +1274,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                    : (nt ? (const void*)k_exact_accumulate<IR, 16, 4, true, false> : (const void*)k_exact_accumulate<IR, 16, 4, false, false>));
     HIP_TRY(allow_lds(ctx, (const void*)k2, lds2));
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * per_cu);
-    if ((rc = ensure(ctx, ctx->blk_obj, (size_t)ab * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->blk_max, (size_t)ab * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->blk_imax, (size_t)ab * 8))) return rc;
+    // statistics: per workgroup (k_exact_accumulate) or per work item (k_exact_accumulate_rec)
+    if ((rc = ensure(ctx, ctx->blk_obj, (size_t)std::max(ab, max_items) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_max, (size_t)std::max(ab, max_items) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->blk_imax, (size_t)std::max(ab, max_items) * 8))) return rc;
     if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
-    // software-pipelined record kernel (k_exact_accumulate_rec): batches of exactly 16 points per wave, columns of up
-    // to 64 entries; SPKM_NO_REC_PIPE=1 keeps k_exact_accumulate on the records (A/B switch)
-    const bool pipe = use_rec && !getenv("SPKM_NO_REC_PIPE") && s->fixed_s <= 64 &&
-                      fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
     if (pipe) {
         const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4>;
         const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
@@ -1276,8 +1318,29 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         HIP_TRY(hipLaunchKernel(k2, dim3(ab), dim3(threads), args, lds2, ctx->stream));
     }
     if (ctx->tlog_both) HIP_TRY(timing_end(ctx));
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
-                       (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, ab, (double*)ctx->stats.p);
+    if (cl_on) {
+        double* cache_s = sm->cl_cache;
+        double* cache_c = cache_s + pk;
+        double* cl_obj = cache_c + pk;
+        double* cl_max = cl_obj + K;
+        long long* cl_imax = reinterpret_cast<long long*>(cl_max + K);
+        hipLaunchKernelGGL(k_cluster_restore, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+                           (const int*)cl_need, K, p, sums, counts, cache_s, cache_c);
+        hipLaunchKernelGGL(k_cluster_stats, dim3(1), dim3(256), 0, ctx->stream, (const int*)cl_need, K, (const int*)cl_ibeg,
+                           (const int*)cl_icnt, (const double*)ctx->blk_obj.p, (const double*)ctx->blk_max.p,
+                           (const long long*)ctx->blk_imax.p, cl_obj, cl_max, cl_imax, (double*)ctx->stats.p);
+        sm->cl_valid = true;
+    } else {
+        sm->cl_valid = false;
+        if (pipe) { // per-item statistics without the per-cluster stage: the items are simply reduced as blocks were
+            // (nitems lives on the device; unused slots are not read: reduce over the items the plan emitted)
+            hipLaunchKernelGGL(k_reduce_stats_n, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
+                               (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, (const int*)ctx->nitems.p,
+                               (double*)ctx->stats.p);
+        } else
+            hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
+                               (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, ab, (double*)ctx->stats.p);
+    }
     hipLaunchKernelGGL(k_nk_to_f64, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)ctx->nk.p, K, nk_f);
     HIP_TRY(hipGetLastError());
@@ -1414,7 +1477,12 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
         HIP_TRY(allow_lds(ctx, k3, lds3));
         const int max_items = (int)(n / ctx->sort_seg) + K + 1;
         const int ab = std::min(max_items, std::max(1, ctx->num_cus));
-        if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(ab, FIN_BLOCKS_MAX) * 24))) return rc; // scratch for the per-block statistics
+        // the kept plan may cover only the clusters the last call had to process: plan all of them again (the
+        // permutation and the offsets stand; the scatter cursors it rewrites are not used any more)
+        hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
+                           ctx->sort_seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                           (int*)ctx->nitems.p, (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+        if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(max_items, FIN_BLOCKS_MAX) * 24))) return rc; // scratch for the per-item statistics
         const char* a_rec = s->rec;
         int a_R = s->rec_R, a_p = p, a_s = s->fixed_s;
         const int* a_perm = (const int*)ctx->perm.p;
@@ -1425,8 +1493,8 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
         double a_gamma = gamma;
         double* a_mind = d_mind;
         float* a_ub = nullptr;
-        double *a_sums = nullptr, *a_counts = nullptr, *a_bo = (double*)ctx->blk_dff.p, *a_bm = a_bo + ab;
-        long long* a_bi = (long long*)(a_bm + ab);
+        double *a_sums = nullptr, *a_counts = nullptr, *a_bo = (double*)ctx->blk_dff.p, *a_bm = a_bo + max_items;
+        long long* a_bi = (long long*)(a_bm + max_items);
         void* args[] = {&a_rec, &a_R, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s,
                         &a_mind, &a_ub, &a_sums, &a_counts, &a_bo, &a_bm, &a_bi};
         HIP_TRY(hipLaunchKernel(k3, dim3(ab), dim3(threads), args, lds3, ctx->stream));
@@ -1451,6 +1519,21 @@ extern "C" int spkm_distances_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K
     if (s->n == 0) return SPKM_OK;
     return s->ir_bits == 16 ? run_distances<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind)
                             : run_distances<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind);
+}
+
+extern "C" int spkm_exact_pass_points(spkm_ctx* ctx, int64_t info[2])
+{
+    if (!ctx || !info) return SPKM_ERR_NULL_ARG;
+    info[0] = info[1] = 0;
+    if (ctx->nlist.p) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned v[34] = {0};
+        HIP_TRY(hipMemcpy(v, ctx->nlist.p, sizeof(v), hipMemcpyDeviceToHost));
+        info[0] = (int64_t)(((unsigned long long)v[33] << 32) | v[32]);
+        info[1] = v[13];
+    }
+    return SPKM_OK;
 }
 
 extern "C" int spkm_last_screen_rounds(spkm_ctx* ctx, int64_t info[2])

@@ -429,19 +429,28 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
 //
 // delta_k (rounded up, f32) for all k; delta[K] = max (bit pattern atomicMax: the values are >= 0).
 // The reference divides each entry by gamma in f64 first: 2^-50 (|c| + |c'|)/gamma covers those roundings.
+// same != nullptr: same[k] = 1 iff centroid k is BITWISE the one of the previous call (the unchanged-cluster shortcut of
+// the exact pass, k_cluster_need)
 __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__ prev, const double* __restrict__ cur,
-                                                      int K, int p, double gamma, float* __restrict__ delta)
+                                                      int K, int p, double gamma, float* __restrict__ delta,
+                                                      int* __restrict__ same)
 {
     __shared__ double sh[3][4];
+    __shared__ int s_diff;
     const int k = blockIdx.x;
     const double g = gamma > 0.0 ? gamma : 1.0;
     double d2 = 0.0, a2 = 0.0, b2 = 0.0;
+    bool diff = false;
+    if (threadIdx.x == 0) s_diff = 0;
+    __syncthreads();
     for (int r = threadIdx.x; r < p; r += blockDim.x) {
         const double a = prev[(size_t)k * p + r], b = cur[(size_t)k * p + r];
         d2 += (b - a) * (b - a);
         a2 += a * a;
         b2 += b * b;
+        diff |= __double_as_longlong(a) != __double_as_longlong(b);
     }
+    if (diff) s_diff = 1; // (benign race: every writer stores 1)
     for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off); a2 += __shfl_down(a2, off); b2 += __shfl_down(b2, off); }
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = d2; sh[1][threadIdx.x >> 6] = a2; sh[2][threadIdx.x >> 6] = b2; }
     __syncthreads();
@@ -454,6 +463,7 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
         if (!(f >= 0.f)) f = __builtin_inff(); // NaN centres: nothing is skipped
         delta[k] = f;
         atomicMax(reinterpret_cast<unsigned*>(delta + K), __builtin_bit_cast(unsigned, f));
+        if (same) same[k] = s_diff ? 0 : 1;
     }
 }
 
@@ -705,12 +715,106 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
 }
 
 // dst = src / dst = 0 unless *gate == 0 (gate == nullptr: always)
+// touched != nullptr (dst then holds the previous call's assignment): touched[k] = 1 for every cluster a point left
+// or entered -- the FINAL assignment of this call against the final one of the previous call
 __global__ __launch_bounds__(256) void k_copy_i32_gated(int* __restrict__ dst, const int* __restrict__ src, long long n,
-                                                        const unsigned* __restrict__ gate)
+                                                        const unsigned* __restrict__ gate, int* __restrict__ touched, int K)
 {
     if (gate != nullptr && *gate == 0u) return;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int a = src[i];
+        if (touched) {
+            const int o = dst[i];
+            if (o != a) {
+                if ((unsigned)o < (unsigned)K) touched[o] = 1;
+                if ((unsigned)a < (unsigned)K) touched[a] = 1;
+            }
+        }
+        dst[i] = a;
+    }
+}
+
+// Unchanged-cluster shortcut of the exact pass.  Cluster k needs no work in this call when (i) its centroid is bitwise
+// the one the previous call was given (same[k], k_center_drift) and (ii) no point left or entered it (touched[k] == 0,
+// k_copy_i32_gated): every member's distance to it, the library's upper bounds, the per-cluster sums and counts, obj2
+// and the largest distance are then exactly what the previous call produced, and they are reused (k_cluster_restore,
+// k_cluster_stats) instead of streamed again.  force != 0: everything is processed (first call of a shard, changed K or
+// gamma, distances requested).  need[k] = 1: process.  counters[32..33]: running total of the points processed.
+__global__ void k_cluster_need(const int* __restrict__ touched, const int* __restrict__ same, int force, int K,
+                               const unsigned long long* __restrict__ nk, int* __restrict__ need,
+                               unsigned* __restrict__ counters)
+{
+    __shared__ unsigned long long s_pts;
+    if (threadIdx.x == 0) s_pts = 0ull;
+    __syncthreads();
+    unsigned long long mine = 0ull;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int nd = (force || touched[k] || !same[k]) ? 1 : 0;
+        need[k] = nd;
+        if (nd) mine += nk[k];
+    }
+    if (mine) atomicAdd(&s_pts, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(counters + 32), s_pts);
+        counters[13] = (unsigned)(s_pts > 0xffffffffull ? 0xffffffffull : s_pts); // points the exact pass processes in this call
+    }
+}
+
+// after the exact pass: clusters that were processed refresh the cache (their LOCAL sums / counts, before any
+// all-reduce), the others get theirs from it
+__global__ __launch_bounds__(256) void k_cluster_restore(const int* __restrict__ need, int K, int p,
+                                                         double* __restrict__ sums, double* __restrict__ counts,
+                                                         double* __restrict__ cache_s, double* __restrict__ cache_c)
+{
+    const size_t pk = (size_t)K * p;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pk; t += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(t / p);
+        if (need[k]) { cache_s[t] = sums[t]; cache_c[t] = counts[t]; }
+        else { sums[t] = cache_s[t]; counts[t] = cache_c[t]; }
+    }
+}
+
+// per-cluster statistics from the per-item ones of the processed clusters (items of a cluster are consecutive:
+// ibeg[k], icnt[k] from k_plan_segments), cached for the others; then stats = { sum obj2, max distance, its first index }
+__global__ __launch_bounds__(256) void k_cluster_stats(const int* __restrict__ need, int K, const int* __restrict__ ibeg,
+                                                       const int* __restrict__ icnt, const double* __restrict__ it_obj,
+                                                       const double* __restrict__ it_max,
+                                                       const long long* __restrict__ it_imax, double* __restrict__ cl_obj,
+                                                       double* __restrict__ cl_max, long long* __restrict__ cl_imax,
+                                                       double* __restrict__ stats)
+{
+    __shared__ double s_o[256], s_m[256];
+    __shared__ long long s_i[256];
+    const int tid = threadIdx.x;
+    double o = 0.0, m = -1.0;
+    long long im = 0x7fffffffffffffffLL;
+    for (int k = tid; k < K; k += 256) {
+        if (need[k]) {
+            double ko = 0.0, km = -1.0;
+            long long ki = 0x7fffffffffffffffLL;
+            for (int t = ibeg[k]; t < ibeg[k] + icnt[k]; t++) {
+                ko += it_obj[t];
+                if (it_max[t] > km || (it_max[t] == km && it_imax[t] < ki)) { km = it_max[t]; ki = it_imax[t]; }
+            }
+            cl_obj[k] = ko; cl_max[k] = km; cl_imax[k] = ki;
+        }
+        o += cl_obj[k];
+        if (cl_max[k] > m || (cl_max[k] == m && cl_imax[k] < im)) { m = cl_max[k]; im = cl_imax[k]; }
+    }
+    s_o[tid] = o; s_m[tid] = m; s_i[tid] = im;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            s_o[tid] += s_o[tid + off];
+            if (s_m[tid + off] > s_m[tid] || (s_m[tid + off] == s_m[tid] && s_i[tid + off] < s_i[tid])) {
+                s_m[tid] = s_m[tid + off];
+                s_i[tid] = s_i[tid + off];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { stats[0] = s_o[0]; stats[1] = s_m[0]; stats[2] = (double)s_i[0]; }
 }
 __global__ void k_zero_u64_gated(unsigned long long* __restrict__ dst, int n, const unsigned* __restrict__ gate)
 {
@@ -1132,8 +1236,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     const char* __restrict__ rec, int R, const int* __restrict__ perm, const long long* __restrict__ offs,
     const int4* __restrict__ items, const int* __restrict__ nitems, const double* __restrict__ C, double gamma, int p,
     int fixed_s, double* __restrict__ mind, float* __restrict__ ubv, double* __restrict__ sums,
-    double* __restrict__ counts, double* __restrict__ blk_obj2, double* __restrict__ blk_max,
-    long long* __restrict__ blk_imax)
+    double* __restrict__ counts, double* __restrict__ it_obj2, double* __restrict__ it_max,
+    long long* __restrict__ it_imax) // per work ITEM: sum of squared distances, largest distance, its first point index
 {
     constexpr int P = 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1257,7 +1361,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             }
             __builtin_amdgcn_wave_barrier();
         }
+        // this item's statistics: wave -> LDS here, combined by thread 0 behind the barrier the flush needs anyway
+        for (int off = 32; off > 0; off >>= 1) {
+            obj2 += __shfl_down(obj2, off);
+            const double om = __shfl_down(dmax, off);
+            const long long oi = __shfl_down(imax, off);
+            if (om > dmax || (om == dmax && oi < imax)) { dmax = om; imax = oi; }
+        }
+        if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
+        obj2 = 0.0; dmax = -1.0; imax = 0x7fffffffffffffffLL;
         __syncthreads();
+        if (tid == 0) {
+            double o = 0.0, m = -1.0;
+            long long im = 0x7fffffffffffffffLL;
+            for (int w = 0; w < nwaves; w++) {
+                o += s_obj[w];
+                if (s_max[w] > m || (s_max[w] == m && s_imax[w] < im)) { m = s_max[w]; im = s_imax[w]; }
+            }
+            it_obj2[item] = o;
+            it_max[item] = m;
+            it_imax[item] = im;
+        }
         for (int r = tid; r < p; r += blockDim.x) {
             const unsigned int c = scnt[r];
             if (c) {
@@ -1266,25 +1390,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             }
         }
         __syncthreads();
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        obj2 += __shfl_down(obj2, off);
-        const double om = __shfl_down(dmax, off);
-        const long long oi = __shfl_down(imax, off);
-        if (om > dmax || (om == dmax && oi < imax)) { dmax = om; imax = oi; }
-    }
-    if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
-    __syncthreads();
-    if (tid == 0) {
-        double o = 0.0, m = -1.0;
-        long long im = 0x7fffffffffffffffLL;
-        for (int w = 0; w < nwaves; w++) {
-            o += s_obj[w];
-            if (s_max[w] > m || (s_max[w] == m && s_imax[w] < im)) { m = s_max[w]; im = s_imax[w]; }
-        }
-        blk_obj2[blockIdx.x] = o;
-        blk_max[blockIdx.x] = m;
-        blk_imax[blockIdx.x] = im;
     }
 }
 

@@ -121,6 +121,28 @@ __global__ void k_reduce_stats(const double* __restrict__ blk_obj2, const double
     if (lane == 0) { stats[0] = o; stats[1] = m; stats[2] = (double)im; }
 }
 
+// the same over a number of entries that lives on the device (the work items the plan emitted)
+__global__ void k_reduce_stats_n(const double* __restrict__ blk_obj2, const double* __restrict__ blk_max,
+                                 const long long* __restrict__ blk_imax, const int* __restrict__ nblk_dev,
+                                 double* __restrict__ stats)
+{
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, nblk = *nblk_dev;
+    double o = 0.0, m = -1.0;
+    long long im = 0x7fffffffffffffffLL;
+    for (int b = lane; b < nblk; b += 64) {
+        o += blk_obj2[b];
+        if (blk_max[b] > m || (blk_max[b] == m && blk_imax[b] < im)) { m = blk_max[b]; im = blk_imax[b]; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        o += __shfl_down(o, off);
+        const double om = __shfl_down(m, off);
+        const long long oi = __shfl_down(im, off);
+        if (om > m || (om == m && oi < im)) { m = om; im = oi; }
+    }
+    if (lane == 0) { stats[0] = o; stats[1] = m; stats[2] = (double)im; }
+}
+
 // Fallback accumulation straight into the global p x K tables with f64 hardware atomics
 // (used when the per-cluster LDS slab of the sorted path does not fit).  One wave per point.
 template <typename IR>
@@ -152,7 +174,9 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
                                                        long long* __restrict__ offs,
                                                        unsigned long long* __restrict__ cursor,
                                                        int4* __restrict__ items, int* __restrict__ nitems,
-                                                       const unsigned* __restrict__ gate)
+                                                       const unsigned* __restrict__ gate,
+                                                       const int* __restrict__ need = nullptr,  // items only for need[k] != 0
+                                                       int* __restrict__ ibeg = nullptr, int* __restrict__ icnt = nullptr)
 {
     __shared__ long long s_pts[256];
     if (gate != nullptr && *gate == 0u) return; // nothing changed: the previous plan stands (see k_hist)
@@ -165,7 +189,7 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
     for (int k0 = 0; k0 < K; k0 += 256) {
         const int k = k0 + tid;
         const long long cnt = (k < K) ? (long long)nk[k] : 0;
-        const int nseg = (int)((cnt + seg - 1) / seg);
+        const int nseg = (k < K && need != nullptr && !need[k]) ? 0 : (int)((cnt + seg - 1) / seg);
         s_pts[tid] = cnt;
         s_items[tid] = nseg;
         __syncthreads();
@@ -183,6 +207,7 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
         if (k < K) {
             offs[k] = pbase;
             cursor[k] = (unsigned long long)pbase;
+            if (ibeg) { ibeg[k] = ibase; icnt[k] = nseg; }
             for (int s = 0; s < nseg; s++) {
                 const long long st = (long long)s * seg;
                 const long long len = (cnt - st < seg) ? cnt - st : seg;

@@ -209,6 +209,13 @@ class LloydEngine:
         _lib.check(_lib.lib().spkm_last_path_info(self.ctx.handle, a))
         return int(a[0]), int(a[1])
 
+    def exact_pass_points(self) -> tuple[int, int]:
+        """(running total of the points the exact pass streamed on this context, points it streamed in the last call):
+        fewer than n once clusters are settled (spkm_exact_pass_points)."""
+        a = (C.c_int64 * 2)()
+        _lib.check(_lib.lib().spkm_exact_pass_points(self.ctx.handle, a))
+        return int(a[0]), int(a[1])
+
     def last_screen_rounds(self) -> tuple[int, int]:
         """(rounds evaluated for all centroids, rounds per column) of the last screen call; the first is smaller
         when the two-phase screen was used (spkm_last_screen_rounds)."""

@@ -504,3 +504,60 @@ def test_point_granular_bounds_list_on_data_in_arbitrary_order(gpu_ctx, oracle, 
     if n >= 4099:
         assert 2 in seen[False], seen                                # the point list was used ...
     assert 2 not in seen[True], seen                                 # ... and not when switched off
+
+
+def test_unchanged_clusters_are_not_streamed_again_and_outputs_stay_exact(gpu_ctx, oracle, monkeypatch):
+    """The exact pass skips clusters whose centroid is bitwise unchanged and that no point left or entered
+    (spkm_exact_pass_points tells how many points it streamed).  A free-running loop converges: from then on nothing is
+    streamed; then one centroid is nudged: its cluster (and whatever its points do) is streamed again, the rest is not.
+    Every call: assignments = oracle, the distances on demand = oracle, sums / counts / obj2 as the all-processing run."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 256, 30000, 12, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=3, noise=0.2)
+    rng = np.random.default_rng(5)
+    d = np.sign(rng.standard_normal(p))
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), synth.small_p_of(gopt, p), rng)
+    gam = synth.small_p_of(gopt, p) / p
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    C0 = oracle.mix(X[:, rng.choice(n, K, replace=False)], d, p)
+    eng = LloydEngine(shard, K, gam)
+    c = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
+    streamed = []
+    nudged = False
+    for it in range(30):
+        used = c.clone()
+        eng.assign_accumulate_step(c, want_mind=False)
+        pts = eng.exact_pass_points()[1]
+        streamed.append(pts)
+        ra, rd = oracle.assign(p, n, *parts(Y), used.cpu().numpy().T, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra), it
+        # sums / counts / nk / obj2 of the call against the oracle's accumulation of the same assignment
+        S, Cnt, nk = oracle.accumulate(p, n, K, *parts(Y), ra)
+        pk = p * K
+        red = eng.reduce.cpu().numpy()
+        assert np.array_equal(red[pk:2 * pk].reshape(K, p).T, Cnt), it
+        assert np.array_equal(red[2 * pk:2 * pk + K], nk.astype(np.float64)), it
+        assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-11 * max(np.abs(S).max(), 1.0), it
+        assert abs(red[-1] - np.sum(rd * rd)) <= 1e-11 * np.sum(rd * rd), it
+        st = eng.stats.cpu().numpy()
+        assert st[1] == rd.max() and int(st[2]) == int(np.argmax(rd)), it
+        assert np.array_equal(eng.distances(used).cpu().numpy(), rd), it          # on demand, all clusters
+        eng.allreduce_step()
+        eng.finalize_step(c)
+        if it >= 6 and streamed[-1] == 0 and not nudged:
+            c[3] += 1e-3                                                          # one centroid moves a little
+            nudged = True
+            nk3 = int(nk[3])
+        elif nudged and len(streamed) >= 2 and streamed[-2] == 0 and pts > 0:
+            assert pts < n // 2 and pts >= nk3 - 50, (pts, nk3)                   # its cluster again, hardly more
+    assert nudged and streamed[0] == n and 0 in streamed, streamed
+    # the A/B switch streams everything every time and gives the same outputs
+    monkeypatch.setenv("SPKM_NO_CLUSTER_SKIP", "1")
+    shard.reset_policy()
+    eng2 = LloydEngine(shard, K, gam)
+    c2 = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
+    for it in range(8):
+        eng2.iterate(c2, want_mind=False)
+        assert eng2.exact_pass_points()[1] == n
