@@ -1241,7 +1241,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
                        ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p, gate);
     if (cl_on)
-        hipLaunchKernelGGL(k_cluster_need, dim3(1), dim3(256), 0, ctx->stream, (const int*)cl_touched, (const int*)cl_same,
+        hipLaunchKernelGGL(k_cluster_need, dim3(1), dim3(256), 0, ctx->stream, cl_touched, (const int*)cl_same,
                            cl_skip ? 0 : 1, K, (const unsigned long long*)ctx->nk.p, cl_need, (unsigned*)ctx->nlist.p);
     // (with the shortcut on the plan is never gated: which clusters need work changes even when no assignment does)
     hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
@@ -1325,7 +1325,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         double* cl_max = cl_obj + K;
         long long* cl_imax = reinterpret_cast<long long*>(cl_max + K);
         hipLaunchKernelGGL(k_cluster_restore, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
-                           (const int*)cl_need, K, p, sums, counts, cache_s, cache_c);
+                           (const int*)cl_touched /* = fresh, after k_cluster_need */, K, p, sums, counts, cache_s, cache_c);
         hipLaunchKernelGGL(k_cluster_stats, dim3(1), dim3(256), 0, ctx->stream, (const int*)cl_need, K, (const int*)cl_ibeg,
                            (const int*)cl_icnt, (const double*)ctx->blk_obj.p, (const double*)ctx->blk_max.p,
                            (const long long*)ctx->blk_imax.p, cl_obj, cl_max, cl_imax, (double*)ctx->stats.p);

@@ -740,7 +740,12 @@ __global__ __launch_bounds__(256) void k_copy_i32_gated(int* __restrict__ dst, c
 // and the largest distance are then exactly what the previous call produced, and they are reused (k_cluster_restore,
 // k_cluster_stats) instead of streamed again.  force != 0: everything is processed (first call of a shard, changed K or
 // gamma, distances requested).  need[k] = 1: process.  counters[32..33]: running total of the points processed.
-__global__ void k_cluster_need(const int* __restrict__ touched, const int* __restrict__ same, int force, int K,
+// The sums and counts of a cluster depend on its MEMBERS only: they are taken from the cache whenever no point left or
+// entered (touched[k] == 0), also when the cluster is streamed again because its centroid moved -- what the pass adds up
+// for it then is discarded (k_cluster_restore).  That is what lets a settled cluster's centroid become bitwise stable in
+// the first place: sums recomputed by atomics in no fixed order would differ in the last bit from call to call, and so
+// would the centroid.  On return touched[k] = 1 marks the clusters whose freshly accumulated sums are the ones to keep.
+__global__ void k_cluster_need(int* __restrict__ touched, const int* __restrict__ same, int force, int K,
                                const unsigned long long* __restrict__ nk, int* __restrict__ need,
                                unsigned* __restrict__ counters)
 {
@@ -749,8 +754,10 @@ __global__ void k_cluster_need(const int* __restrict__ touched, const int* __res
     __syncthreads();
     unsigned long long mine = 0ull;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const int nd = (force || touched[k] || !same[k]) ? 1 : 0;
+        const int fresh = (force || touched[k]) ? 1 : 0;
+        const int nd = (fresh || !same[k]) ? 1 : 0;
         need[k] = nd;
+        touched[k] = fresh;
         if (nd) mine += nk[k];
     }
     if (mine) atomicAdd(&s_pts, mine);
@@ -761,8 +768,8 @@ __global__ void k_cluster_need(const int* __restrict__ touched, const int* __res
     }
 }
 
-// after the exact pass: clusters that were processed refresh the cache (their LOCAL sums / counts, before any
-// all-reduce), the others get theirs from it
+// after the exact pass: clusters whose membership changed (fresh[k], k_cluster_need) refresh the cache with their LOCAL
+// sums / counts (before any all-reduce), all others get theirs from it
 __global__ __launch_bounds__(256) void k_cluster_restore(const int* __restrict__ need, int K, int p,
                                                          double* __restrict__ sums, double* __restrict__ counts,
                                                          double* __restrict__ cache_s, double* __restrict__ cache_c)
