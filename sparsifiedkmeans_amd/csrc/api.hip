@@ -51,6 +51,7 @@ struct spkm_ctx {
     // counting sort kept from the last screen call (perm / offs / items / nitems / nk describe THAT call's assignment):
     // whose shard and shape it was; cleared by everything else that writes those buffers
     const void* sort_owner = nullptr;
+    bool sort_partial = false; // the kept permutation covers only the clusters the last exact pass had to stream
     int sort_K = 0, sort_seg = 0;
     long long sort_n = 0;
     bool tlog_both = false; // fused screen path: log the exact accumulation kernel too (pairs alternate)
@@ -1226,20 +1227,26 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     int* cl_same = cl_on ? sm->cl_flags + 2 * K : nullptr;
     int* cl_ibeg = cl_on ? sm->cl_flags + 3 * K : nullptr;
     int* cl_icnt = cl_on ? sm->cl_flags + 4 * K : nullptr;
-    const bool reuse = quad && bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n &&
-                       ctx->sort_seg == seg && !getenv("SPKM_NO_SORT_REUSE");
+    // the context's sort buffers / cluster sizes still describe this shard's previous screen call
+    const bool kept = quad && bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n;
+    const bool reuse = kept && ctx->sort_seg == seg && !ctx->sort_partial && !getenv("SPKM_NO_SORT_REUSE");
     const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
+    // cluster sizes: updated by the points that moved (k_copy_i32_gated compares the new assignment with the library's
+    // copy of the previous one anyway) instead of a histogram over all points; SPKM_NO_SORT_REUSE=1 recounts
+    const bool nk_incr = kept && !getenv("SPKM_NO_SORT_REUSE");
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     if (cl_on) HIP_TRY(hipMemsetAsync(cl_touched, 0, (size_t)K * 4, ctx->stream));
     if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls); marks the
               // clusters a point left or entered on the way
-        hipLaunchKernelGGL(k_copy_i32_gated, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0,
-                           ctx->stream, (int*)(sm->hb + 2 * npad), (const int*)d_assign, n, gate,
-                           cl_skip ? cl_touched : (int*)nullptr, K);
-    hipLaunchKernelGGL(k_zero_u64_gated, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
-                       (unsigned long long*)ctx->nk.p, K, gate);
-    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
-                       ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p, gate);
+        hipLaunchKernelGGL(k_copy_i32_gated, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256),
+                           nk_incr ? (size_t)K * 4 : 0, ctx->stream, (int*)(sm->hb + 2 * npad), (const int*)d_assign, n, gate,
+                           cl_skip ? cl_touched : (int*)nullptr, K, nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr);
+    if (!nk_incr) {
+        hipLaunchKernelGGL(k_zero_u64_gated, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                           (unsigned long long*)ctx->nk.p, K, gate);
+        hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
+                           ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->nk.p, gate);
+    }
     if (cl_on)
         hipLaunchKernelGGL(k_cluster_need, dim3(1), dim3(256), 0, ctx->stream, cl_touched, (const int*)cl_same,
                            cl_skip ? 0 : 1, K, (const unsigned long long*)ctx->nk.p, cl_need, (unsigned*)ctx->nlist.p);
@@ -1249,8 +1256,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (int*)ctx->nitems.p, cl_on ? (const unsigned*)nullptr : gate, (const int*)cl_need, cl_ibeg, cl_icnt);
     const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+    // (with the shortcut on the scatter is never gated either -- a cluster may need its part of the permutation again
+    //  without any assignment having changed -- and places only the points of clusters that will be streamed)
     hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
-                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate);
+                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, cl_on ? (const unsigned*)nullptr : gate,
+                       cl_skip ? (const int*)cl_need : (const int*)nullptr);
+    ctx->sort_partial = cl_skip;
     if (quad) {
         ctx->sort_owner = sm;
         ctx->sort_K = K;
@@ -1482,6 +1493,13 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
         hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
                            ctx->sort_seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
                            (int*)ctx->nitems.p, (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+        if (ctx->sort_partial) { // ... and so may the kept permutation: place every point again
+            const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
+            const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+            hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
+                               (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, (const unsigned*)nullptr, (const int*)nullptr);
+            ctx->sort_partial = false;
+        }
         if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(max_items, FIN_BLOCKS_MAX) * 24))) return rc; // scratch for the per-item statistics
         const char* a_rec = s->rec;
         int a_R = s->rec_R, a_p = p, a_s = s->fixed_s;

@@ -717,20 +717,44 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
 // dst = src / dst = 0 unless *gate == 0 (gate == nullptr: always)
 // touched != nullptr (dst then holds the previous call's assignment): touched[k] = 1 for every cluster a point left
 // or entered -- the FINAL assignment of this call against the final one of the previous call
+// nk != nullptr: the cluster sizes of the previous call are updated in place by the points that moved (exact:
+// integers), instead of a histogram over all points
 __global__ __launch_bounds__(256) void k_copy_i32_gated(int* __restrict__ dst, const int* __restrict__ src, long long n,
-                                                        const unsigned* __restrict__ gate, int* __restrict__ touched, int K)
+                                                        const unsigned* __restrict__ gate, int* __restrict__ touched, int K,
+                                                        unsigned long long* __restrict__ nk)
 {
+    // (launched with K ints of dynamic LDS when nk != nullptr: the size changes are collected per workgroup -- half the
+    //  points move in the first iterations of a run, and 1e8 global atomics on K addresses would take 100 ms)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* delta = reinterpret_cast<int*>(smem);
     if (gate != nullptr && *gate == 0u) return;
+    if (nk) {
+        for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
+        __syncthreads();
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int a = src[i];
-        if (touched) {
+        if (touched || nk) {
             const int o = dst[i];
             if (o != a) {
-                if ((unsigned)o < (unsigned)K) touched[o] = 1;
-                if ((unsigned)a < (unsigned)K) touched[a] = 1;
+                const bool vo = (unsigned)o < (unsigned)K, va = (unsigned)a < (unsigned)K;
+                if (touched) {
+                    if (vo) touched[o] = 1;
+                    if (va) touched[a] = 1;
+                }
+                if (nk) {
+                    if (vo) atomicAdd(&delta[o], -1);
+                    if (va) atomicAdd(&delta[a], 1);
+                }
+                dst[i] = a;
             }
-        }
-        dst[i] = a;
+        } else
+            dst[i] = a;
+    }
+    if (nk) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += blockDim.x)
+            if (delta[k]) atomicAdd(&nk[k], (unsigned long long)(long long)delta[k]); // (two's complement: adds a negative delta too)
     }
 }
 

@@ -224,8 +224,11 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
 // perm[cursor[assign[i]]++] = i, with one global atomic per (block, cluster) via an LDS histogram.
 __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restrict__ assign, long long n, int K,
                                                             unsigned long long* __restrict__ cursor,
-                                                            int* __restrict__ perm, const unsigned* __restrict__ gate)
+                                                            int* __restrict__ perm, const unsigned* __restrict__ gate,
+                                                            const int* __restrict__ need = nullptr)
 {
+    // need != nullptr: only the points of clusters with need[k] != 0 are placed (the exact pass will not read the
+    // others' part of the permutation: screen.hip, k_cluster_need); the rest of perm[] is then stale
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gate != nullptr && *gate == 0u) return; // nothing changed: the previous permutation stands (see k_hist)
     unsigned int* cnt = reinterpret_cast<unsigned int*>(smem);             // K
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
     // hold the same k, one lane adds the wave's population and the lanes take consecutive ranks.
     for (long long i = lo + tid; i < hi; i += blockDim.x) {
         const int k = assign[i];
+        if (need != nullptr && !need[k]) continue;
         const unsigned long long act = __ballot(1);
         const int k0 = __builtin_amdgcn_readfirstlane(k);
         if (__ballot(k == k0) == act) {
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
     __syncthreads();
     for (long long i = lo + tid; i < hi; i += blockDim.x) {
         const int k = assign[i];
+        if (need != nullptr && !need[k]) continue;
         const unsigned long long act = __ballot(1);
         const int k0 = __builtin_amdgcn_readfirstlane(k);
         unsigned int r;
