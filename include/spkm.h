@@ -197,7 +197,7 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * (a narrow screen tile over the 8 largest movers; opt-in with SPKM_JUMPERS=1); info[7] = 1 if that tile ran, 2 if the
  * bounds were applied point by point (the list then names points; info[4] still counts the steps whose 16 points all
  * passed): the library switches to that form when the previous call's test passed >= 90 % of the points and whole
- * steps would leave many more points on the screen than failed, so that data in arbitrary order -- where a 16-point
+ * steps would leave several times as many points on the screen as failed, so that data in arbitrary order -- where a 16-point
  * step is rarely settled as a whole -- skips as much as cluster-contiguous data does.
  * Blocks on the stream. */
 int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[8]);

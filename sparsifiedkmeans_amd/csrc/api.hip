@@ -116,6 +116,8 @@ struct spkm_shard {
     bool j_on = true;          // explicit bounds for the largest movers (k_pick_jumpers): on until the plain test suffices
     // unchanged-cluster shortcut of the exact pass (screen.hip, k_cluster_need): per-cluster cache of the LOCAL sums and
     // counts (2 p K doubles), obj2 / max distance / its index (3 K), flags need | touched | same | ibeg | icnt (5 K ints)
+    double* hb_cum = nullptr;  // [2]: drift accumulated since the lower bounds were stored (screen.hip, k_bounds_steps), by call parity
+    int cum_par = 0;
     double* cl_cache = nullptr;
     int* cl_flags = nullptr;
     size_t cl_pk = 0;
@@ -374,6 +376,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xf) (void)hipFree(s->xf);
     if (s->xfs) (void)hipFree(s->xfs);
     if (s->rec) (void)hipFree(s->rec);
+    if (s->hb_cum) (void)hipFree(s->hb_cum);
     if (s->cl_cache) (void)hipFree(s->cl_cache);
     if (s->cl_flags) (void)hipFree(s->cl_flags);
     if (s->irs) (void)hipFree(s->irs);
@@ -1008,6 +1011,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
+    const double* cum_prev_p = nullptr; // accumulated drift before this call's bounds test (only set when it ran)
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
     bool skipping = false, jumpers = false, hinted = false, pt_mode = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
@@ -1026,6 +1030,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             sm->hb_centers_len = pk;
         }
         bounds_ok = sm->hb_valid && sm->hb_K == K && sm->hb_gamma == gamma;
+        if (!sm->hb_cum) HIP_TRY(hipMalloc((void**)&sm->hb_cum, 16));
+        if (!bounds_ok) { // every lower bound is written afresh by this call: the accumulated drift starts over
+            HIP_TRY(hipMemsetAsync(sm->hb_cum, 0, 16, ctx->stream));
+            sm->cum_par = 0;
+        }
         // hinted two-phase form: needs the carried bounds (the hints are ub + drift) and a split that saves rounds
         hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds;
         if (hinted) {
@@ -1060,11 +1069,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             // settle the steps (points) the bounds certify, list the others for the screen; write the hints
             if ((rc = ensure(ctx, ctx->todo, pt_mode ? (size_t)(npad + 64) * 4 : (size_t)(npad / 16 + 1) * 4))) return rc;
             const long long span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
-            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)((npad + span - 1) / span)), dim3(256), 0,
+            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, 4096)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
                                (getenv("SPKM_HINT_W") ? (float)atof(getenv("SPKM_HINT_W")) : 2.0f) * (float)s->fixed_s / (float)p,
-                               pt_mode ? 1 : 0);
+                               pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1));
+            if (skip_enabled) { cum_prev_p = sm->hb_cum + sm->cum_par; sm->cum_par ^= 1; } // the drift has been added
         }
         if (skip_enabled) {
             skipping = true;
@@ -1133,7 +1143,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             hipLaunchKernelGGL(k_bounds_steps2, dim3(2048), dim3(256), 0, ctx->stream, sm->hb, npad, n, K,
                                (const int*)ctx->todo.p, (int*)ctx->todo2.p, cn, (const float*)ctx->scr_m1.p,
                                (const double*)s->xn1, (const double*)s->xn2,
-                               (const unsigned long long*)ctx->cmax.p + 1, s->fixed_s, (int*)d_assign);
+                               (const unsigned long long*)ctx->cmax.p + 1, s->fixed_s, (int*)d_assign,
+                               cum_prev_p ? cum_prev_p : (const double*)(sm->hb_cum + sm->cum_par),
+                               (const double*)(sm->hb_cum + sm->cum_par));
             hipLaunchKernelGGL(k_commit_list, dim3(1), dim3(1), 0, ctx->stream, cn);
         }
         const float* a_t = (const float*)ctx->t32.p;
@@ -1169,7 +1181,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
-                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p), pt_mode ? 1 : 0);
+                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p), pt_mode ? 1 : 0,
+                       quad ? (const double*)(sm->hb_cum + sm->cum_par) : (const double*)nullptr);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1390,8 +1403,10 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         if (sm->skip_pending) sm->j_on = ((double)sm->h_nlist[3] - (double)sm->h_nlist[6]) < 0.5 * (nn / 16.0);
         // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed
         // (in cluster-contiguous order the failing points sit together and whole steps are as good)
+        // (entered at 4x, left below 2.5x: the two forms leave slightly different bounds behind, and a choice that flips
+        //  every call pays for both)
         sm->pt_next = sm->skip_pending && (double)sm->h_nlist[12] >= 0.9 * nn &&
-                      (std::ceil(nn / 16.0) - (double)sm->h_nlist[3]) * 16.0 > 1.5 * (nn - (double)sm->h_nlist[12]);
+                      (std::ceil(nn / 16.0) - (double)sm->h_nlist[3]) * 16.0 > (sm->pt_next ? 2.5 : 4.0) * (nn - (double)sm->h_nlist[12]);
         const int nr = (s->fixed_s + 3) / 4;
         const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
         if (sm->hint_pending) {

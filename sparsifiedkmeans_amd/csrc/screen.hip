@@ -536,8 +536,11 @@ __global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, 
                                                        unsigned* __restrict__ counters, const float* __restrict__ m1J,
                                                        const double* __restrict__ xn1, const double* __restrict__ xn2,
                                                        const unsigned long long* __restrict__ cmaxJ_bits, int fixed_s,
-                                                       int* __restrict__ assign)
+                                                       int* __restrict__ assign, const double* __restrict__ cum_in,
+                                                       const double* __restrict__ cum_out)
 {
+    // (lower bounds are stored relative to the accumulated drift: k_bounds_steps)
+    const double cum_prev = *cum_in, cum_now = *cum_out;
     constexpr int CH = 1024; // steps per workgroup pass: one global atomic each
     __shared__ int s_todo[CH];
     __shared__ unsigned s_cnt, s_pos, s_skip;
@@ -571,9 +574,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, 
                 const double E = eu * sqrt(W) * (1.0 + 1e-9);
                 const double r = sqrt((double)m1J[i]);
                 const double mj = (r - (E + gacc * r + 1e-20)) * (1.0 - nu);
-                const double lo = fmin((double)lbi - (double)rest, mj); // NaN mj: guarded below
+                const double lo = fmin(((double)lbi - cum_prev) - (double)rest, mj); // NaN mj: guarded below
                 keep = mj == mj && (double)(ubi + da) * 1.000001 < lo * 0.999999;
-                newlb = __double2float_rd(lo * (1.0 - 0x1p-20));
+                newlb = __double2float_rd(lo * (1.0 - 0x1p-20) + cum_now);
             }
             const unsigned long long b = __ballot(keep);
             const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
@@ -610,14 +613,21 @@ __global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, 
 // a 16-point step is settled only if all 16 pass: 98 % certifiable points leave 28 % of the steps on the screen;
 // point by point it is 2 %.  The host selects it from the previous call's counters (both modes count the points that
 // passed, counters[12], and the steps whose 16 points all passed, counters[3]): >= 90 % of the points passed and the
-// steps left over hold more than 1.5x as many points as failed.  The screen then fetches 16 B per quad instead of
+// steps left over hold several times as many points as failed (entered at 4x, left below 2.5x).  The screen then fetches 16 B per quad instead of
 // 256 B per wave, which only pays while few points are listed.
 __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
                                                       int* __restrict__ assign,
                                                       int* __restrict__ todo, unsigned* __restrict__ counters,
                                                       float* __restrict__ hintu, int skip_enabled, float hint_w,
-                                                      int pt_mode)
+                                                      int pt_mode, const double* __restrict__ cum_in,
+                                                      double* __restrict__ cum_out)
 {
+    // Lower bounds are stored RELATIVE to the drift accumulated so far: bnd[npad + i] = lb_i + cum at the time lb_i was
+    // certified (rounded down), cum = sum over the calls since of the largest centroid drift (each rounded up).  The
+    // bound that holds now is the stored value minus today's cum -- exactly the "lower bound moved by the largest drift"
+    // of every call in between -- so a point that passes needs NO store: the test reads 12 B per point and writes only
+    // the list (a gigabyte of stores costs as much as nine of loads on this part; the eroded bound used to be written
+    // back for every settled point in every call).  cum_out <- cum_in + this call's largest drift.
     // hintu != nullptr: every point's ESTIMATE of its distance to its previous centroid under the NEW centroids --
     // the hint of the two-phase screen (k_screen_quad), what the competition's partial sums are compared with.  Not
     // the rigorous ub + delta_a (far too pessimistic: a centroid's move is almost orthogonal to x - c, and only its
@@ -628,13 +638,18 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     __shared__ int s_todo[BOUNDS_SPAN_PT]; // >= BOUNDS_SPAN / 16
     __shared__ unsigned s_cnt, s_pos, s_skip, s_kept;
     const float dmx = bnd[3 * npad + K];
+    const double cum_now = *cum_in + (double)dmx * (1.0 + 1e-12); // NaN / inf drift: nothing passes
+    if (skip_enabled && blockIdx.x == 0 && threadIdx.x == 0) *cum_out = cum_now;
     const int lane = threadIdx.x & 63;
     unsigned nskip = 0, nkept = 0;
     if (threadIdx.x == 0) { s_cnt = 0; s_skip = 0; s_kept = 0; }
     __syncthreads();
     const int span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
-    const long long span0 = (long long)blockIdx.x * span;
     constexpr int UN = 4; // rounds whose (dependent) loads are in flight together
+    // a workgroup takes several spans: its list is flushed per span (one global atomic, none for a span that lists
+    // nothing), its statistics once at the end (at one span per workgroup the 3-4 same-address atomics of 24000
+    // workgroups took longer than the test itself)
+    for (long long span0 = (long long)blockIdx.x * span; span0 < npad; span0 += (long long)gridDim.x * span) {
     for (int it0 = 0; it0 < span / 256; it0 += UN) {
         if (span0 + it0 * 256 >= npad) break; // npad: whole waves
         float ubv[UN], lbv[UN], dav[UN];
@@ -649,7 +664,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) dav[u] = bnd[3 * npad + apv[u]];
-        if (hintu != nullptr) {
+        if (hintu != nullptr && !skip_enabled) { // (with the test on, only the points that stay on the screen get a hint: below)
 #pragma unroll
             for (int u = 0; u < UN; u++) {
                 const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
@@ -661,14 +676,12 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
         for (int u = 0; u < UN; u++) {
             const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
             if (span0 + (it0 + u) * 256 >= npad) break;
-            const bool keep = !(i < n) || (ubv[u] + dav[u]) * 1.000001f < (lbv[u] - dmx) * 0.999999f; // false for NaN
+            const bool keep = !(i < n) || (double)(ubv[u] + dav[u]) * 1.000001 < ((double)lbv[u] - cum_now) * 0.999999; // false for NaN
             const unsigned long long b = __ballot(keep);
             nkept += (unsigned)__popcll(__ballot(keep && i < n));
             if (pt_mode) {
-                if (keep && i < n) {
-                    assign[i] = apv[u];
-                    bnd[npad + i] = __double2float_rd(((double)lbv[u] - (double)dmx) * (1.0 - 0x1p-20));
-                }
+                if (keep && i < n) assign[i] = apv[u];
+                if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
                 const unsigned long long lm = ~b; // (lanes past n count as kept)
                 if (lm) {
                     unsigned basepos = 0;
@@ -684,10 +697,8 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
             const bool skip = grp == 0xffffu;
             const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
-            if (skip && i < n) {
-                assign[i] = apv[u];
-                bnd[npad + i] = __double2float_rd(((double)lbv[u] - (double)dmx) * (1.0 - 0x1p-20));
-            }
+            if (skip && i < n) assign[i] = apv[u];
+            if (!skip && i < n && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
             const bool lead = (lane & 15) == 0 && live_step && !skip;
             const unsigned long long lm = __ballot(lead);
             if (lm) {
@@ -699,19 +710,24 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             nskip += (unsigned)__popcll(__ballot((lane & 15) == 0 && live_step && skip));
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo[s_pos + j] = s_todo[j];
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    }
     if (lane == 0 && nskip) atomicAdd(&s_skip, nskip);
     if (lane == 0 && nkept) atomicAdd(&s_kept, nkept);
     __syncthreads();
     if (threadIdx.x == 0) {
-        s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
         if (s_kept) atomicAdd(counters + 12, s_kept); // points that passed the test (either mode)
         if (s_skip) {
             atomicAdd(counters + 3, s_skip);
             atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)s_skip); // never reset: running total
         }
     }
-    __syncthreads();
-    for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo[s_pos + j] = s_todo[j];
 }
 
 // dst = src / dst = 0 unless *gate == 0 (gate == nullptr: always)
@@ -866,8 +882,10 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         int* __restrict__ assign, int* __restrict__ list,
                                                         unsigned int* __restrict__ nlist,
                                                         float* __restrict__ bnd, long long npad, int skipping,
-                                                        const int* __restrict__ todo, int pt_mode)
+                                                        const int* __restrict__ todo, int pt_mode,
+                                                        const double* __restrict__ cum)
 {
+    const double cum_now = cum ? *cum : 0.0; // lower bounds are stored relative to the accumulated drift (k_bounds_steps)
     // nlist[5]: points whose (tentative) assignment differs from the previous call's (the library's copy in bnd)
     const int* aprev = bnd ? reinterpret_cast<const int*>(bnd + 2 * npad) : nullptr;
     bool changed = false;
@@ -904,7 +922,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         const bool certified = (bk >= 0) && ((r1 + e1) * (1.0 + nu) < (r2 - e2) * (1.0 - nu));
         assign[i] = bk >= 0 ? bk : 0;
         if (aprev && aprev[i] != (bk >= 0 ? bk : 0)) changed = true;
-        if (lbv) lbv[i] = certified ? fmaxf(0.f, __double2float_rd((r2 - e2) * (1.0 - nu))) : 0.f;
+        if (lbv) lbv[i] = __double2float_rd((certified ? fmax(0.0, (r2 - e2) * (1.0 - nu)) : 0.0) + cum_now);
         if (!certified) {
             const unsigned at = atomicAdd(nlist, 1u);
             list[at] = (int)i;
