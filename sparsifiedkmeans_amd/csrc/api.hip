@@ -832,6 +832,18 @@ extern "C" int spkm_timing_read(spkm_ctx* ctx, double* ms, int cap, int* count)
 // ------------------------------------------------------------------------------------------
 // accumulation + finalise
 // ------------------------------------------------------------------------------------------
+// counting-sort placement; reads the assignment with 16-B loads when the caller's pointer allows it
+static void launch_scatter(spkm_ctx* ctx, int sb, size_t sc_lds, const int* d_assign, long long n, int K, const unsigned* gate,
+                           const int* need)
+{
+    if (((uintptr_t)d_assign & 15) == 0)
+        hipLaunchKernelGGL(k_scatter_by_cluster<true>, dim3(sb), dim3(256), sc_lds, ctx->stream, d_assign, n, K,
+                           (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate, need);
+    else
+        hipLaunchKernelGGL(k_scatter_by_cluster<false>, dim3(sb), dim3(256), sc_lds, ctx->stream, d_assign, n, K,
+                           (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate, need);
+}
+
 static constexpr int SEG_POINTS = 2048;
 // confirmation pass: longer segments amortise the per-segment slab reset / flush (13.4 -> 12.4 ms at N = 1e8 from
 // 2048 to 8192 points) as long as every workgroup still gets >= 16 of them
@@ -873,8 +885,7 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
                                (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p, (int*)ctx->nitems.p, (const unsigned*)nullptr);
             const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
             const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
-            hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n,
-                               K, (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, (const unsigned*)nullptr);
+            launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
             const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
             if (s->ir_bits == 16)
                 hipLaunchKernelGGL((k_accumulate_sorted<unsigned short>), dim3(ab), dim3(256), slab, ctx->stream,
@@ -1271,9 +1282,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
     // (with the shortcut on the scatter is never gated either -- a cluster may need its part of the permutation again
     //  without any assignment having changed -- and places only the points of clusters that will be streamed)
-    hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
-                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, cl_on ? (const unsigned*)nullptr : gate,
-                       cl_skip ? (const int*)cl_need : (const int*)nullptr);
+    launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, cl_on ? (const unsigned*)nullptr : gate, cl_skip ? (const int*)cl_need : (const int*)nullptr);
     ctx->sort_partial = cl_skip;
     if (quad) {
         ctx->sort_owner = sm;
@@ -1511,8 +1520,7 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
         if (ctx->sort_partial) { // ... and so may the kept permutation: place every point again
             const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
             const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
-            hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
-                               (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, (const unsigned*)nullptr, (const int*)nullptr);
+            launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
             ctx->sort_partial = false;
         }
         if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(max_items, FIN_BLOCKS_MAX) * 24))) return rc; // scratch for the per-item statistics
@@ -2054,8 +2062,7 @@ extern "C" int spkm_dense_accumulate_dev(spkm_ctx* ctx, uint64_t p64, uint64_t n
                        (int*)ctx->nitems.p, (const unsigned*)nullptr);
     const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
-    hipLaunchKernelGGL(k_scatter_by_cluster, dim3(sb), dim3(256), sc_lds, ctx->stream, (const int*)d_assign, n, K,
-                       (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, (const unsigned*)nullptr);
+    launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
     hipLaunchKernelGGL(k_dense_accumulate, dim3(ab), dim3(256), 0, ctx->stream, d_X, p, (const int*)ctx->perm.p,
                        (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)ctx->nitems.p, d_sums);

@@ -222,10 +222,13 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
 }
 
 // perm[cursor[assign[i]]++] = i, with one global atomic per (block, cluster) via an LDS histogram.
+// VEC: the assignment is read four points at a time (16-B loads; the pointer must be 16-B aligned) -- two passes over
+// 4 B per point are latency bound with one 4-B load per lane in flight.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restrict__ assign, long long n, int K,
                                                             unsigned long long* __restrict__ cursor,
                                                             int* __restrict__ perm, const unsigned* __restrict__ gate,
-                                                            const int* __restrict__ need = nullptr)
+                                                            const int* __restrict__ need)
 {
     // need != nullptr: only the points of clusters with need[k] != 0 are placed (the exact pass will not read the
     // others' part of the permutation: screen.hip, k_cluster_need); the rest of perm[] is then stale
@@ -234,7 +237,9 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
     unsigned int* cnt = reinterpret_cast<unsigned int*>(smem);             // K
     unsigned long long* base = reinterpret_cast<unsigned long long*>(cnt + ((K + 1) & ~1)); // K
     const int tid = threadIdx.x;
-    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    constexpr int W = VEC ? 4 : 1;
+    long long per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + W - 1) / W * W;
     const long long lo = (long long)blockIdx.x * per;
     const long long hi = (lo + per < n) ? lo + per : n;
     for (int k = tid; k < K; k += blockDim.x) cnt[k] = 0;
@@ -242,9 +247,8 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
     // Neighbouring points very often share a cluster (any dataset stored roughly by class, and every dataset once
     // the counting sort of the previous iteration is reflected in its order): when all active lanes of a wave
     // hold the same k, one lane adds the wave's population and the lanes take consecutive ranks.
-    for (long long i = lo + tid; i < hi; i += blockDim.x) {
-        const int k = assign[i];
-        if (need != nullptr && !need[k]) continue;
+    auto count_one = [&](int k) {
+        if (need != nullptr && !need[k]) return;
         const unsigned long long act = __ballot(1);
         const int k0 = __builtin_amdgcn_readfirstlane(k);
         if (__ballot(k == k0) == act) {
@@ -252,16 +256,9 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
                 atomicAdd(&cnt[k0], (unsigned)__builtin_popcountll(act));
         } else
             atomicAdd(&cnt[k], 1u);
-    }
-    __syncthreads();
-    for (int k = tid; k < K; k += blockDim.x) {
-        base[k] = cnt[k] ? atomicAdd(&cursor[k], (unsigned long long)cnt[k]) : 0ull;
-        cnt[k] = 0;
-    }
-    __syncthreads();
-    for (long long i = lo + tid; i < hi; i += blockDim.x) {
-        const int k = assign[i];
-        if (need != nullptr && !need[k]) continue;
+    };
+    auto place_one = [&](int k, long long i) {
+        if (need != nullptr && !need[k]) return;
         const unsigned long long act = __ballot(1);
         const int k0 = __builtin_amdgcn_readfirstlane(k);
         unsigned int r;
@@ -273,6 +270,32 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
         } else
             r = atomicAdd(&cnt[k], 1u);
         perm[base[k] + r] = (int)i;
+    };
+    if constexpr (VEC) {
+        const long long hv = lo + ((hi - lo) & ~3LL); // whole groups of four
+        for (long long i = lo + 4LL * tid; i < hv; i += 4LL * blockDim.x) {
+            const int4 a = *reinterpret_cast<const int4*>(assign + i);
+            count_one(a.x); count_one(a.y); count_one(a.z); count_one(a.w);
+        }
+        for (long long i = hv + tid; i < hi; i += blockDim.x) count_one(assign[i]);
+    } else {
+        for (long long i = lo + tid; i < hi; i += blockDim.x) count_one(assign[i]);
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += blockDim.x) {
+        base[k] = cnt[k] ? atomicAdd(&cursor[k], (unsigned long long)cnt[k]) : 0ull;
+        cnt[k] = 0;
+    }
+    __syncthreads();
+    if constexpr (VEC) {
+        const long long hv = lo + ((hi - lo) & ~3LL);
+        for (long long i = lo + 4LL * tid; i < hv; i += 4LL * blockDim.x) {
+            const int4 a = *reinterpret_cast<const int4*>(assign + i);
+            place_one(a.x, i); place_one(a.y, i + 1); place_one(a.z, i + 2); place_one(a.w, i + 3);
+        }
+        for (long long i = hv + tid; i < hi; i += blockDim.x) place_one(assign[i], i);
+    } else {
+        for (long long i = lo + tid; i < hi; i += blockDim.x) place_one(assign[i], i);
     }
 }
 
