@@ -101,21 +101,47 @@ def attach_rccl(ctx: Context, group=None) -> int:
 
     if comm_size(ctx):
         return comm_size(ctx)
-    _lib.preload_rccl()
     if not (dist.is_available() and dist.is_initialized()):
         world, rank = 1, 0
     else:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def agree(ok: bool, what: str, why: str = ""):
+        """every rank learns whether ALL ranks got through a step -- a rank that cannot bind RCCL must not leave the
+        others waiting inside ncclCommInitRank"""
+        if world > 1:
+            votes = [None] * world
+            dist.all_gather_object(votes, (bool(ok), why), group=group)
+        else:
+            votes = [(bool(ok), why)]
+        bad = [(r, w) for r, (o, w) in enumerate(votes) if not o]
+        if bad:
+            raise _lib.SpkmError(_lib.ERR_COMM, f"{what} failed on rank(s) " + "; ".join(f"{r}: {w}" for r, w in bad))
+
+    # step 1 (local): RCCL can be loaded and bound here -- every rank asks for a token, only rank 0's is used
     ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-    if rank == 0:
-        _lib.check(_lib.lib().spkm_comm_unique_id(ident), "spkm_comm_unique_id")
+    why = ""
+    try:
+        _lib.preload_rccl()
+        st = _lib.lib().spkm_comm_unique_id(ident)
+        if st != 0:
+            why = _lib.lib().spkm_strerror(st).decode()
+    except Exception as e:                                      # noqa: BLE001 -- reported to every rank below
+        st, why = -1, repr(e)
+    agree(st == 0, "binding RCCL (spkm_comm_unique_id)", why)
+    # step 2 (collective): the communicator
     if world > 1:
         box = [bytes(ident)]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
     st = _lib.lib().spkm_comm_init(ctx.handle, world, rank, ident)
-    if st != 0:
-        raise _lib.SpkmError(st, "spkm_comm_init: " + _lib.lib().spkm_ctx_last_error(ctx.handle).decode())
+    why = "" if st == 0 else _lib.lib().spkm_ctx_last_error(ctx.handle).decode()
+    try:
+        agree(st == 0, "spkm_comm_init", why)
+    except _lib.SpkmError:
+        if st == 0:
+            _lib.lib().spkm_comm_destroy(ctx.handle)
+        raise
     return world
 
 

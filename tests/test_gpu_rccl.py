@@ -70,12 +70,11 @@ def test_lloyd_iter_without_a_communicator_equals_the_three_calls(gpu_ctx, oracl
         assert np.array_equal(a.assign.cpu().numpy(), ref["assign"])
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
-def test_two_ranks_over_rccl_match_one_process(tmp_path, oracle):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _check_two_ranks(tmp_path, oracle, env_extra, port, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(ROOT, "tests", "_rccl_worker.py"), str(tmp_path), "4"]
-    subprocess.run(cmd, check=True, env=env, timeout=600)
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_rccl_worker.py"), str(tmp_path), "4"]
+    subprocess.run(cmd, check=True, env=env, timeout=timeout)
     r = [np.load(tmp_path / f"rank{i}.npz") for i in range(2)]
     p, n, K, s = 256, 20000, 12, 16
     X = random_csc(p, n, s, seed=77)
@@ -87,3 +86,15 @@ def test_two_ranks_over_rccl_match_one_process(tmp_path, oracle):
     assert np.array_equal(assign, ref["assign"])
     assert np.abs(r[0]["centers"].T - ref["centers"]).max() <= 1e-9 * np.abs(ref["centers"]).max()
     assert np.allclose(np.sqrt(r[0]["hist"][:, 1]), ref["obj"], rtol=1e-9)   # obj2 is a global sum
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_two_ranks_over_rccl_match_one_process(tmp_path, oracle):
+    _check_two_ranks(tmp_path, oracle, {}, 29531)
+
+
+def test_communicator_that_cannot_form_fails_on_every_rank_and_the_loop_falls_back(tmp_path, oracle):
+    """Two ranks on ONE device: RCCL refuses the communicator.  Every rank must come back with SPKM_ERR_COMM (no rank
+    left waiting in ncclCommInitRank), nothing stays attached and LloydEngine.iterate exchanges through
+    torch.distributed (gloo here) -- same answers as one process."""
+    _check_two_ranks(tmp_path, oracle, {"SPKM_TEST_ONE_DEVICE": "1", "SPKM_TEST_BACKEND": "gloo"}, 29533, timeout=240)
