@@ -836,6 +836,10 @@ extern "C" int spkm_timing_read(spkm_ctx* ctx, double* ms, int cap, int* count)
 static void launch_scatter(spkm_ctx* ctx, int sb, size_t sc_lds, const int* d_assign, long long n, int K, const unsigned* gate,
                            const int* need)
 {
+    if (sc_lds > 48 * 1024) { // (K in the thousands: beyond the default dynamic-LDS allowance)
+        (void)allow_lds(ctx, (const void*)k_scatter_by_cluster<true>, sc_lds);
+        (void)allow_lds(ctx, (const void*)k_scatter_by_cluster<false>, sc_lds);
+    }
     if (((uintptr_t)d_assign & 15) == 0)
         hipLaunchKernelGGL(k_scatter_by_cluster<true>, dim3(sb), dim3(256), sc_lds, ctx->stream, d_assign, n, K,
                            (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate, need);
@@ -884,7 +888,7 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
                                (const unsigned long long*)ctx->nk.p, K, SEG_POINTS, (long long*)ctx->offs.p,
                                (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p, (int*)ctx->nitems.p, (const unsigned*)nullptr);
             const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
-            const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+            const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
             launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
             const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
             if (s->ir_bits == 16)
@@ -947,7 +951,8 @@ static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
 
 template <typename IR>
 static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d_centers, double gamma,
-                      int32_t* d_assign, double* d_mind, double* d_reduce, int prune_a, bool want_hint)
+                      int32_t* d_assign, double* d_mind, double* d_reduce, int prune_a, bool want_hint,
+                      double* d_stats, uint64_t* d_nk_u64)
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
@@ -1016,9 +1021,23 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->ct, pk * 8))) return rc;
     if ((rc = ensure(ctx, ctx->nk, (size_t)K * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->cmax.p, 0, 16, ctx->stream)); // [0] all tiles, [1] the jumper tile
-    HIP_TRY(hipMemsetAsync(ctx->nlist.p, 0, 32, ctx->stream));
-    HIP_TRY(hipMemsetAsync((char*)ctx->nlist.p + 40, 0, 128 - 40, ctx->stream)); // (not the running total at [8..9])
+    // everything this call needs zeroed, in one launch (flushed in front of the first kernel): the counters, the
+    // largest-drift cell, the touched flags of the cluster shortcut and the caller's reduce buffer
+    spkm_zero_jobs zj;
+    zj.n = 0;
+    auto zero_later = [&](void* q, size_t bytes) { zj.p[zj.n] = (unsigned*)q; zj.words[zj.n] = bytes / 4; zj.n++; };
+    auto zero_flush = [&]() {
+        if (!zj.n) return;
+        unsigned long long mx = 0;
+        for (int q = 0; q < zj.n; q++) mx = std::max(mx, zj.words[q]);
+        hipLaunchKernelGGL(k_zero_many, dim3((unsigned)std::min<unsigned long long>((mx + 1023) / 1024, 256)), dim3(256), 0,
+                           ctx->stream, zj);
+        zj.n = 0;
+    };
+    zero_later(ctx->cmax.p, 16);                       // [0] all tiles, [1] the jumper tile
+    zero_later(ctx->nlist.p, 32);
+    zero_later((char*)ctx->nlist.p + 40, 128 - 40);    // (not the running total at [8..9])
+    zero_later(d_reduce, (2 * pk + K + 1) * 8);
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
@@ -1072,8 +1091,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             HIP_TRY(hipMalloc((void**)&sm->cl_flags, (size_t)5 * K * 4));
             sm->cl_pk = pk; sm->cl_K = K;
         }
+        if (sm->cl_flags) zero_later(sm->cl_flags + K, (size_t)K * 4); // touched[] (k_copy_i32_gated marks, k_cluster_need reads)
         if (skip_enabled || hinted) {
-            HIP_TRY(hipMemsetAsync(sm->hb + 3 * npad + K, 0, 4, ctx->stream));
+            zero_later(sm->hb + 3 * npad + K, 4);
+            zero_flush();
             drift_ran = true;
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
                                d_centers, K, p, gamma, sm->hb + 3 * npad, sm->cl_flags + 2 * K);
@@ -1100,7 +1121,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         sm->hb_valid = false; // until this call has gone through
     } else
         sm->hb_valid = false;
-    HIP_TRY(hipMemsetAsync(d_reduce, 0, (2 * pk + K + 1) * 8, ctx->stream));
+    zero_flush();
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
                        0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
                        (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0, (const int*)nullptr);
@@ -1259,7 +1280,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // copy of the previous one anyway) instead of a histogram over all points; SPKM_NO_SORT_REUSE=1 recounts
     const bool nk_incr = kept && !getenv("SPKM_NO_SORT_REUSE");
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
-    if (cl_on) HIP_TRY(hipMemsetAsync(cl_touched, 0, (size_t)K * 4, ctx->stream));
     if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls); marks the
               // clusters a point left or entered on the way
         hipLaunchKernelGGL(k_copy_i32_gated, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256),
@@ -1279,7 +1299,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
                        (int*)ctx->nitems.p, cl_on ? (const unsigned*)nullptr : gate, (const int*)cl_need, cl_ibeg, cl_icnt);
     const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
-    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
     // (with the shortcut on the scatter is never gated either -- a cluster may need its part of the permutation again
     //  without any assignment having changed -- and places only the points of clusters that will be streamed)
     launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, cl_on ? (const unsigned*)nullptr : gate, cl_skip ? (const int*)cl_need : (const int*)nullptr);
@@ -1374,10 +1394,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
                                (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, ab, (double*)ctx->stats.p);
     }
-    hipLaunchKernelGGL(k_nk_to_f64, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
-                       (const unsigned long long*)ctx->nk.p, K, nk_f);
+    hipLaunchKernelGGL(k_call_tail, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
+                       (unsigned long long*)d_nk_u64);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(obj2, ctx->stats.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
         HIP_TRY(hipMemcpyAsync(sm->hb_centers, d_centers, pk * 8, hipMemcpyDeviceToDevice, ctx->stream));
         sm->hb_K = K;
@@ -1448,8 +1468,8 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         // (run_screen / k_bounds_steps); needs this shard's previous call to have been a screen call.
         const bool want_hint = prune_a == 0 && !getenv("SPKM_NO_PRUNE") && !getenv("SPKM_NO_HINT") &&
                                sm->hint_cooldown == 0 && screen_use_quad(s);
-        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint)
-                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint);
+        rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint, d_stats, d_nk_u64)
+                                : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint, d_stats, d_nk_u64);
         if (rc) return rc;
         ctx->last_mode = ctx->last_hinted ? 2 : (ctx->last_rounds_all < ctx->last_rounds ? 1 : 0);
         if (!sm->h_nlist) {
@@ -1464,9 +1484,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             sm->hint_pending = ctx->last_hinted;
             sm->skip_pending = ctx->last_skipping;
         }
-        if (d_stats) HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        if (d_nk_u64) HIP_TRY(hipMemcpyAsync(d_nk_u64, ctx->nk.p, (size_t)K64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        return SPKM_OK;
+        return SPKM_OK; // (statistics and cluster sizes were handed over by run_screen's last kernel)
     }
     ctx->last_path = 0;
     sm->hb_valid = false; // the carried bounds describe the previous SCREEN call only
@@ -1519,7 +1537,7 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
                            (int*)ctx->nitems.p, (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
         if (ctx->sort_partial) { // ... and so may the kept permutation: place every point again
             const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
-            const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+            const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
             launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
             ctx->sort_partial = false;
         }
@@ -2061,7 +2079,7 @@ extern "C" int spkm_dense_accumulate_dev(spkm_ctx* ctx, uint64_t p64, uint64_t n
                        (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
                        (int*)ctx->nitems.p, (const unsigned*)nullptr);
     const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
-    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 8;
+    const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
     launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * 8);
     hipLaunchKernelGGL(k_dense_accumulate, dim3(ab), dim3(256), 0, ctx->stream, d_X, p, (const int*)ctx->perm.p,

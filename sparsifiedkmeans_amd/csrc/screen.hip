@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const unsigned long long b = __ballot(keep);
             nkept += (unsigned)__popcll(__ballot(keep && i < n));
             if (pt_mode) {
-                if (keep && i < n) assign[i] = apv[u];
+                if (keep && i < n && assign[i] != apv[u]) assign[i] = apv[u]; // (see the step mode below)
                 if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
                 const unsigned long long lm = ~b; // (lanes past n count as kept)
                 if (lm) {
@@ -697,7 +697,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
             const bool skip = grp == 0xffffu;
             const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
-            if (skip && i < n) assign[i] = apv[u];
+            // a caller that passes the same buffer call after call already holds this value: a 4-B read instead of a
+            // 4-B store (a gigabyte of stores costs as much as several of loads here)
+            if (skip && i < n && assign[i] != apv[u]) assign[i] = apv[u];
             if (!skip && i < n && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
             const bool lead = (lane & 15) == 0 && live_step && !skip;
             const unsigned long long lm = __ballot(lead);
@@ -863,6 +865,22 @@ __global__ __launch_bounds__(256) void k_cluster_stats(const int* __restrict__ n
     }
     if (tid == 0) { stats[0] = s_o[0]; stats[1] = s_m[0]; stats[2] = (double)s_i[0]; }
 }
+// several small buffers zeroed by ONE launch (the per-call counters, flags and the reduce buffer of the fused
+// iteration: six memsets were six launches in front of the first kernel that does work)
+struct spkm_zero_jobs {
+    unsigned* p[8];
+    unsigned long long words[8]; // 4-byte words
+    int n;
+};
+__global__ __launch_bounds__(256) void k_zero_many(const spkm_zero_jobs j)
+{
+    for (int q = 0; q < j.n; q++) {
+        unsigned* d = j.p[q];
+        for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < j.words[q];
+             i += (unsigned long long)gridDim.x * blockDim.x)
+            d[i] = 0u;
+    }
+}
 __global__ void k_zero_u64_gated(unsigned long long* __restrict__ dst, int n, const unsigned* __restrict__ gate)
 {
     if (gate != nullptr && *gate == 0u) return;
@@ -899,6 +917,10 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     unsigned nambig = 0;
     // skipping: k_bounds_steps has settled the skipped steps; only the listed ones (nlist[4] of them) are looked at
     const long long total = skipping ? (pt_mode ? (long long)nlist[4] : (long long)nlist[4] * 16) : n;
+    __shared__ unsigned s_amb, s_chg;
+    if ((long long)blockIdx.x * blockDim.x >= total) return; // (whole workgroup)
+    if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; }
+    __syncthreads();
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
          q += (long long)gridDim.x * blockDim.x) {
         const long long i = skipping ? (pt_mode ? (long long)todo[q] : (long long)todo[q >> 4] * 16 + (q & 15)) : q;
@@ -924,17 +946,30 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         if (aprev && aprev[i] != (bk >= 0 ? bk : 0)) changed = true;
         if (lbv) lbv[i] = __double2float_rd((certified ? fmax(0.0, (r2 - e2) * (1.0 - nu)) : 0.0) + cum_now);
         if (!certified) {
-            const unsigned at = atomicAdd(nlist, 1u);
-            list[at] = (int)i;
+            // one atomic per wave, not per point: atomics on one address are served one after the other (~12 ns each --
+            // 30 000 uncertified points of a cold iteration cost more than the rest of this kernel)
+            const unsigned long long um = __ballot(1);
+            const int ln = threadIdx.x & 63;
+            unsigned at = 0;
+            if (ln == __builtin_ctzll(um)) at = atomicAdd(nlist, (unsigned)__popcll(um));
+            at = (unsigned)__builtin_amdgcn_readlane((int)at, __builtin_ctzll(um));
+            list[at + __popcll(um & ((1ull << ln) - 1ull))] = (int)i;
         }
         // nlist[1]: points whose runner-up is within 2.25x of the winner -- the ones a partial-sum lower bound (a
         // quarter of the rounds: 5x in the squares leaves a margin) 
         // could not separate; the host decides from this count whether the next call may use the two-phase screen
         if (!(r2 >= 2.25 * r1)) nambig++;
     }
+    // per workgroup: with a short list nearly every wave holds an ambiguous point (the listed points ARE the ones near a
+    // boundary), and one atomic per wave on one address took longer than the rest of the kernel
     for (int off = 32; off > 0; off >>= 1) nambig += __shfl_down(nambig, off);
-    if ((threadIdx.x & 63) == 0 && nambig) atomicAdd(nlist + 1, nambig);
-    if (__any(changed) && (threadIdx.x & 63) == 0) atomicAdd(nlist + 5, 1u);
+    if ((threadIdx.x & 63) == 0 && nambig) atomicAdd(&s_amb, nambig);
+    if (__any(changed) && (threadIdx.x & 63) == 0) s_chg = 1u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_amb) atomicAdd(nlist + 1, s_amb);
+        if (s_chg) atomicAdd(nlist + 5, 1u);
+    }
 }
 
 // Listed points: exact reference arithmetic over all K centroids (row-major scaled centres Cs in
@@ -1726,7 +1761,9 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             }
         }
     }
-    if (counters != nullptr && lane == 0 && npruned) atomicAdd(counters + 2, npruned);
+    // (per workgroup, not per wave: 4096 waves finishing together queued 4096 atomics on one address -- ~50 us at the
+    //  end of every launch; the kernel adds ticket[1] to counters[2] behind its last barrier)
+    if (counters != nullptr && lane == 0 && npruned) atomicAdd(ticket + 1, npruned);
 }
 
 // TWO: the two-phase forms -- the first A = quad_split(NR) rounds for all centroids, the rest only for each
@@ -1762,7 +1799,7 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
         }
     }
     unsigned* ticket = reinterpret_cast<unsigned*>(smem + tile_bytes + extra_bytes);
-    if (tid == 0) *ticket = 0u;
+    if (tid == 0) { ticket[0] = 0u; ticket[1] = 0u; }
     __syncthreads();
     float* m1o = scr_m1 + (size_t)bm.tile * n;
     float* m2o = scr_m2 + (size_t)bm.tile * n;
@@ -1779,6 +1816,10 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
     else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
     else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
+    if (counters != nullptr) {
+        __syncthreads();
+        if (tid == 0 && ticket[1]) atomicAdd(counters + 2, ticket[1]);
+    }
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
