@@ -37,7 +37,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, todo2, bmapj, t32j;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, todo2, bmapj, t32j, bstat;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
@@ -232,7 +232,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->mscr, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->todo2, &ctx->bmapj, &ctx->t32j};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->todo2, &ctx->bmapj, &ctx->t32j, &ctx->bstat};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1042,6 +1042,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
     const double* cum_prev_p = nullptr; // accumulated drift before this call's bounds test (only set when it ran)
+    int bstat_n = 0; // workgroups of k_bounds_steps whose statistics wait in ctx->bstat
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
     bool skipping = false, jumpers = false, hinted = false, pt_mode = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
@@ -1100,12 +1101,20 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                                d_centers, K, p, gamma, sm->hb + 3 * npad, sm->cl_flags + 2 * K);
             // settle the steps (points) the bounds certify, list the others for the screen; write the hints
             if ((rc = ensure(ctx, ctx->todo, pt_mode ? (size_t)(npad + 64) * 4 : (size_t)(npad / 16 + 1) * 4))) return rc;
-            const long long span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
-            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, 4096)), dim3(256), 0,
+            // (small shards: shorter spans, so that the launch still has >= 8 workgroups per CU)
+            // (its statistics leave per workgroup, bstat, and are added up by the call's last kernel: same-address atomics of
+            //  a few thousand workgroups took longer than the test itself on small shards)
+            long long span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
+            const long long bgrid = 4LL * std::max(1, ctx->num_cus);
+            if ((rc = ensure(ctx, ctx->bstat, (size_t)bgrid * 8))) return rc;
+            while (span > 1024 && (npad + span - 1) / span < 4 * bgrid) span /= 2;
+            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
                                (getenv("SPKM_HINT_W") ? (float)atof(getenv("SPKM_HINT_W")) : 2.0f) * (float)s->fixed_s / (float)p,
-                               pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1));
+                               pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1),
+                               (int)span, (unsigned*)ctx->bstat.p);
+            bstat_n = (int)std::min<long long>((npad + span - 1) / span, bgrid);
             if (skip_enabled) { cum_prev_p = sm->hb_cum + sm->cum_par; sm->cum_par ^= 1; } // the drift has been added
         }
         if (skip_enabled) {
@@ -1396,7 +1405,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     }
     hipLaunchKernelGGL(k_call_tail, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
-                       (unsigned long long*)d_nk_u64);
+                       (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p);
     HIP_TRY(hipGetLastError());
     if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
         HIP_TRY(hipMemcpyAsync(sm->hb_centers, d_centers, pk * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1653,9 +1662,9 @@ extern "C" int spkm_finalize_dev(spkm_ctx* ctx, uint64_t p, uint64_t K, const do
     const int fb = (int)std::min<size_t>(FIN_BLOCKS, (pk + 255) / 256);
     hipLaunchKernelGGL(k_finalize_centers, dim3(fb), dim3(256), 0, ctx->stream, d_reduce, d_reduce + pk,
                        d_reduce + 2 * pk, (int)p, (int)K, gamma, d_centers, (double*)ctx->blk_dff.p);
-    hipLaunchKernelGGL(k_reduce_dff, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_dff.p, fb, d_out);
+    hipLaunchKernelGGL(k_reduce_dff, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_dff.p, fb, d_out,
+                       d_reduce + 2 * pk + K);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(d_out + 1, d_reduce + 2 * pk + K, 8, hipMemcpyDeviceToDevice, ctx->stream));
     return SPKM_OK;
 }
 

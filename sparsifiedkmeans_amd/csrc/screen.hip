@@ -78,8 +78,15 @@ __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int
         }
         T32[t] = v;
     }
+    // one atomic per workgroup (2000 waves on one address were most of this kernel's 20 us)
+    __shared__ double s_mx[16];
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(cmax_bits, __builtin_bit_cast(unsigned long long, mx));
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) mx = fmax(mx, s_mx[w]);
+        if (mx > 0.0) atomicMax(cmax_bits, __builtin_bit_cast(unsigned long long, mx));
+    }
 }
 
 // xn1[i] = sum_j |x_j|, xn2[i] = sum_j x_j^2 over column i (any order: used only inside an upper bound),
@@ -620,8 +627,11 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                                                       int* __restrict__ todo, unsigned* __restrict__ counters,
                                                       float* __restrict__ hintu, int skip_enabled, float hint_w,
                                                       int pt_mode, const double* __restrict__ cum_in,
-                                                      double* __restrict__ cum_out)
+                                                      double* __restrict__ cum_out, int span,
+                                                      unsigned* __restrict__ blkstat)
 {
+    // span: points per list flush (<= BOUNDS_SPAN_PT when points are listed, <= 16 BOUNDS_SPAN_PT for steps; a multiple
+    // of 1024) -- the host shortens it on small shards so that every CU still gets several workgroups
     // Lower bounds are stored RELATIVE to the drift accumulated so far: bnd[npad + i] = lb_i + cum at the time lb_i was
     // certified (rounded down), cum = sum over the calls since of the largest centroid drift (each rounded up).  The
     // bound that holds now is the stored value minus today's cum -- exactly the "lower bound moved by the largest drift"
@@ -644,7 +654,6 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     unsigned nskip = 0, nkept = 0;
     if (threadIdx.x == 0) { s_cnt = 0; s_skip = 0; s_kept = 0; }
     __syncthreads();
-    const int span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
     constexpr int UN = 4; // rounds whose (dependent) loads are in flight together
     // a workgroup takes several spans: its list is flushed per span (one global atomic, none for a span that lists
     // nothing), its statistics once at the end (at one span per workgroup the 3-4 same-address atomics of 24000
@@ -723,12 +732,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     if (lane == 0 && nskip) atomicAdd(&s_skip, nskip);
     if (lane == 0 && nkept) atomicAdd(&s_kept, nkept);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (s_kept) atomicAdd(counters + 12, s_kept); // points that passed the test (either mode)
-        if (s_skip) {
-            atomicAdd(counters + 3, s_skip);
-            atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)s_skip); // never reset: running total
-        }
+    if (threadIdx.x == 0) { // points that passed the test (either mode), steps whose 16 points all passed: k_call_tail adds them up
+        blkstat[2 * blockIdx.x] = s_kept;
+        blkstat[2 * blockIdx.x + 1] = s_skip;
     }
 }
 
@@ -995,7 +1001,16 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
         for (int k = lane; k < K; k += 64) {
             double acc = 0.0;
             long long j = j0;
-            for (; j + 4 <= j1; j += 4) { // four independent gathers in flight; the additions stay in storage order
+            for (; j + 8 <= j1; j += 8) { // eight independent gathers in flight; the additions stay in storage order
+                double c[8], d[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) c[u] = Cs[(size_t)ir[j + u] * K + k];
+#pragma unroll
+                for (int u = 0; u < 8; u++) d[u] = xval[j + u] - c[u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc = acc + d[u] * d[u];
+            }
+            for (; j + 4 <= j1; j += 4) {
                 const double c0 = Cs[(size_t)ir[j] * K + k], c1 = Cs[(size_t)ir[j + 1] * K + k],
                              c2 = Cs[(size_t)ir[j + 2] * K + k], c3 = Cs[(size_t)ir[j + 3] * K + k];
                 const double d0 = xval[j] - c0, d1 = xval[j + 1] - c1, d2 = xval[j + 2] - c2, d3 = xval[j + 3] - c3;

@@ -415,12 +415,17 @@ __global__ __launch_bounds__(256) void k_finalize_centers(const double* __restri
     }
 }
 
-__global__ void k_reduce_dff(const double* __restrict__ blk_dff2, int nblk, double* __restrict__ out_dff2)
+__global__ void k_reduce_dff(const double* __restrict__ blk_dff2, int nblk, double* __restrict__ out_dff2,
+                             const double* __restrict__ obj2)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && obj2) out_dff2[1] = *obj2; // d_out = [dff^2, obj^2]
+    // one wave, a fixed order (lane l adds blocks l, l + 64, ...; then a shuffle tree): one thread walking all the
+    // blocks took 17 us of serial load latency per iteration
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double o = 0.0;
-    for (int b = 0; b < nblk; b++) o += blk_dff2[b];
-    *out_dff2 = o;
+    for (int b = threadIdx.x; b < nblk; b += 64) o += blk_dff2[b];
+    for (int off = 32; off > 0; off >>= 1) o += __shfl_down(o, off);
+    if (threadIdx.x == 0) *out_dff2 = o;
 }
 
 // nk (u64 counters) -> f64 slots of the reduce buffer, so that one SUM all-reduce covers everything.
@@ -434,8 +439,27 @@ __global__ void k_nk_to_f64(const unsigned long long* __restrict__ nk, int K, do
 // the reduce buffer, the statistics and cluster sizes into the caller's buffers (either may be null)
 __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, double* __restrict__ nk_f,
                             const double* __restrict__ stats, double* __restrict__ obj2, double* __restrict__ d_stats,
-                            unsigned long long* __restrict__ d_nk)
+                            unsigned long long* __restrict__ d_nk, const unsigned* __restrict__ bstat, int bstat_n,
+                            unsigned* __restrict__ counters)
 {
+    // bstat: (points kept, steps skipped) per workgroup of k_bounds_steps -> counters[12], counters[3] and the running
+    // total at counters[8..9] (read by the host one call later)
+    if (blockIdx.x == 0 && bstat_n > 0) {
+        __shared__ unsigned s_k[256], s_s[256];
+        unsigned a = 0, b = 0;
+        for (int t = threadIdx.x; t < bstat_n; t += blockDim.x) { a += bstat[2 * t]; b += bstat[2 * t + 1]; }
+        s_k[threadIdx.x] = a; s_s[threadIdx.x] = b;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) { s_k[threadIdx.x] += s_k[threadIdx.x + off]; s_s[threadIdx.x] += s_s[threadIdx.x + off]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            counters[12] += s_k[0];
+            counters[3] += s_s[0];
+            *reinterpret_cast<unsigned long long*>(counters + 8) += (unsigned long long)s_s[0];
+        }
+    }
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) {
         const unsigned long long v = nk[k];
