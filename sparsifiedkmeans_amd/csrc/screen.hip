@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     for (int it0 = 0; it0 < span / 256; it0 += UN) {
         if (span0 + it0 * 256 >= npad) break; // npad: whole waves
         float ubv[UN], lbv[UN], dav[UN];
-        int apv[UN];
+        int apv[UN], curv[UN];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
@@ -670,6 +670,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             ubv[u] = in ? bnd[i] : 0.f;
             lbv[u] = in ? bnd[npad + i] : 0.f;
             apv[u] = in ? reinterpret_cast<const int*>(bnd)[2 * npad + i] : 0;
+            // what the caller's buffer holds now, fetched with the rest (behind the test it would be a second memory
+            // round trip per group): a point that keeps its assignment is stored only if the buffer differs
+            curv[u] = (in && skip_enabled) ? assign[i] : 0;
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) dav[u] = bnd[3 * npad + apv[u]];
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const unsigned long long b = __ballot(keep);
             nkept += (unsigned)__popcll(__ballot(keep && i < n));
             if (pt_mode) {
-                if (keep && i < n && assign[i] != apv[u]) assign[i] = apv[u]; // (see the step mode below)
+                if (keep && i < n && curv[u] != apv[u]) assign[i] = apv[u]; // (see the step mode below)
                 if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
                 const unsigned long long lm = ~b; // (lanes past n count as kept)
                 if (lm) {
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
             // a caller that passes the same buffer call after call already holds this value: a 4-B read instead of a
             // 4-B store (a gigabyte of stores costs as much as several of loads here)
-            if (skip && i < n && assign[i] != apv[u]) assign[i] = apv[u];
+            if (skip && i < n && curv[u] != apv[u]) assign[i] = apv[u];
             if (!skip && i < n && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
             const bool lead = (lane & 15) == 0 && live_step && !skip;
             const unsigned long long lm = __ballot(lead);
