@@ -1788,7 +1788,11 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
 // tile's leader (or, hinted, for all again when a step's points do not clear their hints).  The split is a
 // compile-time constant: with a run-time split every round sits behind its own branch and the finish's LDS reads
 // are waited for one by one.
+#ifdef SPKM_QUAD_A // experiment builds only (tools/build_variant.sh): a fixed split
+__host__ __device__ constexpr int quad_split(int nr) { return nr > SPKM_QUAD_A ? SPKM_QUAD_A : nr; }
+#else
 __host__ __device__ constexpr int quad_split(int nr) { return nr >= 3 ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : nr; }
+#endif
 
 template <int NR, typename IR, bool TWO>
 __global__ __launch_bounds__(1024) void k_screen_quad(
