@@ -58,6 +58,7 @@ struct spkm_ctx {
     int assign_KT = 0, assign_G = 0; // of the last assign call
     int last_path = 0;               // 0 = exact tiled/generic, 1 = f32 screen + exact confirmation
     unsigned last_listed = 0;        // points sent to the exact list by the last screen (read lazily)
+    bool last_hint_late = false; // the last hinted call used the late split
     int last_rounds_all = 0, last_rounds = 0; // rounds for all centroids / total rounds of the last 4-lane screen call
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
@@ -101,6 +102,8 @@ struct spkm_shard {
     float* hintu = nullptr;   // per-point hints of the two-phase screen (k_bounds_steps), npad floats
     long long hintu_len = 0;
     bool hint_pending = false;
+    bool hint_late = true, hint_late_pending = false; // which compiled split the next hinted call uses / the pending one used
+    int hint_late_left = 3;                           // hinted calls left on the late split
     int hint_cooldown = 0;
     int hint_fail_streak = 0; // consecutive hinted calls that did not pay: the pause doubles (2, 4, 8, 16 calls)
     // bounds carried between screen calls (screen.hip, k_center_drift): ub | lb | assignment | drift table, the
@@ -403,6 +406,8 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->hint_cooldown = 0;
     s->hint_fail_streak = 0;
     s->hint_pending = false;
+    s->hint_late = true; // a run starts with loose hints
+    s->hint_late_left = 3;
     s->skip_pending = false;
     s->j_on = true;
     s->pt_next = false;
@@ -1069,7 +1074,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // hinted two-phase form: needs the carried bounds (the hints are ub + drift) and a split that saves rounds
         hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds;
         if (hinted) {
-            prune_a = quad_split(q_rounds);
+            const bool late = sm->hint_late && quad_split_late(q_rounds) > quad_split(q_rounds) && !getenv("SPKM_NO_LATE_SPLIT");
+            prune_a = late ? quad_split_late(q_rounds) : quad_split(q_rounds);
+            ctx->last_hint_late = late;
+            if (sm->hint_late_left > 0) sm->hint_late_left--;
+            if (sm->hint_late_left == 0) sm->hint_late = false;
             if (sm->hintu_len < npad) {
                 if (sm->hintu) (void)hipFree(sm->hintu);
                 sm->hintu = nullptr;
@@ -1144,7 +1153,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (const char* ev = getenv("SPKM_CHUNK")) chunk = std::max<long long>(sweep, (atoll(ev) / sweep) * sweep); // tuning aid
     {
         const size_t lds = (size_t)(p + 1) * (SCREEN_KT * 4 + (pl_last == 5 ? 16 : 0)) + 16;
-        const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0) : (const void*)k_screen_tile<IR>;
+        const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0 ? prune_a : (s->fixed_s + 3) / 4) : (const void*)k_screen_tile<IR>;
         HIP_TRY(allow_lds(ctx, kern, lds));
         HIP_TRY(timing_begin(ctx));
         const IR* a_ir = quad ? (const IR*)s->irs : (const IR*)s->ir;
@@ -1164,7 +1173,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                                ctx->stream, d_centers, p, K, 1, gamma, (float*)ctx->t32j.p,
                                (unsigned long long*)ctx->cmax.p + 1, 1, 1, (const int*)(dl + K + 2));
             if ((rc = build_blockmap_quad(ctx, 1, 1, q_rounds, true))) return rc;
-            const void* kj = screen_quad_kernel<IR>(q_rounds, false);
+            const void* kj = screen_quad_kernel<IR>(q_rounds, q_rounds); // plain form
             const size_t ldsj = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
             HIP_TRY(allow_lds(ctx, kj, std::max(lds, ldsj)));
             const float* j_t = (const float*)ctx->t32j.p;
@@ -1197,8 +1206,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         int* a_k = (int*)ctx->scr_k.p;
         int a_extra = G - 1; // buffer / centroid block of the carried remainder (pl 5)
         // two-phase forms: the split is compiled into the kernel (quad_split, screen.hip)
-        const bool two = quad && prune_a > 0 && quad_split(q_rounds) < q_rounds;
-        const int a_rounds = two ? quad_split(q_rounds) : q_rounds;
+        const bool two = quad && prune_a > 0 && prune_a < q_rounds; // (prune_a: quad_split or quad_split_late of q_rounds)
+        const int a_rounds = two ? prune_a : q_rounds;
         ctx->last_rounds_all = quad ? a_rounds : 0;
         ctx->last_rounds = quad ? q_rounds : 0;
         const float* a_hint = (hinted && a_rounds < q_rounds) ? sm->hintu : nullptr; // nullptr: every step is finished for the leaders only
@@ -1452,7 +1461,17 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             // while the hints do not mislead (stale buffer: many listed points)
             // (steps skipped on the carried bounds never got as far as their hints)
             const double steps = std::max(0.0, nn / 16.0 - (double)sm->h_nlist[3]) * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
-            if (listed > 0.005 * nn || ((double)sm->h_nlist[2] < 0.05 * steps && steps > 0.01 * nn / 16.0)) {
+            // early or late split (screen.hip, quad_split_late): a run's first three hinted calls use the late one (its
+            // hints are loose: the centroids have just moved a long way), then the early one; an early call that finishes
+            // fewer than 15 % of its (step, tile) pairs early sends the next two back to the late split.  (The late split's
+            // own early-finish share says little about when to leave it -- it moves from 0.37 to 0.44 over the iterations
+            // in which the early split's goes from 0.1 to 0.4 -- so the way back is a fixed count, not a threshold.)
+            const double share = steps > 0.0 ? (double)sm->h_nlist[2] / steps : 1.0;
+            const bool was_late = sm->hint_late_pending;
+            if (!was_late && share < 0.15 && steps > 0.01 * nn / 16.0 && sm->hint_late_left == 0) sm->hint_late_left = 2;
+            sm->hint_late = sm->hint_late_left > 0;
+            const bool fallback_to_late = !was_late && sm->hint_late && quad_split_late(nr) > quad_split(nr);
+            if (listed > 0.005 * nn || ((double)sm->h_nlist[2] < 0.05 * steps && steps > 0.01 * nn / 16.0 && !fallback_to_late)) {
                 sm->hint_fail_streak = std::min(sm->hint_fail_streak + 1, 4);
                 sm->hint_cooldown = 1 << sm->hint_fail_streak; // early iterations mislead briefly, not for 16 calls
             } else {
@@ -1491,6 +1510,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             sm->nlist_pending = true;
             sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
             sm->hint_pending = ctx->last_hinted;
+            sm->hint_late_pending = ctx->last_hinted && ctx->last_hint_late;
             sm->skip_pending = ctx->last_skipping;
         }
         return SPKM_OK; // (statistics and cluster sizes were handed over by run_screen's last kernel)

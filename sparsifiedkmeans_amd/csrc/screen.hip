@@ -1788,13 +1788,19 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
 // tile's leader (or, hinted, for all again when a step's points do not clear their hints).  The split is a
 // compile-time constant: with a run-time split every round sits behind its own branch and the finish's LDS reads
 // are waited for one by one.
+// Late split of the HINTED form (columns of >= 37 entries): half of the rounds.  In the first iterations of a run the
+// hints are loose (the own centroid has just moved a long way) and the competition's partial sums clear them only after
+// about half of the rounds; measured on the headline run (s = 51, 13 rounds) a split at 7 is best in iterations 2-4
+// (28.4 / 27.9 / 26.9 ms against 33.9 / 32.6 / 29.7 at 3), the early one from the fifth on.  The host picks per call from
+// the early-finish count of the previous call (api.hip).
+__host__ __device__ constexpr int quad_split_late(int nr) { return nr >= 10 ? (nr + 1) / 2 : 0; } // 0: none
 #ifdef SPKM_QUAD_A // experiment builds only (tools/build_variant.sh): a fixed split
 __host__ __device__ constexpr int quad_split(int nr) { return nr > SPKM_QUAD_A ? SPKM_QUAD_A : nr; }
 #else
 __host__ __device__ constexpr int quad_split(int nr) { return nr >= 3 ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : nr; }
 #endif
 
-template <int NR, typename IR, bool TWO>
+template <int NR, typename IR, int TWO> // TWO: 0 all rounds for all centroids, 1 split at quad_split, 2 at quad_split_late
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
@@ -1827,7 +1833,7 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
-    constexpr int A = TWO ? quad_split(NR) : NR;
+    constexpr int A = TWO == 0 ? NR : (TWO == 2 && quad_split_late(NR) > 0 ? quad_split_late(NR) : quad_split(NR));
     int nv = n, chunk_v = chunk_points, tp = 0;
     if (todo != nullptr) { // counters[4] = length of the list; chunks small enough that every workgroup gets several
         if (todo_points) { tp = (int)counters[4]; nv = (tp + 15) & ~15; }
@@ -1845,11 +1851,16 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
-template <typename IR> static const void* screen_quad_kernel(int rounds, bool two)
+template <typename IR> static const void* screen_quad_kernel(int rounds, int a_rounds)
 {
+    // a_rounds: rounds evaluated for all centroids (>= rounds: the plain form; else one of the two compiled splits)
+    const bool late = a_rounds < rounds && quad_split_late(rounds) > 0 && a_rounds == quad_split_late(rounds);
+    const bool two = a_rounds < rounds;
     switch (rounds) {
 #define SPKM_QUAD_CASE(N)                                                                                   \
-    case N: return two && quad_split(N) < N ? (const void*)k_screen_quad<N, IR, (quad_split(N) < N)> : (const void*)k_screen_quad<N, IR, false>;
+    case N:                                                                                                 \
+        if (late) return (const void*)k_screen_quad<N, IR, (quad_split_late(N) > 0 ? 2 : 0)>;               \
+        return two && quad_split(N) < N ? (const void*)k_screen_quad<N, IR, (quad_split(N) < N ? 1 : 0)> : (const void*)k_screen_quad<N, IR, 0>;
         SPKM_QUAD_CASE(1) SPKM_QUAD_CASE(2) SPKM_QUAD_CASE(3) SPKM_QUAD_CASE(4) SPKM_QUAD_CASE(5) SPKM_QUAD_CASE(6)
         SPKM_QUAD_CASE(7) SPKM_QUAD_CASE(8) SPKM_QUAD_CASE(9) SPKM_QUAD_CASE(10) SPKM_QUAD_CASE(11) SPKM_QUAD_CASE(12)
         SPKM_QUAD_CASE(13) SPKM_QUAD_CASE(14) SPKM_QUAD_CASE(15) SPKM_QUAD_CASE(16)
