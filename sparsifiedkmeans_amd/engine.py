@@ -349,25 +349,37 @@ def dense_accumulate_device(ctx: Context, x: torch.Tensor, assign: torch.Tensor,
 
 
 _WIDEN_KIND = {torch.float32: 1, torch.uint8: 2, torch.int16: 3, torch.int32: 4}
-_copy_pool = None
+def _copy_threads() -> int:
+    """threads of the host-side staging copy (SPKM_COPY_THREADS overrides).  Measured on the benchmark box (256 hardware
+    threads, tools/ingest_probe2.py): torch's own parallel copy moves 93 GB/s into pinned memory with 16 threads, 21 GB/s
+    with its default of 128 (oversubscribed), and a Python thread pool of sliced copies 14 GB/s whatever its size (every
+    slice's copy_ fans out over all intra-op threads again)."""
+    import os
+
+    if os.environ.get("SPKM_COPY_THREADS"):
+        return max(1, int(os.environ["SPKM_COPY_THREADS"]))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 8
+    return max(1, min(16, cores))
 
 
-def _parallel_host_copy(dst: torch.Tensor, src: torch.Tensor, threads: int = 8) -> None:
-    """dst.copy_(src) for large host tensors, row blocks in parallel: one thread's memcpy moves ~6 GB/s, a fraction of
-    what PCIe takes from the pinned buffer afterwards (torch's copy releases the GIL)."""
-    global _copy_pool
-    m = dst.shape[0]
-    if m * dst.shape[1] * dst.element_size() < (8 << 20) or threads <= 1:
+def _parallel_host_copy(dst: torch.Tensor, src: torch.Tensor, threads: int | None = None) -> None:
+    """dst.copy_(src) for large host tensors with a bounded number of intra-op threads (see _copy_threads); PCIe takes
+    57 GB/s out of the pinned buffer afterwards, so the staging copy must not be the slower of the two."""
+    if dst.numel() * dst.element_size() < (8 << 20):
         dst.copy_(src)
         return
-    if _copy_pool is None:
-        from concurrent.futures import ThreadPoolExecutor
-
-        _copy_pool = ThreadPoolExecutor(max_workers=threads)
-    step = -(-m // threads)
-    futs = [_copy_pool.submit(lambda a=a: dst[a:a + step].copy_(src[a:a + step])) for a in range(0, m, step)]
-    for f in futs:
-        f.result()
+    want = threads if threads is not None else _copy_threads()
+    before = torch.get_num_threads()
+    if before != want:
+        torch.set_num_threads(want)
+    try:
+        dst.copy_(src)
+    finally:
+        if before != want:
+            torch.set_num_threads(before)
 
 
 class StreamingSparsifier:

@@ -494,9 +494,12 @@ def kmeans_sparsified(X, K, **options):
     OUTPUT["TimeAlgo_wo_initialization"] = float(OUTPUT["replicateTimes"].sum()) - OUTPUT["TimeInitialization"]
     Kb = best["K"]
     IDX = best["assign"] if best["assign"] is not None else np.zeros(0, np.int64)
+    # :514-518, SUMD(ki) = sum(distances(IDX==ki).^2) with the LAST trial's distances -- in one pass over the points
+    # instead of K (at n = 1e7, K = 100 the K masked sums took a second, five times the Lloyd loop)
     SUMD = np.zeros(Kb)
-    for ki in range(Kb):                                                         # :514-518: the LAST trial's distances
-        SUMD[ki] = np.sum(distances[IDX == ki + 1] ** 2) if IDX.size else 0.0
+    if IDX.size:
+        ok = (IDX >= 1) & (IDX <= Kb)                                            # ('drop' blanks assignments to 0)
+        SUMD = np.bincount(IDX[ok] - 1, weights=distances[ok] ** 2, minlength=Kb)[:Kb].astype(np.float64)
     if dist_on:                                                                  # SUMD is a sum over all points
         sd = torch.tensor(SUMD, dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(sd, op=torch.distributed.ReduceOp.SUM)
@@ -564,7 +567,7 @@ def kmeans_sparsified(X, K, **options):
             extra += (IDX2, D2)
             if nargout >= 9:
                 t1 = time.time()
-                S2 = np.array([np.sum(distances[IDX2 == ki + 1] ** 2) for ki in range(Kb)])
+                S2 = np.bincount(IDX2 - 1, weights=distances ** 2, minlength=Kb)[:Kb].astype(np.float64)   # (one pass, as SUMD)
                 if dist_on:
                     sd = torch.tensor(S2, dtype=torch.float64, device=dev)
                     torch.distributed.all_reduce(sd, op=torch.distributed.ReduceOp.SUM)
