@@ -1468,7 +1468,10 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             // in which the early split's goes from 0.1 to 0.4 -- so the way back is a fixed count, not a threshold.)
             const double share = steps > 0.0 ? (double)sm->h_nlist[2] / steps : 1.0;
             const bool was_late = sm->hint_late_pending;
-            if (!was_late && share < 0.15 && steps > 0.01 * nn / 16.0 && sm->hint_late_left == 0) sm->hint_late_left = 2;
+            // (only while a good part of the data is on the screen: with most steps settled by the carried bounds the
+            //  few that are left are the hard ones, and the late split just costs more rounds on them)
+            const double all_pairs = nn / 16.0 * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
+            if (!was_late && share < 0.15 && steps > 0.25 * all_pairs && sm->hint_late_left == 0) sm->hint_late_left = 2;
             sm->hint_late = sm->hint_late_left > 0;
             const bool fallback_to_late = !was_late && sm->hint_late && quad_split_late(nr) > quad_split(nr);
             if (listed > 0.005 * nn || ((double)sm->h_nlist[2] < 0.05 * steps && steps > 0.01 * nn / 16.0 && !fallback_to_late)) {

@@ -2,13 +2,13 @@
 # Timeline of single Lloyd iterations (GPU box): rocprofv3 kernel trace of a bench run, cut at k_finalize_centers; prints
 # for chosen iterations every kernel with its start offset, duration and the idle gap in front of it, and per iteration
 # the busy / idle split -- what the launches and the host's per-iteration read cost when the shard is small.
-#   tools/timeline.sh TAG [bench.py arguments]
+#   tools/timeline.sh TAG [bench.py arguments]        (TIMELINE_SCRIPT=tools/driver_bench.py: another entry point)
 export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
 raw=/tmp/timeline_$tag; rm -rf $raw; mkdir -p $raw $root/gpurun_out/timeline_$tag
 cd /tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $raw -o t -- python $root/bench.py "$@" > $root/gpurun_out/timeline_$tag/bench.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $raw -o t -- python $root/${TIMELINE_SCRIPT:-bench.py} "$@" > $root/gpurun_out/timeline_$tag/bench.log 2>&1
 f=$(find $raw -name "*kernel_trace.csv" | head -1)
 m=$(find $raw -name "*memory_copy_trace.csv" | head -1)
 python - "$f" "$m" > $root/gpurun_out/timeline_$tag/timeline.txt <<'PY'
