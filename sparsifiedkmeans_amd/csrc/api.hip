@@ -1101,7 +1101,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             HIP_TRY(hipMalloc((void**)&sm->cl_flags, (size_t)5 * K * 4));
             sm->cl_pk = pk; sm->cl_K = K;
         }
-        if (sm->cl_flags) zero_later(sm->cl_flags + K, (size_t)K * 4); // touched[] (k_copy_i32_gated marks, k_cluster_need reads)
+        if (sm->cl_flags) zero_later(sm->cl_flags + K, (size_t)K * 4); // touched[] (k_combine_screen / k_assign_list mark, k_cluster_need reads)
         if (skip_enabled || hinted) {
             zero_later(sm->hb + 3 * npad + K, 4);
             zero_flush();
@@ -1225,18 +1225,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     HIP_TRY(timing_end(ctx));
     ctx->last_skipping = skipping;
     ctx->last_pt_mode = pt_mode;
-    // 2. certification, 3. exact evaluation of the uncertified points
-    const int cb = (int)std::min<long long>(4096, (n + 255) / 256);
-    hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), 0, ctx->stream, (const float*)ctx->scr_m1.p,
-                       (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
-                       (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
-                       (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
-                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p), pt_mode ? 1 : 0,
-                       quad ? (const double*)(sm->hb_cum + sm->cum_par) : (const double*)nullptr);
-    hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
-                       (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
-                       s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
-                       bounds_ok ? (const int*)(sm->hb + 2 * npad) : (const int*)nullptr, (unsigned*)ctx->nlist.p + 5);
     // 4. counting sort by cluster.  When the context still holds the sort of THIS shard's previous screen call (same
     // K, n, segment length; nothing else has written those buffers since) and no assignment changed -- nlist[5],
     // counted on the device by the combine and list kernels against the library's copy of the previous assignment --
@@ -1294,15 +1282,29 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const bool kept = quad && bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n;
     const bool reuse = kept && ctx->sort_seg == seg && !ctx->sort_partial && !getenv("SPKM_NO_SORT_REUSE");
     const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
-    // cluster sizes: updated by the points that moved (k_copy_i32_gated compares the new assignment with the library's
-    // copy of the previous one anyway) instead of a histogram over all points; SPKM_NO_SORT_REUSE=1 recounts
+    // cluster sizes: updated by the points that moved (k_combine_screen / k_assign_list see every change against the
+    // library's copy of the previous assignment) instead of a histogram over all points; SPKM_NO_SORT_REUSE=1 recounts
     const bool nk_incr = kept && !getenv("SPKM_NO_SORT_REUSE");
+    // 2. certification, 3. exact evaluation of the uncertified points.  Both kernels also keep the library's own copy of
+    // the assignment (hb + 2 npad; the caller's buffer may change between calls) up to date IN PLACE -- only they can
+    // change an assignment -- and, against the previous call's value, mark the clusters a point left or entered and move
+    // the cluster sizes (a separate pass comparing the two arrays used to do that: 0.16 ms per call at N = 1e8)
+    int* a_lib = quad ? (int*)(sm->hb + 2 * npad) : (int*)nullptr;
+    const int cb = (int)std::min<long long>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), nk_incr ? (size_t)K * 4 : 0, ctx->stream, (const float*)ctx->scr_m1.p,
+                       (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
+                       (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
+                       (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
+                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p), pt_mode ? 1 : 0,
+                       quad ? (const double*)(sm->hb_cum + sm->cum_par) : (const double*)nullptr,
+                       bounds_ok ? 1 : 0, cl_skip ? cl_touched : (int*)nullptr, K,
+                       nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr);
+    hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
+                       (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
+                       s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
+                       a_lib, bounds_ok ? 1 : 0, (unsigned*)ctx->nlist.p + 5, cl_skip ? cl_touched : (int*)nullptr,
+                       nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
-    if (quad) // the library's own copy of the assignment (the caller's buffer may change between calls); marks the
-              // clusters a point left or entered on the way
-        hipLaunchKernelGGL(k_copy_i32_gated, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256),
-                           nk_incr ? (size_t)K * 4 : 0, ctx->stream, (int*)(sm->hb + 2 * npad), (const int*)d_assign, n, gate,
-                           cl_skip ? cl_touched : (int*)nullptr, K, nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr);
     if (!nk_incr) {
         hipLaunchKernelGGL(k_zero_u64_gated, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
                            (unsigned long long*)ctx->nk.p, K, gate);

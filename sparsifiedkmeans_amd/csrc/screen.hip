@@ -741,53 +741,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     }
 }
 
-// dst = src / dst = 0 unless *gate == 0 (gate == nullptr: always)
-// touched != nullptr (dst then holds the previous call's assignment): touched[k] = 1 for every cluster a point left
-// or entered -- the FINAL assignment of this call against the final one of the previous call
-// nk != nullptr: the cluster sizes of the previous call are updated in place by the points that moved (exact:
-// integers), instead of a histogram over all points
-__global__ __launch_bounds__(256) void k_copy_i32_gated(int* __restrict__ dst, const int* __restrict__ src, long long n,
-                                                        const unsigned* __restrict__ gate, int* __restrict__ touched, int K,
-                                                        unsigned long long* __restrict__ nk)
-{
-    // (launched with K ints of dynamic LDS when nk != nullptr: the size changes are collected per workgroup -- half the
-    //  points move in the first iterations of a run, and 1e8 global atomics on K addresses would take 100 ms)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* delta = reinterpret_cast<int*>(smem);
-    if (gate != nullptr && *gate == 0u) return;
-    if (nk) {
-        for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
-        __syncthreads();
-    }
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int a = src[i];
-        if (touched || nk) {
-            const int o = dst[i];
-            if (o != a) {
-                const bool vo = (unsigned)o < (unsigned)K, va = (unsigned)a < (unsigned)K;
-                if (touched) {
-                    if (vo) touched[o] = 1;
-                    if (va) touched[a] = 1;
-                }
-                if (nk) {
-                    if (vo) atomicAdd(&delta[o], -1);
-                    if (va) atomicAdd(&delta[a], 1);
-                }
-                dst[i] = a;
-            }
-        } else
-            dst[i] = a;
-    }
-    if (nk) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < K; k += blockDim.x)
-            if (delta[k]) atomicAdd(&nk[k], (unsigned long long)(long long)delta[k]); // (two's complement: adds a negative delta too)
-    }
-}
-
 // Unchanged-cluster shortcut of the exact pass.  Cluster k needs no work in this call when (i) its centroid is bitwise
 // the one the previous call was given (same[k], k_center_drift) and (ii) no point left or entered it (touched[k] == 0,
-// k_copy_i32_gated): every member's distance to it, the library's upper bounds, the per-cluster sums and counts, obj2
+// k_combine_screen / k_assign_list): every member's distance to it, the library's upper bounds, the per-cluster sums and counts, obj2
 // and the largest distance are then exactly what the previous call produced, and they are reused (k_cluster_restore,
 // k_cluster_stats) instead of streamed again.  force != 0: everything is processed (first call of a shard, changed K or
 // gamma, distances requested).  need[k] = 1: process.  counters[32..33]: running total of the points processed.
@@ -910,11 +866,22 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         unsigned int* __restrict__ nlist,
                                                         float* __restrict__ bnd, long long npad, int skipping,
                                                         const int* __restrict__ todo, int pt_mode,
-                                                        const double* __restrict__ cum)
+                                                        const double* __restrict__ cum, int lib_valid,
+                                                        int* __restrict__ touched, int K,
+                                                        unsigned long long* __restrict__ nk)
 {
     const double cum_now = cum ? *cum : 0.0; // lower bounds are stored relative to the accumulated drift (k_bounds_steps)
-    // nlist[5]: points whose (tentative) assignment differs from the previous call's (the library's copy in bnd)
-    const int* aprev = bnd ? reinterpret_cast<const int*>(bnd + 2 * npad) : nullptr;
+    // The library's own copy of the assignment (bnd + 2 npad) is kept up to date here and in k_assign_list -- the only
+    // two places an assignment can change: a CERTIFIED point's new cluster is written at once; an uncertified one keeps
+    // the previous call's value until k_assign_list has the exact answer.  lib_valid: the copy holds the previous call's
+    // final assignment, so that a change is known on the spot --
+    //   nlist[5]: counts (per workgroup) that some assignment changed: the gate of the counting-sort reuse;
+    //   touched[k] = 1 for every cluster a point left or entered (the unchanged-cluster shortcut, k_cluster_need);
+    //   nk[k]: the cluster sizes, moved by the points that changed (collected per workgroup in K ints of dynamic LDS:
+    //   half the points move in the first iterations of a run, and global atomics on K addresses would take 100 ms).
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    int* delta = reinterpret_cast<int*>(smem_c);
+    int* alib = bnd ? reinterpret_cast<int*>(bnd + 2 * npad) : nullptr;
     bool changed = false;
     // bnd != nullptr: write each point's new lower bound (k_center_drift's comment)
     float* lbv = bnd ? bnd + npad : nullptr;
@@ -929,6 +896,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     __shared__ unsigned s_amb, s_chg;
     if ((long long)blockIdx.x * blockDim.x >= total) return; // (whole workgroup)
     if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; }
+    if (nk) for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
     __syncthreads();
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
          q += (long long)gridDim.x * blockDim.x) {
@@ -951,8 +919,20 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         const double r1 = sqrt((double)b1), r2 = sqrt((double)b2);
         const double e1 = E + gacc * r1 + 1e-20, e2 = E + gacc * r2 + 1e-20;
         const bool certified = (bk >= 0) && ((r1 + e1) * (1.0 + nu) < (r2 - e2) * (1.0 - nu));
-        assign[i] = bk >= 0 ? bk : 0;
-        if (aprev && aprev[i] != (bk >= 0 ? bk : 0)) changed = true;
+        const int newk = bk >= 0 ? bk : 0;
+        assign[i] = newk; // (the caller's buffer; tentative for an uncertified point)
+        if (alib && certified) {
+            const int old = lib_valid ? alib[i] : -1;
+            if (old != newk) {
+                alib[i] = newk;
+                if (lib_valid) {
+                    changed = true;
+                    const bool vo = (unsigned)old < (unsigned)K;
+                    if (touched) { if (vo) touched[old] = 1; touched[newk] = 1; }
+                    if (nk) { if (vo) atomicAdd(&delta[old], -1); atomicAdd(&delta[newk], 1); }
+                }
+            }
+        }
         if (lbv) lbv[i] = __double2float_rd((certified ? fmax(0.0, (r2 - e2) * (1.0 - nu)) : 0.0) + cum_now);
         if (!certified) {
             // one atomic per wave, not per point: atomics on one address are served one after the other (~12 ns each --
@@ -979,6 +959,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         if (s_amb) atomicAdd(nlist + 1, s_amb);
         if (s_chg) atomicAdd(nlist + 5, 1u);
     }
+    if (nk)
+        for (int k = threadIdx.x; k < K; k += blockDim.x)
+            if (delta[k]) atomicAdd(&nk[k], (unsigned long long)(long long)delta[k]);
 }
 
 // Listed points: exact reference arithmetic over all K centroids (row-major scaled centres Cs in
@@ -988,9 +971,12 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      const double* __restrict__ xval, const double* __restrict__ Cs,
                                                      int K, int fixed_s, const int* __restrict__ list,
                                                      const unsigned int* __restrict__ nlist,
-                                                     int* __restrict__ assign, const int* __restrict__ aprev,
-                                                     unsigned* __restrict__ changed)
+                                                     int* __restrict__ assign, int* __restrict__ alib, int lib_valid,
+                                                     unsigned* __restrict__ changed, int* __restrict__ touched,
+                                                     unsigned long long* __restrict__ nk)
 {
+    // alib / lib_valid / touched / nk: the library's copy of the assignment and what follows from a change, as in
+    // k_combine_screen (these points kept their previous value there); few points: global atomics
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -1037,7 +1023,18 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
         if (lane == 0) {
             if ((unsigned)bk >= (unsigned)K) bk = 0; // non-finite distances: MATLAB's min() gives index 1; never an out-of-range cluster
             assign[i] = bk;
-            if (aprev && aprev[i] != bk) atomicAdd(changed, 1u);
+            if (alib) {
+                const int old = lib_valid ? alib[i] : -1;
+                if (old != bk) {
+                    alib[i] = bk;
+                    if (lib_valid) {
+                        atomicAdd(changed, 1u);
+                        const bool vo = (unsigned)old < (unsigned)K;
+                        if (touched) { if (vo) touched[old] = 1; touched[bk] = 1; }
+                        if (nk) { if (vo) atomicAdd(&nk[old], ~0ull); atomicAdd(&nk[bk], 1ull); }
+                    }
+                }
+            }
         }
     }
 }
@@ -1500,9 +1497,9 @@ template __global__ void k_screen_tile<unsigned short>(const unsigned short*, co
 template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const float*, const float*, int, int, int,
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*, const int*, unsigned*);
+    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*, const int*, unsigned*);
+    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*);
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
