@@ -12,6 +12,7 @@ timeout 600 python bench.py --workload config3 --steps 100 --warmup 5 --cpu-samp
 timeout 600 python bench.py --n-total 2e7 --clusters 10 --steps 20 --warmup 5 --cpu-sample 0 > $out/bench_k10_n2e7.json 2> $out/bench_k10.err
 timeout 600 python bench.py --n-total 1e7 --steps 20 --warmup 5 --cpu-sample 0 > $out/bench_config2_n1e7.json 2> $out/bench_config2.err
 for f in 1.25e7 2.5e7 5e7; do timeout 600 python bench.py --n-total $f --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/bench_shard_$f.json 2>> $out/bench_shards.err; done
+timeout 900 python tools/driver_bench.py 1e7 100 100 2>&1 | grep -v Warn | tail -3 > $out/driver_bench_n1e7.txt
 bash tools/prof.sh r02_headline --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_headline.log 2>&1
 PROF_TRACE_ONLY=1 bash tools/prof.sh r02_k10 --n-total 2e7 --clusters 10 --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_k10.log 2>&1
 PROF_TRACE_ONLY=1 bash tools/prof.sh r02_shuffled --order shuffled --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_shuffled.log 2>&1
