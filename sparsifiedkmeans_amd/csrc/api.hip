@@ -1114,7 +1114,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             // (its statistics leave per workgroup, bstat, and are added up by the call's last kernel: same-address atomics of
             //  a few thousand workgroups took longer than the test itself on small shards)
             long long span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
-            const long long bgrid = 4LL * std::max(1, ctx->num_cus);
+            long long bgrid = 4LL * std::max(1, ctx->num_cus);
+            if (const char* ev = getenv("SPKM_BOUNDS_WG")) bgrid = (long long)std::max(1, atoi(ev)) * std::max(1, ctx->num_cus); // tuning aid
             if ((rc = ensure(ctx, ctx->bstat, (size_t)bgrid * 8))) return rc;
             while (span > 1024 && (npad + span - 1) / span < 4 * bgrid) span /= 2;
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
@@ -1318,7 +1319,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
                        seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
                        (int*)ctx->nitems.p, cl_on ? (const unsigned*)nullptr : gate, (const int*)cl_need, cl_ibeg, cl_icnt);
-    const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
+    // (two passes over 4 B per point are latency bound: 8192 workgroups at N = 1e8 -- 0.23 -> 0.12 ms against 1024)
+    int sb = (int)std::max<long long>(std::min<long long>(1024, (n + 1023) / 1024), std::min<long long>(8192, n / 4096));
+    if (const char* ev = getenv("SPKM_SCATTER_BLOCKS")) sb = std::max(1, std::min(atoi(ev), (int)((n + 1023) / 1024))); // tuning aid
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
     // (with the shortcut on the scatter is never gated either -- a cluster may need its part of the permutation again
     //  without any assignment having changed -- and places only the points of clusters that will be streamed)
