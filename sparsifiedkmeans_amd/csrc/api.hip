@@ -1114,8 +1114,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             // (its statistics leave per workgroup, bstat, and are added up by the call's last kernel: same-address atomics of
             //  a few thousand workgroups took longer than the test itself on small shards)
             long long span = pt_mode ? BOUNDS_SPAN_PT : BOUNDS_SPAN;
-            long long bgrid = 4LL * std::max(1, ctx->num_cus);
-            if (const char* ev = getenv("SPKM_BOUNDS_WG")) bgrid = (long long)std::max(1, atoi(ev)) * std::max(1, ctx->num_cus); // tuning aid
+            const long long bgrid = 4LL * std::max(1, ctx->num_cus); // (8, 16, 32 per CU measured within noise of 4)
             if ((rc = ensure(ctx, ctx->bstat, (size_t)bgrid * 8))) return rc;
             while (span > 1024 && (npad + span - 1) / span < 4 * bgrid) span /= 2;
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
@@ -1291,7 +1290,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // change an assignment -- and, against the previous call's value, mark the clusters a point left or entered and move
     // the cluster sizes (a separate pass comparing the two arrays used to do that: 0.16 ms per call at N = 1e8)
     int* a_lib = quad ? (int*)(sm->hb + 2 * npad) : (int*)nullptr;
-    const int cb = (int)std::min<long long>(4096, (n + 255) / 256);
+    const int cb = (int)std::min<long long>(4096, (n + 255) / 256); // (8192+: the cold pass gains 6 %, the short lists of a converged run lose 70 %)
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), nk_incr ? (size_t)K * 4 : 0, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
