@@ -561,3 +561,43 @@ def test_unchanged_clusters_are_not_streamed_again_and_outputs_stay_exact(gpu_ct
     for it in range(8):
         eng2.iterate(c2, want_mind=False)
         assert eng2.exact_pass_points()[1] == n
+
+
+def test_hinted_screen_early_and_late_split_give_the_oracles_answers(gpu_ctx, oracle, monkeypatch):
+    """Columns of 51 entries (13 rounds): a run's first hinted calls ask after 7 rounds (spkm_last_screen_rounds reports
+    (7, 13)), later ones after 3; SPKM_NO_LATE_SPLIT=1 keeps to 3.  Which split runs changes the work, never an output:
+    assignments and distances are the oracle's in every call of both runs."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 512, 24000, 40, 0.1                               # s = 51
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=17, noise=0.25)
+    rng = np.random.default_rng(8)
+    d = np.sign(rng.standard_normal(p))
+    s = synth.small_p_of(gopt, p)
+    assert s == 51
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    gam = s / p
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    C0 = oracle.mix(X[:, rng.choice(n, K, replace=False)], d, p)     # K mixture points: duplicates, uncovered clusters
+    seen = {}
+    for nolate in (False, True):
+        if nolate:
+            monkeypatch.setenv("SPKM_NO_LATE_SPLIT", "1")
+        shard.reset_policy()
+        eng = LloydEngine(shard, K, gam)
+        c = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
+        rounds = []
+        for it in range(12):
+            used = c.cpu().numpy().T.copy()
+            eng.iterate(c)
+            torch.cuda.synchronize()                                 # (lets the library's asynchronous counters land)
+            rounds.append(eng.last_screen_rounds())
+            assert eng.last_path_info()[0] == 1
+            ra, rd = oracle.assign(p, n, *parts(Y), used, gam)
+            assert np.array_equal(eng.assign.cpu().numpy(), ra), (nolate, it)
+            assert np.array_equal(eng.mind.cpu().numpy(), rd), (nolate, it)
+        seen[nolate] = rounds
+    assert (7, 13) in seen[False], seen                              # the late split ran ...
+    assert (7, 13) not in seen[True], seen                           # ... and not when switched off
+    assert all(r[1] == 13 for r in seen[False] + seen[True]), seen
