@@ -1153,7 +1153,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if (const char* ev = getenv("SPKM_CHUNK")) chunk = std::max<long long>(sweep, (atoll(ev) / sweep) * sweep); // tuning aid
     {
         const size_t lds = (size_t)(p + 1) * (SCREEN_KT * 4 + (pl_last == 5 ? 16 : 0)) + 16;
-        const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0 ? prune_a : (s->fixed_s + 3) / 4) : (const void*)k_screen_tile<IR>;
+        const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0 ? prune_a : (s->fixed_s + 3) / 4, pt_mode) : (const void*)k_screen_tile<IR>;
         HIP_TRY(allow_lds(ctx, kern, lds));
         HIP_TRY(timing_begin(ctx));
         const IR* a_ir = quad ? (const IR*)s->irs : (const IR*)s->ir;
@@ -1187,8 +1187,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             unsigned* j_cnt = cn + 24; // its list length sits at [24 + 4]
             const int* j_todo = (const int*)ctx->todo.p;
             int j_tp = 0;
+            const char* j_rec = nullptr;
+            int j_recR = 0;
             void* jargs[] = {&a_ir, &a_xf, &j_t, &j_p, &j_n, &j_s, &j_K, &j_bm, &j_chunk, &j_m1, &j_m2, &j_k, &j_extra,
-                             &j_hint, &j_hc, &j_cnt, &j_todo, &j_tp};
+                             &j_hint, &j_hc, &j_cnt, &j_todo, &j_tp, &j_rec, &j_recR};
             HIP_TRY(hipLaunchKernel(kj, dim3(ctx->bmapj_blocks), dim3(1024), jargs, ldsj, ctx->stream));
             hipLaunchKernelGGL(k_bounds_steps2, dim3(2048), dim3(256), 0, ctx->stream, sm->hb, npad, n, K,
                                (const int*)ctx->todo.p, (int*)ctx->todo2.p, cn, (const float*)ctx->scr_m1.p,
@@ -1217,8 +1219,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
         const int* a_todo = skipping ? (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p) : nullptr;
         int a_tp = pt_mode ? 1 : 0;
+        // point lists: the listed points' entries come from the record layout of the exact pass when this shard has one
+        // (built in an earlier call: point lists only appear once most points pass the bounds); SPKM_PTS_NO_REC=1: A/B
+        const char* a_rec = (pt_mode && sm->rec && !getenv("SPKM_PTS_NO_REC")) ? sm->rec : (const char*)nullptr;
+        int a_recR = sm->rec_R;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
-                        &a_hint, &a_hc, &a_cnt, &a_todo, &a_tp};
+                        &a_hint, &a_hc, &a_cnt, &a_todo, &a_tp, &a_rec, &a_recR};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());

@@ -1554,7 +1554,7 @@ __device__ __forceinline__ float quad_min_f32(float v)
     return v;
 }
 
-template <int NR, typename IR, int PL, int A>
+template <int NR, typename IR, int PL, int A, bool PTS>
 __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
                                                  int nv, int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
@@ -1562,8 +1562,11 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int extra_k0,
                                                  const float* __restrict__ hint, float hint_c,
                                                  unsigned* __restrict__ counters, const int* __restrict__ todo,
-                                                 int todo_pts)
+                                                 int todo_pts, const char* __restrict__ rec, int rec_R)
 {
+    // PTS (its own kernel instantiation): the list names POINTS; rec != nullptr: their entries are read from the record
+    // layout of the exact pass (k_build_records: one point = R contiguous bytes, f64 values then row ids) instead of the
+    // step-major f32 copy, where the entries of ONE point are 13 pieces of 16 + 8 B in 26 different cache lines
     constexpr int PPS = 16;
     const int lane = threadIdx.x & 63;
     const int ps = lane >> 2, l4 = lane & 3;
@@ -1606,9 +1609,11 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             // step-major screen copy (k_screen_reorder): round r of a step is 64 consecutive elements, element
             // 4 * slot + l4 belongs to the step's point `slot`
             int i;
-            const float* xp;
-            const IR* rp;
-            if (todo_pts > 0) {
+            const float* xp = nullptr;
+            const IR* rp = nullptr;
+            const double* xd = nullptr; // record mode: the point's values / row ids, entry e at xd[e] / rd[e]
+            const IR* rd = nullptr;
+            if constexpr (PTS) {
                 // the list names POINTS (k_bounds_steps, point mode): 16 unrelated points share this wave's step, each
                 // quad fetches its own point's elements (16 B per quad and round instead of one 256-B row per wave --
                 // affordable only while few points are listed, which is when the host selects this mode)
@@ -1616,8 +1621,14 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                 const int q = slot < todo_pts ? todo[slot] : n;       // n: an empty slot (no output)
                 const int qc = q < n ? q : n - 1;
                 i = q;
-                xp = xval + (size_t)(qc >> 4) * (NR * 64) + ((qc & 15) << 2) + l4;
-                rp = ir + (size_t)(qc >> 4) * (NR * 64) + ((qc & 15) << 2) + l4;
+                if (rec != nullptr) {
+                    const char* rb = rec + (size_t)qc * (size_t)rec_R;
+                    xd = reinterpret_cast<const double*>(rb) + l4;
+                    rd = reinterpret_cast<const IR*>(rb + (size_t)fixed_s * 8) + l4;
+                } else {
+                    xp = xval + (size_t)(qc >> 4) * (NR * 64) + ((qc & 15) << 2) + l4;
+                    rp = ir + (size_t)(qc >> 4) * (NR * 64) + ((qc & 15) << 2) + l4;
+                }
             } else {
                 const int base = todo != nullptr ? todo[vbase >> 4] << 4 : vbase;
                 i = base + ps;
@@ -1629,14 +1640,36 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             float hraw = 0.f;
             if (A < NR && hint != nullptr) hraw = hint[i < n ? i : n - 1];
             // scalars, not arrays: the compiler turns constant-indexed arrays into 16-wide register tuples and spills them
+#define SPKM_QUAD_DECL(r) float x##r = 0.f; int o##r = 0;
+            SPKM_QUAD_DECL(0) SPKM_QUAD_DECL(1) SPKM_QUAD_DECL(2) SPKM_QUAD_DECL(3) SPKM_QUAD_DECL(4) SPKM_QUAD_DECL(5)
+            SPKM_QUAD_DECL(6) SPKM_QUAD_DECL(7) SPKM_QUAD_DECL(8) SPKM_QUAD_DECL(9) SPKM_QUAD_DECL(10)
+            SPKM_QUAD_DECL(11) SPKM_QUAD_DECL(12) SPKM_QUAD_DECL(13) SPKM_QUAD_DECL(14) SPKM_QUAD_DECL(15)
+#undef SPKM_QUAD_DECL
 #define SPKM_QUAD_LOAD(r)                                                              \
-    float x##r = 0.f;                                                                  \
-    int o##r = 0;                                                                      \
     if constexpr (NR > r) { x##r = xp[r * 64]; o##r = (int)rp[r * 64]; }
-            SPKM_QUAD_LOAD(0) SPKM_QUAD_LOAD(1) SPKM_QUAD_LOAD(2) SPKM_QUAD_LOAD(3) SPKM_QUAD_LOAD(4) SPKM_QUAD_LOAD(5)
-            SPKM_QUAD_LOAD(6) SPKM_QUAD_LOAD(7) SPKM_QUAD_LOAD(8) SPKM_QUAD_LOAD(9) SPKM_QUAD_LOAD(10)
-            SPKM_QUAD_LOAD(11) SPKM_QUAD_LOAD(12) SPKM_QUAD_LOAD(13) SPKM_QUAD_LOAD(14) SPKM_QUAD_LOAD(15)
+            // record mode: entry 4 r + l4 of the point, converted and encoded as k_screen_reorder does (x~ = fl32(x); row id
+            // -> row * 8 ^ swizzle; slots past the column: x = 0 on the all-zero row p).  Storage order, not partitioned by
+            // row parity: more LDS bank conflicts per round, in a mode that is bound by its gathers
+#define SPKM_QUAD_LOAD_REC(r)                                                          \
+    if constexpr (NR > r) {                                                            \
+        const bool okr = (r < NR - 1) || (4 * r + l4 < fixed_s);                       \
+        const double xv_ = okr ? xd[4 * r] : 0.0;                                      \
+        const unsigned row_ = okr ? (unsigned)rd[4 * r] : (unsigned)p;                 \
+        x##r = (float)xv_;                                                             \
+        o##r = (int)((row_ << 3) ^ ((row_ >> 1) & 3u));                                \
+    }
+            if (PTS && rec != nullptr) {
+                SPKM_QUAD_LOAD_REC(0) SPKM_QUAD_LOAD_REC(1) SPKM_QUAD_LOAD_REC(2) SPKM_QUAD_LOAD_REC(3) SPKM_QUAD_LOAD_REC(4)
+                SPKM_QUAD_LOAD_REC(5) SPKM_QUAD_LOAD_REC(6) SPKM_QUAD_LOAD_REC(7) SPKM_QUAD_LOAD_REC(8) SPKM_QUAD_LOAD_REC(9)
+                SPKM_QUAD_LOAD_REC(10) SPKM_QUAD_LOAD_REC(11) SPKM_QUAD_LOAD_REC(12) SPKM_QUAD_LOAD_REC(13)
+                SPKM_QUAD_LOAD_REC(14) SPKM_QUAD_LOAD_REC(15)
+            } else {
+                SPKM_QUAD_LOAD(0) SPKM_QUAD_LOAD(1) SPKM_QUAD_LOAD(2) SPKM_QUAD_LOAD(3) SPKM_QUAD_LOAD(4) SPKM_QUAD_LOAD(5)
+                SPKM_QUAD_LOAD(6) SPKM_QUAD_LOAD(7) SPKM_QUAD_LOAD(8) SPKM_QUAD_LOAD(9) SPKM_QUAD_LOAD(10)
+                SPKM_QUAD_LOAD(11) SPKM_QUAD_LOAD(12) SPKM_QUAD_LOAD(13) SPKM_QUAD_LOAD(14) SPKM_QUAD_LOAD(15)
+            }
 #undef SPKM_QUAD_LOAD
+#undef SPKM_QUAD_LOAD_REC
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; // two f32 sums each (bit pattern 0 = (0.f, 0.f))
             float acc4 = 0.f;                                       // PL = 5: the lane's extra centroid
             // the last round broadcasts only the nvl = fixed_s - 4 (NR - 1) entries the column still has
@@ -1797,13 +1830,14 @@ __host__ __device__ constexpr int quad_split(int nr) { return nr > SPKM_QUAD_A ?
 __host__ __device__ constexpr int quad_split(int nr) { return nr >= 3 ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : nr; }
 #endif
 
-template <int NR, typename IR, int TWO> // TWO: 0 all rounds for all centroids, 1 split at quad_split, 2 at quad_split_late
+template <int NR, typename IR, int TWO, bool PTS> // TWO: 0 all rounds for all centroids, 1 split at quad_split, 2 at quad_split_late; PTS: the list names points
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile,
     const float* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const int* __restrict__ todo,
-    int todo_points) // todo_points != 0: the list holds point ids (counters[4] of them), not 16-point steps
+    int todo_points, // todo_points != 0 (the PTS instantiation): the list holds point ids (counters[4] of them), not 16-point steps
+    const char* __restrict__ rec, int rec_R) // record layout for the listed points (PTS; may be null)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -1833,14 +1867,14 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     constexpr int A = TWO == 0 ? NR : (TWO == 2 && quad_split_late(NR) > 0 ? quad_split_late(NR) : quad_split(NR));
     int nv = n, chunk_v = chunk_points, tp = 0;
     if (todo != nullptr) { // counters[4] = length of the list; chunks small enough that every workgroup gets several
-        if (todo_points) { tp = (int)counters[4]; nv = (tp + 15) & ~15; }
+        if (PTS) { tp = (int)counters[4]; nv = (tp + 15) & ~15; }
         else nv = (int)counters[4] * 16;
         chunk_v = max(256, min(chunk_points, (nv / (int)(gridDim.x * 2)) & ~255));
     }
-    if (pl == 4) screen_quad_body<NR, IR, 4, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
-    else if (pl == 5) screen_quad_body<NR, IR, 5, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
-    else if (pl == 2) screen_quad_body<NR, IR, 2, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
-    else screen_quad_body<NR, IR, 1, A>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp);
+    if (pl == 4) screen_quad_body<NR, IR, 4, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
+    else if (pl == 5) screen_quad_body<NR, IR, 5, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
+    else if (pl == 2) screen_quad_body<NR, IR, 2, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
+    else screen_quad_body<NR, IR, 1, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
     if (counters != nullptr) {
         __syncthreads();
         if (tid == 0 && ticket[1]) atomicAdd(counters + 2, ticket[1]);
@@ -1848,7 +1882,7 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
 }
 
 // one kernel per round count (a switch inside one kernel makes the register allocator spill)
-template <typename IR> static const void* screen_quad_kernel(int rounds, int a_rounds)
+template <typename IR, bool PTS> static const void* screen_quad_kernel_p(int rounds, int a_rounds)
 {
     // a_rounds: rounds evaluated for all centroids (>= rounds: the plain form; else one of the two compiled splits)
     const bool late = a_rounds < rounds && quad_split_late(rounds) > 0 && a_rounds == quad_split_late(rounds);
@@ -1856,14 +1890,19 @@ template <typename IR> static const void* screen_quad_kernel(int rounds, int a_r
     switch (rounds) {
 #define SPKM_QUAD_CASE(N)                                                                                   \
     case N:                                                                                                 \
-        if (late) return (const void*)k_screen_quad<N, IR, (quad_split_late(N) > 0 ? 2 : 0)>;               \
-        return two && quad_split(N) < N ? (const void*)k_screen_quad<N, IR, (quad_split(N) < N ? 1 : 0)> : (const void*)k_screen_quad<N, IR, 0>;
+        if (late) return (const void*)k_screen_quad<N, IR, (quad_split_late(N) > 0 ? 2 : 0), PTS>;          \
+        return two && quad_split(N) < N ? (const void*)k_screen_quad<N, IR, (quad_split(N) < N ? 1 : 0), PTS> : (const void*)k_screen_quad<N, IR, 0, PTS>;
         SPKM_QUAD_CASE(1) SPKM_QUAD_CASE(2) SPKM_QUAD_CASE(3) SPKM_QUAD_CASE(4) SPKM_QUAD_CASE(5) SPKM_QUAD_CASE(6)
         SPKM_QUAD_CASE(7) SPKM_QUAD_CASE(8) SPKM_QUAD_CASE(9) SPKM_QUAD_CASE(10) SPKM_QUAD_CASE(11) SPKM_QUAD_CASE(12)
         SPKM_QUAD_CASE(13) SPKM_QUAD_CASE(14) SPKM_QUAD_CASE(15) SPKM_QUAD_CASE(16)
 #undef SPKM_QUAD_CASE
     default: return nullptr;
     }
+}
+
+template <typename IR> static const void* screen_quad_kernel(int rounds, int a_rounds, bool pts = false)
+{
+    return pts ? screen_quad_kernel_p<IR, true>(rounds, a_rounds) : screen_quad_kernel_p<IR, false>(rounds, a_rounds);
 }
 
 // ============================================================================================
