@@ -905,8 +905,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         float b1 = __builtin_inff(), b2 = __builtin_inff();
         int bk = -1;
         for (int g = 0; g < G; g++) {
-            const float m1 = scr_m1[(size_t)g * n + i], m2 = scr_m2[(size_t)g * n + i];
-            const int k = scr_k[(size_t)g * n + i];
+            const size_t at = (size_t)g * n + (size_t)((skipping && pt_mode) ? q : i); // (point lists: stored by list slot)
+            const float m1 = scr_m1[at], m2 = scr_m2[at];
+            const int k = scr_k[at];
             // m1 = estimate of the tile's leader, m2 = a LOWER bound of every other centroid of the tile (the
             // second smallest estimate, or with the two-phase screen the second smallest partial sum -- which
             // can lie below m1): every m2 and every m1 but the best one bound the competition from below
@@ -1803,9 +1804,12 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             }
             if (l4 == first && i < n) {
                 const bool none = seg == 0u;
-                m1o[i] = none ? __builtin_inff() : full;
-                m2o[i] = none ? __builtin_inff() : m2;
-                ko[i] = none ? -1 : klo;
+                // (point lists: the results are stored by LIST SLOT, not by point id -- the screen writes and
+                //  k_combine_screen reads them contiguously instead of at 2 % random places of three n-sized arrays)
+                const int at = PTS ? vbase + ps : i;
+                m1o[at] = none ? __builtin_inff() : full;
+                m2o[at] = none ? __builtin_inff() : m2;
+                ko[at] = none ? -1 : klo;
             }
         }
     }
