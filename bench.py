@@ -349,6 +349,9 @@ def main():
         regimes[other] = traced_run(loop2, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)
         regimes[other]["datagen_s"] = round(t_gen2, 1)
         result["regimes"] = regimes
+        # what a user waits for, independent of --steps / --warmup: iterations / time of one whole run to convergence
+        # (Tol 1e-6, MaxIter 100) from the cold start, on this data order and on the other one
+        result["run_to_convergence_iters_per_s"] = {o: regimes[o]["run_to_convergence_iters_per_s"] for o in regimes}
         del loop2
         shard2.close()
         del data2, shard2
