@@ -27,6 +27,14 @@ while time.time() < t_end:
     noise = float(rng.choice([0.1, 0.3, 0.6]))
     shuffled = bool(rng.integers(0, 2))
     iters = int(rng.integers(6, 26))
+    # the library's A/B switches (read at call time; none may change an output): each on in about one case of six
+    switches = ["SPKM_NO_REC", "SPKM_NO_REC_PIPE", "SPKM_NO_CLUSTER_SKIP", "SPKM_NO_POINT_LIST", "SPKM_NO_LATE_SPLIT",
+                "SPKM_PTS_NO_REC", "SPKM_NO_HINT", "SPKM_NO_PRUNE", "SPKM_NO_BOUNDS", "SPKM_NO_SORT_REUSE", "SPKM_NO_FUSE"]
+    on = [w for w in switches if rng.random() < 1 / 6]
+    for w in switches:
+        os.environ.pop(w, None)
+    for w in on:
+        os.environ[w] = "1"
     X, centres, labels = synth.gmm_dense(p, n, K, seed=int(rng.integers(1 << 30)), noise=noise)
     if shuffled:
         X = X[:, rng.permutation(n)]
@@ -46,9 +54,9 @@ while time.time() < t_end:
         torch.cuda.synchronize()
         ra, rd = O.assign(p, n, *parts(Y), used, gam)
         if not np.array_equal(eng.assign.cpu().numpy(), ra):
-            ok = False; print("ASSIGN MISMATCH", dict(p=p, n=n, K=K, s=s, noise=noise, shuffled=shuffled, it=it)); break
+            ok = False; print("ASSIGN MISMATCH", dict(p=p, n=n, K=K, s=s, noise=noise, shuffled=shuffled, it=it, on=on)); break
         if want_mind and not np.array_equal(eng.mind.cpu().numpy(), rd):
-            ok = False; print("MIND MISMATCH", dict(p=p, n=n, K=K, s=s, it=it)); break
+            ok = False; print("MIND MISMATCH", dict(p=p, n=n, K=K, s=s, it=it, on=on)); break
         # centres after the update vs the oracle's update from the same assignment
         # (kmeans_sparsified.m:447-448 in numpy for the clusters that have members; an empty cluster keeps its column)
         got = c.cpu().numpy().T
@@ -58,11 +66,11 @@ while time.time() < t_end:
         refc = np.where(np.bincount(ra, minlength=K)[None, :] > 0, gam * S / (Cnt + 1e-16), used)
         scale = max(1e-300, np.abs(refc).max())
         if np.abs(got - refc).max() > 1e-9 * scale:
-            ok = False; print("CENTRE MISMATCH", dict(p=p, n=n, K=K, s=s, it=it, err=np.abs(got - refc).max() / scale)); break
+            ok = False; print("CENTRE MISMATCH", dict(p=p, n=n, K=K, s=s, it=it, on=on, err=np.abs(got - refc).max() / scale)); break
     if ok and not want_mind:
         eng.distances(torch.tensor(np.ascontiguousarray(used.T), device="cuda"))
         if not np.array_equal(eng.mind.cpu().numpy(), rd):
-            ok = False; print("DISTANCES-ON-DEMAND MISMATCH", dict(p=p, n=n, K=K, s=s))
+            ok = False; print("DISTANCES-ON-DEMAND MISMATCH", dict(p=p, n=n, K=K, s=s, on=on))
     cases += 1; fails += (not ok)
     del shard, eng
 print(f"{cases} random cases, {fails} failures")
