@@ -153,8 +153,10 @@ int spkm_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const in
  * Hints: from the second screen call on a shard, the screen compares the competition's partial sums with a
  * per-point estimate of the distance to the previous centroid (previous exact distance and that centroid's
  * movement): a group of 16 points stops after a quarter of its entries once the partial squared distance of every
- * other centroid of a tile already exceeds 1.5x the hinted distance squared.  A misleading hint costs time (and
- * pauses the hints for a few calls), never correctness.  SPKM_NO_HINT=1 disables them.
+ * other centroid of a tile already exceeds 1.5x the hinted distance squared (after half of them in the first three
+ * hinted calls following spkm_shard_reset_policy, when the hints are still loose; SPKM_NO_LATE_SPLIT=1: always a
+ * quarter).  A misleading hint costs time (and pauses the hints for a few calls), never correctness.  SPKM_NO_HINT=1
+ * disables them.
  * Carried bounds: the library keeps, per shard, its own copy of the previous screen call's assignment, an
  * upper bound of every point's distance to its centroid and a lower bound of its distance to all others, plus
  * that call's centroids.  On the next call the centroids' movement (triangle inequality on the masked distances)
@@ -168,7 +170,8 @@ int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, c
 /* d_mind == NULL in spkm_assign_accumulate_dev / spkm_lloyd_iter: the caller does not need the per-point distances of
  * THIS call.  Everything is computed as before -- every distance in reference arithmetic, obj2, the largest distance and
  * its index for EmptyAction='singleton', the library's bounds -- only the n doubles are not written (on this part a
- * gigabyte of stores costs as much as eight of loads: 1.1 ms of a 13 ms iteration at N = 1e8).  A driver wants the
+ * gigabyte of stores costs as much as eight of loads: 1.1 ms per iteration at N = 1e8; and the unchanged-cluster
+ * shortcut below applies only then).  A driver wants the
  * distances of its LAST iteration only (kmeans_sparsified.m:493-503,514-518 use `distances` after the loop); it gets them
  * from spkm_distances_dev:
  *   d_mind[i] = distance of point i to centroid d_assign[i] under d_centers / gamma -- the value findClusterAssignments
@@ -198,7 +201,9 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * bounds were applied point by point (the list then names points; info[4] still counts the steps whose 16 points all
  * passed): the library switches to that form when the previous call's test passed >= 90 % of the points and whole
  * steps would leave several times as many points on the screen as failed, so that data in arbitrary order -- where a 16-point
- * step is rarely settled as a whole -- skips as much as cluster-contiguous data does.
+ * step is rarely settled as a whole -- skips as much as cluster-contiguous data does.  (The listed points' entries are
+ * then read from the record layout of the exact pass, 512 contiguous bytes per point at s = 51, when the shard has
+ * one; SPKM_PTS_NO_REC=1 reads the screen's own step-major copy instead.)
  * Blocks on the stream. */
 int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[8]);
 
