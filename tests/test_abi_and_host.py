@@ -141,3 +141,28 @@ def test_ops_reject_non_sparse_like_the_mex(oracle):
         S.SparseMatrixColumnNormSq(np.zeros((4, 4)))
     with pytest.raises(TypeError):
         S.hadamard(sp.csc_matrix(np.eye(4)))
+
+
+def test_staging_copy_is_exact_and_leaves_the_thread_count_alone(monkeypatch):
+    """engine._parallel_host_copy: the host-side staging copy of the streamed ingest runs torch's own copy with a bounded
+    number of intra-op threads (SPKM_COPY_THREADS overrides) and restores the process's setting afterwards."""
+    import numpy as np
+    import torch
+
+    from sparsifiedkmeans_amd import engine
+
+    before = torch.get_num_threads()
+    for dt in (torch.float64, torch.float32, torch.uint8, torch.int16):
+        src = (torch.arange(4099 * 1031, dtype=torch.float64) % 251).to(dt).view(4099, 1031)       # > 8 MB for f64 / f32
+        dst = torch.empty_like(src)
+        engine._parallel_host_copy(dst, src)
+        assert torch.equal(dst, src)
+        assert torch.get_num_threads() == before
+    monkeypatch.setenv("SPKM_COPY_THREADS", "3")
+    assert engine._copy_threads() == 3
+    monkeypatch.delenv("SPKM_COPY_THREADS")
+    assert 1 <= engine._copy_threads() <= 16
+    small = torch.ones(8, 8)
+    out = torch.empty_like(small)
+    engine._parallel_host_copy(out, small)
+    assert np.array_equal(out.numpy(), small.numpy())
