@@ -57,6 +57,9 @@ def lib():
         L.orc_lloyd_ex.argtypes = [_sz, _sz, C.POINTER(C.c_size_t), _u64p, _u64p, _f64p, C.c_double, C.c_int, C.c_int,
                                    C.c_double, C.c_int, _f64p, _i32p, _f64p, _f64p, _f64p, C.POINTER(C.c_int)]
         L.orc_lloyd_ex.restype = C.c_int
+        L.orc_lloyd_plain.argtypes = L.orc_lloyd_ex.argtypes
+        L.orc_lloyd_plain.restype = C.c_int
+        L.orc_finalize_plain_mean.argtypes = [_sz, _sz, _f64p, _i64p, _f64p]
         L.orc_lloyd_iter_threads.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, C.c_double, C.c_int, _f64p, _i32p,
                                              _f64p, C.c_uint]
         L.orc_fwht.argtypes = [C.c_uint, _sz, _f64p, _f64p]
@@ -152,13 +155,23 @@ def finalize_centers(sums, counts, nk, gamma, centers):
     return c.reshape(K, p).T.copy()
 
 
+def finalize_plain_mean(sums, nk, centers):
+    """'MLcorrection',false (kmeans_sparsified.m:449-451): centers(:,k) = mean(full(X(:,ind)),2) = sums(:,k) / nk(k)."""
+    p, K = sums.shape
+    c = _colmajor(centers).copy()
+    lib().orc_finalize_plain_mean(p, K, _colmajor(sums), np.ascontiguousarray(nk, np.int64), c)
+    return c.reshape(K, p).T.copy()
+
+
 _EMPTY_ACTIONS = {"singleton": 0, "drop": 1, "error": 2}
 
 
-def lloyd(p, n, jc, ir, x, centers, gamma, unbiased=True, maxiter=100, tol=1e-6, empty_action="singleton"):
+def lloyd(p, n, jc, ir, x, centers, gamma, unbiased=True, maxiter=100, tol=1e-6, empty_action="singleton",
+          mlcorrection=True):
     """Dense-centre Lloyd loop (kmeans_sparsified.m:417-486) with the reference's three EmptyAction choices
     (:432-445,454-459).  Returns dict; under 'drop' ``centers`` has the surviving columns only and ``assign`` is
-    None when the last iteration dropped one (the reference leaves assignments = [] then, :457)."""
+    None when the last iteration dropped one (the reference leaves assignments = [] then, :457).
+    mlcorrection=False: the plain-mean update of :449-451 instead of :447-448."""
     jc, ir, x = _csc(jc, ir, x)
     centers = np.asarray(centers, np.float64).reshape(p, -1)
     K = centers.shape[1]
@@ -166,8 +179,9 @@ def lloyd(p, n, jc, ir, x, centers, gamma, unbiased=True, maxiter=100, tol=1e-6,
     a, mind = np.zeros(n, np.int32), np.zeros(n)
     dff, obj = np.zeros(maxiter), np.zeros(maxiter)
     Kio, dropped = C.c_size_t(K), C.c_int(0)
-    its = lib().orc_lloyd_ex(p, n, C.byref(Kio), jc, ir, x, float(gamma), int(bool(unbiased)), int(maxiter),
-                             float(tol), _EMPTY_ACTIONS[empty_action], c, a, mind, dff, obj, C.byref(dropped))
+    fn = lib().orc_lloyd_ex if mlcorrection else lib().orc_lloyd_plain
+    its = fn(p, n, C.byref(Kio), jc, ir, x, float(gamma), int(bool(unbiased)), int(maxiter),
+             float(tol), _EMPTY_ACTIONS[empty_action], c, a, mind, dff, obj, C.byref(dropped))
     if its < 0:
         raise RuntimeError("One cluster lost all its members")       # kmeans_sparsified.m:439
     Kf = int(Kio.value)
@@ -216,3 +230,51 @@ def mix(x, d, p2):
     lib().orc_mix(p, p2, n, xin, np.ascontiguousarray(d, np.float64), 1.0 + 2 * np.finfo(np.float64).eps,
                   float(np.sqrt(np.float64(p2))), out, np.zeros(p2))
     return out.reshape(n, p2).T.copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle/_ref: the part of the REFERENCE's own C that builds here (oracle/Makefile, ref_hadamard*_shim.c):
+# private/hadamard.c:57-92 and private/hadamard_pthreads.c:57-119, compiled from where the files lie under
+# /root/reference.  Present only where `make -C oracle` ran with the reference on disk (and, as prebuilt binaries,
+# wherever the snapshot travelled).  Used to PIN orc_fwht / orc_fwht_threads (rows a13, a14), nothing else.
+# ------------------------------------------------------------------------------------------------
+_REF_DIR = os.path.join(_HERE, "_ref")
+_ref_libs: dict = {}
+
+
+def ref_available(flavor: str = "portable") -> bool:
+    """flavor: 'native' (setup_kmeans.m:53's -march=native build: only meaningful on the machine that built it),
+    'portable' (the same excerpt, -O3 without -march), 'pthreads' (hadamard_pthreads.c's worker + kernels)."""
+    name = {"native": "libref_hadamard.so", "portable": "libref_hadamard_portable.so",
+            "pthreads": "libref_hadamard_pthreads.so"}[flavor]
+    return os.path.exists(os.path.join(_REF_DIR, name))
+
+
+def _ref(flavor: str):
+    if flavor not in _ref_libs:
+        name = {"native": "libref_hadamard.so", "portable": "libref_hadamard_portable.so",
+                "pthreads": "libref_hadamard_pthreads.so"}[flavor]
+        L = C.CDLL(os.path.join(_REF_DIR, name))
+        if flavor == "pthreads":
+            L.ref_hadamard_pthreads.argtypes = [C.c_uint, C.c_uint, _f64p, _f64p, C.c_uint]
+        else:
+            L.ref_hadamard.argtypes = [C.c_uint, C.c_uint, _f64p, _f64p]
+        _ref_libs[flavor] = L
+    return _ref_libs[flavor]
+
+
+def ref_fwht(x, flavor: str = "portable", threads: int = 4):
+    """The reference's own hadamard_apply_matrix (hadamard.c:86-92 / hadamard_pthreads.c:101-107 behind `worker`)
+    on an m x n array.  No size validation: the reference does that in its gateway, which needs mex.h."""
+    x = np.asarray(x, np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+    m, n = x.shape
+    assert m > 1 and (m & (m - 1)) == 0 and m * n < 2 ** 32   # (`unsigned j*m`, hadamard.c:90)
+    xin = np.ascontiguousarray(x.T).ravel()
+    out = np.zeros_like(xin)
+    if flavor == "pthreads":
+        _ref(flavor).ref_hadamard_pthreads(m, n, xin, out, int(threads))
+    else:
+        _ref(flavor).ref_hadamard(m, n, xin, out)
+    return out.reshape(n, m).T.copy()

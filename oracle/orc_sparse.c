@@ -226,6 +226,20 @@ void orc_finalize_centers(size_t p, size_t K, const double *sums, const double *
     }
 }
 
+/* kmeans_sparsified.m:449-451, 'MLcorrection',false:
+ *   centers(:,ki) = mean( full(X(:,ind)), 2 )
+ * the plain mean over the cluster's members of the DENSIFIED sparse columns -- zeros included, i.e. the per-row sum of
+ * the stored entries divided by the number of members |ind| (not by the per-row count of stored entries as in :448).
+ * mean(A,2) adds along the columns of A = full(X(:,ind)) in ascending member order and divides once; adding a stored
+ * zero is exact, so sums (orc_accumulate: ascending point order) ./ nk is the same value.  Empty clusters untouched. */
+void orc_finalize_plain_mean(size_t p, size_t K, const double *sums, const int64_t *nk, double *centers)
+{
+    for (size_t k = 0; k < K; k++) {
+        if (nk[k] == 0) continue; /* EmptyAction handled by caller */
+        for (size_t r = 0; r < p; r++) centers[k * p + r] = sums[k * p + r] / (double)nk[k];
+    }
+}
+
 /* kmeans_sparsified.m:470-471:  dff = norm(centersOld-centers,'fro'); obj = sqrt(sum(distances.^2)) */
 double orc_fro_diff(size_t len, const double *a, const double *b)
 {
@@ -252,10 +266,10 @@ double orc_obj(size_t n, const double *mind)
  * *dropped_last = 1 when the LAST iteration dropped a cluster (the reference then returns empty assignments).
  * Returns the number of iterations run; assign / mind are those of the last iteration, dff and obj per iteration
  * (arrays of maxiter). */
-int orc_lloyd_ex(size_t p, size_t n, size_t *K_io, const idx_t *jc, const idx_t *ir, const double *x,
-                 double gamma, int unbiased, int maxiter, double tol, int empty_action,
-                 double *centers /* p*K in/out */, int32_t *assign, double *mind, double *dff_hist,
-                 double *obj_hist, int *dropped_last)
+static int lloyd_impl(size_t p, size_t n, size_t *K_io, const idx_t *jc, const idx_t *ir, const double *x,
+                      double gamma, int unbiased, int maxiter, double tol, int empty_action, int mlcorrection,
+                      double *centers /* p*K in/out */, int32_t *assign, double *mind, double *dff_hist,
+                      double *obj_hist, int *dropped_last)
 {
     size_t K = *K_io;
     double *Cs = (double *)malloc(p * K * sizeof(double));
@@ -269,7 +283,8 @@ int orc_lloyd_ex(size_t p, size_t n, size_t *K_io, const idx_t *jc, const idx_t 
         orc_assign(p, n, K, jc, ir, x, centers, unbiased ? gamma : 0., Cs, assign, mind);
         memcpy(old, centers, p * K * sizeof(double));
         orc_accumulate(p, n, K, jc, ir, x, assign, sums, counts, nk);
-        orc_finalize_centers(p, K, sums, counts, nk, gamma, centers);
+        if (mlcorrection) orc_finalize_centers(p, K, sums, counts, nk, gamma, centers); /* :447-448 */
+        else orc_finalize_plain_mean(p, K, sums, nk, centers);                          /* :449-451 */
         size_t imax = 0;
         int have_empty = 0;
         for (size_t k = 0; k < K; k++) if (nk[k] == 0) have_empty = 1;
@@ -306,6 +321,25 @@ int orc_lloyd_ex(size_t p, size_t n, size_t *K_io, const idx_t *jc, const idx_t 
     free(Cs); free(old); free(sums); free(counts); free(nk);
     *K_io = K;
     return rc ? rc : its;
+}
+
+int orc_lloyd_ex(size_t p, size_t n, size_t *K_io, const idx_t *jc, const idx_t *ir, const double *x,
+                 double gamma, int unbiased, int maxiter, double tol, int empty_action,
+                 double *centers /* p*K in/out */, int32_t *assign, double *mind, double *dff_hist,
+                 double *obj_hist, int *dropped_last)
+{
+    return lloyd_impl(p, n, K_io, jc, ir, x, gamma, unbiased, maxiter, tol, empty_action, 1, centers, assign, mind,
+                      dff_hist, obj_hist, dropped_last);
+}
+
+/* the same loop with 'MLcorrection',false (kmeans_sparsified.m:449-451; row a8) */
+int orc_lloyd_plain(size_t p, size_t n, size_t *K_io, const idx_t *jc, const idx_t *ir, const double *x,
+                    double gamma, int unbiased, int maxiter, double tol, int empty_action,
+                    double *centers /* p*K in/out */, int32_t *assign, double *mind, double *dff_hist,
+                    double *obj_hist, int *dropped_last)
+{
+    return lloyd_impl(p, n, K_io, jc, ir, x, gamma, unbiased, maxiter, tol, empty_action, 0, centers, assign, mind,
+                      dff_hist, obj_hist, dropped_last);
 }
 
 /* EmptyAction='singleton' form kept under its round-1 name (bench.py's cpu_baseline, smoke(), the Lloyd tests). */

@@ -10,6 +10,17 @@
 
 #include "../../include/spkm.h"
 
+// k_screen_quad lives in its own translation units (screen_quad.hip, one per row-id width and list granularity)
+const void* spkm_sq_kernel_16_0(int rounds, int a_rounds);
+const void* spkm_sq_kernel_16_1(int rounds, int a_rounds);
+const void* spkm_sq_kernel_32_0(int rounds, int a_rounds);
+const void* spkm_sq_kernel_32_1(int rounds, int a_rounds);
+template <typename IR> static const void* screen_quad_kernel(int rounds, int a_rounds, bool pts = false)
+{
+    if (sizeof(IR) == 2) return pts ? spkm_sq_kernel_16_1(rounds, a_rounds) : spkm_sq_kernel_16_0(rounds, a_rounds);
+    return pts ? spkm_sq_kernel_32_1(rounds, a_rounds) : spkm_sq_kernel_32_0(rounds, a_rounds);
+}
+
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -1567,7 +1578,7 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
         fast = diff == 0;
     }
     if (fast) {
-        const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4, 3>; // (EXP 3: the sums / counts atomics compiled out)
+        const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4, false>; // (distance-only variant: no sums / counts)
         const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
         HIP_TRY(allow_lds(ctx, k3, lds3));
         const int max_items = (int)(n / ctx->sort_seg) + K + 1;
@@ -1583,7 +1594,8 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
             launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
             ctx->sort_partial = false;
         }
-        if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(max_items, FIN_BLOCKS_MAX) * 24))) return rc; // scratch for the per-item statistics
+        // scratch for the per-item statistics: the plan above emits at most n / seg + K + 1 items for THIS segment length
+        if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(max_items, FIN_BLOCKS_MAX) * 24))) return rc;
         const char* a_rec = s->rec;
         int a_R = s->rec_R, a_p = p, a_s = s->fixed_s;
         const int* a_perm = (const int*)ctx->perm.p;
@@ -1724,17 +1736,25 @@ rccl_api& rccl()
     static rccl_api api;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* h = nullptr;
-        // 1. already in the process (PyTorch's bundled librccl.so, or whatever the host linked)
-        if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = RTLD_DEFAULT;
-        const char* cands[] = {getenv("SPKM_RCCL_PATH"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* c : cands) {
-            if (h) break;
-            if (!c || !*c) continue;
-            h = dlopen(c, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); // loaded under this name but not exported globally
-            if (!h) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        // 1. already in the process (PyTorch's bundled librccl.so, or whatever the host linked): bind through the global
+        //    scope.  RTLD_DEFAULT is a null pointer on glibc, so "found there" is a flag of its own, not a handle.
+        void* h = RTLD_DEFAULT;
+        bool have = dlsym(RTLD_DEFAULT, "ncclAllReduce") != nullptr;
+        if (!have) {
+            const char* cands[] = {getenv("SPKM_RCCL_PATH"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+            // 2. loaded under one of these names but not exported globally: NOLOAD for EVERY candidate before any real
+            //    load (a second, different RCCL beside the one the host already uses is what must not happen)
+            for (const char* c : cands) {
+                if (have || !c || !*c) continue;
+                if (void* q = dlopen(c, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL)) { h = q; have = true; }
+            }
+            // 3. not in the process at all: load it
+            for (const char* c : cands) {
+                if (have || !c || !*c) continue;
+                if (void* q = dlopen(c, RTLD_NOW | RTLD_GLOBAL)) { h = q; have = true; }
+            }
         }
-        if (!h) { snprintf(api.why, sizeof(api.why), "librccl not found (set SPKM_RCCL_PATH): %s", dlerror()); return; }
+        if (!have) { snprintf(api.why, sizeof(api.why), "librccl not found (set SPKM_RCCL_PATH): %s", dlerror()); return; }
         api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");

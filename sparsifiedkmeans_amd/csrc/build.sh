@@ -3,11 +3,22 @@
 # the loader (sparsifiedkmeans_amd/_lib.py) binds them to the libamdhip64 that is already in the
 # process (PyTorch's bundled copy when torch is imported, /opt/rocm otherwise), so that device
 # pointers handed over from torch tensors belong to the same runtime.
+# Five translation units, compiled in parallel: api.hip (host side + every kernel but one) and the four
+# instantiation sets of the 4-lanes-per-point screen kernel (screen_quad.hip).
 set -euo pipefail
 cd "$(dirname "$0")"
 python3 gen_assign_steps.py
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function \
-    -c api.hip -o api.o "$@"
-g++ -shared -o ../libspkm.so api.o -Wl,-z,undefs
-rm -f api.o
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
+pids=()
+$HIPCC $FLAGS -c api.hip -o api.o "$@" & pids+=($!)
+for bits in 16 32; do
+  for pts in 0 1; do
+    $HIPCC $FLAGS -DSPKM_SQ_IRBITS=$bits -DSPKM_SQ_PTS=$pts -c screen_quad.hip -o sq_${bits}_${pts}.o "$@" & pids+=($!)
+  done
+done
+rc=0
+for pid in "${pids[@]}"; do wait "$pid" || rc=1; done
+[ $rc -eq 0 ] || { echo "build.sh: a translation unit failed to compile" >&2; exit 1; }
+g++ -shared -o ../libspkm.so api.o sq_16_0.o sq_16_1.o sq_32_0.o sq_32_1.o -Wl,-z,undefs
+rm -f api.o sq_16_0.o sq_16_1.o sq_32_0.o sq_32_1.o

@@ -401,12 +401,16 @@ def main():
                "int& rA1n, int& rB0n, int& rB1n);\n\n")
     for irb in (2, 4):
         out += [screen32_func(n, irb) for n in range(1, 33)]
-    out.append("// rounds of the 4-lanes-per-point f32 screen (see gen_assign_steps.py, quad_round_block)\n"
-               "template <int NV, int PL>\n__device__ __forceinline__ void quad_round(int xi, int ro, int off0, "
-               "int delta, int ce,\n    double& acc0, double& acc1, double& acc2, double& acc3, float& acc4);\n\n")
+    with open(os.path.join(here, "assign_steps.inc"), "w") as f:
+        f.write("".join(out))
+    # the quad rounds go to their own file: screen_quad.hip is compiled as separate translation units
+    out = ["// GENERATED by gen_assign_steps.py -- do not edit.\n",
+           "// rounds of the 4-lanes-per-point f32 screen (see gen_assign_steps.py, quad_round_block)\n"
+           "template <int NV, int PL>\n__device__ __forceinline__ void quad_round(int xi, int ro, int off0, "
+           "int delta, int ce,\n    double& acc0, double& acc1, double& acc2, double& acc3, float& acc4);\n\n"]
     for pl in (1, 2, 4, 5):
         out += [quad_round_func(nv, pl) for nv in range(1, 5)]
-    with open(os.path.join(here, "assign_steps.inc"), "w") as f:
+    with open(os.path.join(here, "quad_steps.inc"), "w") as f:
         f.write("".join(out))
 
 

@@ -245,6 +245,10 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
     per = (per + W - 1) / W * W;
     const long long lo = (long long)blockIdx.x * per;
     const long long hi = (lo + per < n) ? lo + per : n;
+    // `per` is rounded up to a multiple of W, so trailing workgroups can start past the end: with lo > n the
+    // "whole groups of four" bound below would round a NEGATIVE length down and the scalar tail would place the
+    // last n % 4 points a second time.  The whole workgroup leaves together, before any barrier.
+    if (lo >= hi) return;
     for (int k = tid; k < K; k += blockDim.x) { cnt[k] = 0; needl[k] = need != nullptr ? need[k] : 1; }
     __syncthreads();
     // Neighbouring points very often share a cluster (any dataset stored roughly by class, and every dataset once

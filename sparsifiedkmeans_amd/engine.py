@@ -417,10 +417,20 @@ class StreamingSparsifier:
         self._turn = 0
         self._copy_stream = torch.cuda.Stream(device=dev)
         self.bytes_in = 0                      # bytes that crossed PCIe (for the ingest-rate report)
+        self._src_inflight = None              # (storage pointer, event) of the last PINNED source chunk sent in place
+
+    def wait_source(self) -> None:
+        """Block until the last pinned chunk handed to append() has left host memory.  A pinned source is transferred
+        from where it lies (no staging copy), asynchronously: refilling that buffer before this returns would race with
+        the DMA engine.  Pageable / numpy sources are copied to the sparsifier's own pinned buffers inside append()."""
+        if self._src_inflight is not None:
+            self._src_inflight[1].synchronize()
+            self._src_inflight = None
 
     def append(self, chunk) -> None:
         """chunk: [m, p] points as rows (numpy array or torch tensor, host or device; float64 / float32 / uint8 /
-        int16 / int32)."""
+        int16 / int32).  A PINNED host tensor is read asynchronously after this returns: call wait_source() before
+        overwriting it."""
         dev = self.x.device
         t = torch.from_numpy(np.ascontiguousarray(chunk)) if isinstance(chunk, np.ndarray) else chunk
         if t.dtype not in _WIDEN_KIND and t.dtype != torch.float64:
@@ -439,6 +449,8 @@ class StreamingSparsifier:
             b = self._turn
             self._turn ^= 1
             if self._stage[b] is None or self._stage[b].shape[0] < m or self._stage[b].dtype != t.dtype:
+                if self._ev_free[b] is not None:
+                    self._ev_free[b].synchronize()           # kernels on the context's stream may still read the old block
                 self._stage[b] = torch.empty((m, self.p), dtype=t.dtype, device=dev)
                 self._ev_free[b] = None
             host = t
@@ -458,6 +470,12 @@ class StreamingSparsifier:
                 if not t.is_pinned():
                     self._ev_pin_free[b] = torch.cuda.Event()
                     self._ev_pin_free[b].record(self._copy_stream)
+                else:
+                    # a pinned source is sent from where it lies: the caller must not refill it before this event
+                    # (wait_source())
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                    self._src_inflight = (t.untyped_storage().data_ptr(), ev)
             main.wait_event(self._ev_copied[b])
             src = self._stage[b][:m]
             self.bytes_in += m * self.p * t.element_size()

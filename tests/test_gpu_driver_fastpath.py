@@ -189,3 +189,28 @@ def test_non_finite_distances_never_index_out_of_range(gpu_ctx):
         assert a.min() >= 0 and a.max() < K
         nk = eng.global_nk().cpu().numpy()
         assert nk.sum() == n and np.array_equal(nk, np.bincount(a, minlength=K))
+
+
+@pytest.mark.parametrize("gopt,K,p", [(0.05, 6, 256), (0.2, 9, 128)])
+def test_mlcorrection_false_matches_the_oracle_loop_at_gamma_below_one(gpu_ctx, oracle, gopt, K, p):
+    """Row a8 where it differs from a7: 'MLcorrection',false at SparsityLevel < 1 -- centers(:,k) = mean(full(X(:,ind)),2)
+    (kmeans_sparsified.m:449-451), the per-row sums over the members divided by the cluster size, zeros included --
+    against the oracle's restatement of that loop (orc_lloyd_plain).  At gamma < 1 the plain mean is about gamma times
+    the ML estimate, so the runs diverge from the MLcorrection=true ones after the first update."""
+    from sparsifiedkmeans_amd import synth
+
+    n = 5000
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=31)
+    S = X[:, np.random.default_rng(4).choice(n, K, replace=False)].T
+    IDX, C, SUMD, D, OUT = _run(X, K, SparsityLevel=gopt, Start=S, rng=6, MaxIter=12, MLcorrection=False)
+    Y, d, s, p2, g = replay_driver_products(oracle, X, gopt, 6)
+    ref = oracle.lloyd(p2, n, *parts(Y), mix_start(oracle, S, d, p2), g, maxiter=12, tol=1e-6, mlcorrection=False)
+    assert OUT["iterations"][0] == ref["iterations"]
+    assert np.array_equal(IDX - 1, ref["assign"])
+    assert np.allclose(D, ref["mind"], rtol=1e-9, atol=0)
+    assert abs(OUT["objectives"][0] - ref["obj"][-1]) <= 1e-9 * ref["obj"][-1]
+    Cref = (oracle.fwht(ref["centers"]) / np.sqrt(np.float64(p2)) * d[:, None])[:p]   # unmix (:523)
+    assert np.abs(C.T - Cref).max() <= 1e-6 * np.abs(Cref).max()
+    # and it is NOT the ML-corrected run
+    ml = oracle.lloyd(p2, n, *parts(Y), mix_start(oracle, S, d, p2), g, maxiter=12, tol=1e-6)
+    assert np.abs(ml["centers"] - ref["centers"]).max() > 0.1 * np.abs(ml["centers"]).max()

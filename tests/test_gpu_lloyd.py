@@ -95,3 +95,39 @@ def test_mix_fused_matches_oracle(gpu_ctx, oracle):
     y = mix_device(gpu_ctx, torch.tensor(np.ascontiguousarray(X.T), device="cuda:0"), p2,
                    torch.tensor(d, device="cuda:0"), 1.0 + 2 * np.finfo(float).eps, float(np.sqrt(p2)))
     assert np.array_equal(y.cpu().numpy().T, oracle.mix(X, d, p2))
+
+
+@pytest.mark.parametrize("n", [1_048_581, 1_048_578, 2_000_003])
+@pytest.mark.parametrize("fused", [False, True])
+def test_counting_sort_with_n_not_a_multiple_of_four(gpu_ctx, oracle, n, fused):
+    """k_scatter_by_cluster reads the assignment four points at a time and rounds every workgroup's span up to a multiple
+    of four: from n = 1 048 577 on, trailing workgroups start PAST the end, and (round 2) their scalar tail placed the
+    last n % 4 points a second time -- one cluster got nk + 1 entries in the permutation.  Counts
+    exact and every point accumulated exactly once, on the exact path and on the fused one."""
+    import scipy.sparse as sp
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, s, K, gamma = 64, 3, 5, 3 / 64
+    rng = np.random.default_rng(n)
+    rows = np.sort(np.argsort(rng.random((n, p)), axis=1)[:, :s], axis=1)          # s distinct ascending rows per point
+    vals = rng.standard_normal((n, s)) * 2.0
+    X = sp.csc_matrix((vals.ravel(), rows.ravel().astype(np.int64), np.arange(0, (n + 1) * s, s)), shape=(p, n))
+    Cm = rng.standard_normal((p, K))
+    eng = LloydEngine(Shard.from_scipy(gpu_ctx, X), K, gamma)
+    assert eng.assign.data_ptr() % 16 == 0                                         # the 16-B vector path
+    centers = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda:0")
+    if fused:
+        eng.assign_accumulate_step(centers)
+    else:
+        eng.assign_step(centers)
+        eng.accumulate_step()
+    a = eng.assign.cpu().numpy()
+    a_ref, d_ref = oracle.assign(p, n, *parts(X), Cm, gamma)
+    assert np.array_equal(a, a_ref) and np.array_equal(eng.mind.cpu().numpy(), d_ref)
+    S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), a)
+    red = eng.reduce.cpu().numpy()
+    pk = p * K
+    assert np.array_equal(red[pk:2 * pk].reshape(K, p).T, Cnt)
+    assert np.array_equal(red[2 * pk:2 * pk + K], nk.astype(float))
+    assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-11 * np.abs(S).max()
+    assert abs(red[-1] - np.sum(d_ref * d_ref)) <= 1e-11 * np.sum(d_ref * d_ref)

@@ -66,6 +66,28 @@ def test_hadamard_bit_exact(gpu_ctx, oracle, m, n):
     assert np.array_equal(S.hadamard_pthreads(x, ctx=gpu_ctx), ref)
 
 
+def test_hadamard_equals_the_reference_s_own_outputs(gpu_ctx, oracle):
+    """The HIP FWHT against vectors produced by the REFERENCE's code (tests/golden/make_ref_fixtures.py: hadamard.c:57-92
+    and hadamard_pthreads.c:57-119 compiled from /root/reference in the build container) -- bit for bit.  Where the
+    prebuilt oracle/_ref binary travelled with the snapshot, a fresh random matrix goes through it as well."""
+    import os
+
+    import sparsifiedkmeans_amd as S
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    files = sorted(f for f in os.listdir(gold) if f.startswith("ref_fwht_"))
+    assert len(files) >= 5
+    for f in files:
+        z = np.load(os.path.join(gold, f))
+        assert np.array_equal(S.hadamard(z["x"], ctx=gpu_ctx), z["out"]), f
+        assert np.array_equal(S.hadamard_pthreads(z["x"], ctx=gpu_ctx), z["out"]), f
+    if oracle.ref_available("portable"):
+        x = np.random.default_rng(77).standard_normal((1024, 2500))
+        assert np.array_equal(S.hadamard(x, ctx=gpu_ctx), oracle.ref_fwht(x, "portable"))
+        if oracle.ref_available("pthreads"):
+            assert np.array_equal(S.hadamard_pthreads(x, ctx=gpu_ctx), oracle.ref_fwht(x, "pthreads", 8))
+
+
 def test_hadamard_many_columns_and_vector(gpu_ctx, oracle):
     import sparsifiedkmeans_amd as S
 

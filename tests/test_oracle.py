@@ -66,6 +66,73 @@ def test_fwht_bitwise_and_identities(oracle, m):
     assert np.allclose(oracle.fwht(y) / m, x, rtol=0, atol=1e-12 * m)
 
 
+REF_ROOT = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_ROOT, "private", "hadamard.c")),
+                    reason="the reference tree is not on this machine (oracle/_ref is built from it in place)")
+@pytest.mark.parametrize("m,n", [(2, 1), (2, 7), (8, 3), (64, 1), (64, 13), (1024, 17), (4096, 4), (16, 4096)])
+def test_fwht_oracle_equals_the_reference_build(oracle, m, n):
+    """PINS rows a13 / a14: orc_fwht / orc_fwht_threads / numpy_ref.fwht against the reference's OWN
+    hadamard_apply_vector / hadamard_apply_matrix / worker (private/hadamard.c:57-92, private/hadamard_pthreads.c:57-119
+    cut out at build time and compiled with setup_kmeans.m:53,55-57's flags -- oracle/Makefile, no stand-in header)."""
+    oracle.build(force=True)
+    assert oracle.ref_available("native") and oracle.ref_available("portable") and oracle.ref_available("pthreads")
+    rng = np.random.default_rng(1000 * m + n)
+    x = rng.standard_normal((m, n)) * np.exp(rng.uniform(-30, 30, (1, n)))
+    x[:, 0] = np.round(x[:, 0])                                   # an integer column among them
+    want = oracle.ref_fwht(x, "native")                           # -O3 -march=native (setup_kmeans.m:53)
+    assert np.array_equal(oracle.ref_fwht(x, "portable"), want)   # the build that travels: same bits (add / sub only)
+    assert np.array_equal(oracle.fwht(x), want)
+    assert np.array_equal(R.fwht(x), want)
+    for nt in (1, 4, 8):                                          # NTHREADS of SURVEY 8(c)(i)
+        assert np.array_equal(oracle.ref_fwht(x, "pthreads", nt), want)   # the reference's worker, our partition
+        assert np.array_equal(oracle.fwht(x, threads=nt), want)
+
+
+def test_reference_generated_fwht_fixtures(oracle):
+    """tests/golden/ref_fwht_*.npz are outputs of the reference's own code (make_ref_fixtures.py): they pin the
+    oracle wherever the tests run, with or without /root/reference."""
+    files = sorted(f for f in os.listdir(GOLDEN) if f.startswith("ref_fwht_"))
+    assert len(files) >= 5, "run tests/golden/make_ref_fixtures.py in the build container"
+    for f in files:
+        z = np.load(os.path.join(GOLDEN, f))
+        assert str(z["kind"]) == "ref_fwht"
+        assert np.array_equal(oracle.fwht(z["x"]), z["out"]), f
+        assert np.array_equal(oracle.fwht(z["x"], threads=4), z["out"]), f
+        assert np.array_equal(R.fwht(z["x"]), z["out"]), f
+        if oracle.ref_available("portable"):                      # the prebuilt binary that travelled with the snapshot
+            assert np.array_equal(oracle.ref_fwht(z["x"], "portable"), z["out"]), f
+
+
+def test_plain_mean_update_is_the_dense_mean(oracle):
+    """Row a8, 'MLcorrection',false (kmeans_sparsified.m:449-451): centers(:,k) = mean(full(X(:,ind)),2) -- zeros
+    included, so it differs from the ML estimate of :448 whenever a row is not stored in every member."""
+    p, n, K, gamma = 48, 500, 4, 0.25
+    X = random_csc(p, n, 12, seed=21)
+    C0 = np.random.default_rng(5).standard_normal((p, K))
+    a, d = oracle.assign(p, n, *parts(X), C0, gamma)
+    S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), a)
+    got = oracle.finalize_plain_mean(S, nk, C0)
+    Xd = X.toarray()
+    for k in range(K):
+        assert nk[k] > 0
+        assert np.allclose(got[:, k], Xd[:, a == k].mean(axis=1), rtol=1e-13, atol=1e-15)
+    ml = oracle.finalize_centers(S, Cnt, nk, gamma, C0)
+    assert np.abs(got - ml).max() > 0.1 * np.abs(ml).max()        # the two estimators are far apart at gamma < 1
+    # an empty cluster keeps its column (EmptyAction is the caller's)
+    nk2 = nk.copy(); nk2[1] = 0
+    assert np.array_equal(oracle.finalize_plain_mean(S, nk2, C0)[:, 1], C0[:, 1])
+    # the loop: every iteration is assign -> sums -> sums ./ nk
+    res = oracle.lloyd(p, n, *parts(X), C0, gamma, maxiter=3, tol=0.0, mlcorrection=False)
+    C = C0.copy()
+    for _ in range(3):
+        a, d = oracle.assign(p, n, *parts(X), C, gamma)
+        S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), a)
+        C = oracle.finalize_plain_mean(S, nk, C)
+    assert np.array_equal(res["centers"], C) and np.array_equal(res["assign"], a)
+
+
 def test_fwht_size_errors(oracle):
     with pytest.raises(ValueError, match="power of 2"):
         oracle.fwht(np.zeros((12, 1)))
@@ -116,7 +183,7 @@ def test_golden_regression_fixtures(oracle):
     """tests/golden/*.npz were written by tests/golden/make_fixtures.py from THIS oracle (the
     reference ships no vectors and cannot be run here): they pin the oracle against drift, not
     against the reference."""
-    files = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    files = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("ref_"))
     assert files, "run tests/golden/make_fixtures.py"
     for f in files:
         z = np.load(os.path.join(GOLDEN, f))
