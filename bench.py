@@ -59,6 +59,11 @@ def main():
     ap.add_argument("--start", choices=["sample", "planted"], default="sample",
                     help="initial centres: K mixture points drawn with replacement (default: duplicate and uncovered "
                          "clusters, a run needs many iterations) or the K planted means + noise (converges at once)")
+    ap.add_argument("--noise", type=float, default=0.1,
+                    help="sigma of the mixture components (example_sparseKMeans.m:20-21 uses 0.1: clusters 14 radii apart). "
+                         "The `overlap` regime reruns the headline at --overlap-noise, where the sampled distances of "
+                         "neighbouring clusters overlap and the carried bounds keep failing")
+    ap.add_argument("--overlap-noise", type=float, default=1.5)
     ap.add_argument("--no-regimes", action="store_true", help="skip the traced runs to convergence (quick experiments)")
     ap.add_argument("--workload", choices=["headline", "config3", "config5"], default="headline",
                     help="headline: BASELINE.json's metric config (N=1e8, d=1024, K=100).  config3: MNIST-shaped "
@@ -71,13 +76,19 @@ def main():
     elif args.workload == "config5":
         args.n_total, args.dim, args.clusters, args.order = 1.25e8 * args.gpus, 784, 10, "shuffled"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one process per GPU ourselves (the contract's command line, 127.0.0.1 rendezvous)
+        # and hand its output and exit status through -- `python bench.py --gpus N` is a complete command
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} processes")
     # developer aid (1-GPU boxes): SPKM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # SPKM_BENCH_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised there
     if os.environ.get("SPKM_BENCH_ONE_DEVICE"):
@@ -120,13 +131,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_dataset(order):
+    def make_dataset(order, noise_sigma=None):
         t = time.time()
+        noise_sigma = args.noise if noise_sigma is None else noise_sigma
         if args.workload == "config5":
             data = synth.streamed_pixel_dataset(ctx, p, n_local, first, K, args.sparsity, seed=args.seed, chunk=args.gen_chunk)
         else:
             data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
-                                               chunk=args.gen_chunk, order=order)
+                                               chunk=args.gen_chunk, order=order, noise=noise_sigma)
         shard = Shard.from_device(ctx, data["p2"], data["jc"], data["ir"], data["x"], nnz=data["nnz"])
         # initial centres: K mixture points in the ORIGINAL space passed through mix(), as the
         # 'Start'-matrix path does (kmeans_sparsified.m:401-406); identical on every rank
@@ -135,7 +147,7 @@ def main():
         lab = torch.randint(0, K, (K,), generator=g, device="cuda")
         if args.start == "planted":
             lab = torch.arange(K, device="cuda")
-        noise = 10.0 if args.workload == "config5" else 0.1
+        noise = 10.0 if args.workload == "config5" else noise_sigma
         start = data["means"][lab] + noise * torch.randn((K, p), generator=g, device="cuda", dtype=torch.float64)
         centers0 = mix_device(ctx, start.contiguous(), data["p2"], data["sign"], 1.0, float(np.sqrt(np.float64(data["p2"]))))
         torch.cuda.synchronize()
@@ -174,6 +186,10 @@ def main():
 
         def __init__(self, shard_, centers0_):
             self.shard, self.c0 = shard_, centers0_
+            # as kmeans_sparsified() with Display off: the objective is wanted for the LAST iteration of a run only
+            # (kmeans_sparsified.m:489-503), so the library may leave it out of the other iterations' calls
+            # (spkm_shard_set_lazy_stats); it comes with the run's distances, on demand
+            shard_.set_lazy_stats(not os.environ.get("SPKM_BENCH_EAGER_STATS"))
             self.eng = LloydEngine(shard_, K, gamma)
             self.centers = centers0_.clone()
             self.prev = centers0_.clone()           # the centres the latest assignment was computed with
@@ -192,11 +208,21 @@ def main():
             self.it += 1
             dff = float(np.sqrt(out[0]))
             done = dff < TOL or self.it >= MAXITER
+            obj = float(np.sqrt(out[1]))            # NaN when the library left the objective out of this call
             if done:
-                # what the run returns besides the centres: IDX (eng.assign, written every iteration) and D, the
-                # distances of the LAST iteration -- materialised once per run, as kmeans_sparsified() does
-                self.eng.distances(self.prev)
-            return dff, float(np.sqrt(out[1])), done
+                # what the run returns besides the centres: IDX (eng.assign, written every iteration), D, the
+                # distances of the LAST iteration, and its objective -- materialised once per run, as
+                # kmeans_sparsified() does
+                obj = self.objective_now()
+            return dff, obj, done
+
+        def objective_now(self):
+            """distances + objective of the latest iteration (under the centres its assignment was computed with)"""
+            self.eng.distances(self.prev)
+            o2 = self.eng.stats[0:1].clone()
+            if world > 1:
+                dist.all_reduce(o2, op=dist.ReduceOp.SUM)
+            return float(np.sqrt(o2.item()))
 
         def steps(self, k):
             for _ in range(k):
@@ -275,7 +301,7 @@ def main():
     roofline["screen_steps_processed_share"] = done
     roofline["exact_pass_points_share"] = acc_share
     ops = 3.0 * nnz_local * K
-    out = eng.out.cpu().numpy()
+    final_obj = loop.objective_now() if loop.it > 0 else float("nan")   # (after the timed region; every rank calls it)
 
     result = {
         "metric": "Lloyd iters/sec + achieved HBM GB/s, N=1e8 d=1024 K=100" if args.workload == "headline"
@@ -302,7 +328,7 @@ def main():
                    "order": args.order, "tol": TOL, "maxiter": MAXITER,
                    "gamma": gamma, "parallelism": f"dp{world} (1 RCCL all-reduce/iter)" if world > 1 else "single GPU",
                    "allreduce": allreduce_via,
-                   "datagen_s": round(t_gen, 1), "final_obj": float(np.sqrt(out[1])),
+                   "datagen_s": round(t_gen, 1), "final_obj": final_obj,
                    "runs_completed_in_timed_region": loop.runs_completed, "run_lengths": loop.run_lengths,
                    "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "
                                   "bit-identical to the all-exact kernels)" if path == 1 else "exact f64 tiles",
@@ -369,6 +395,22 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(ngpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def roofline_obj(kernel, ms, nbytes, note):

@@ -53,6 +53,10 @@ int spkm_version(void); /* 10000*major + 100*minor + patch */
 int spkm_ctx_create(int device, void *stream, spkm_ctx **out);
 void spkm_ctx_destroy(spkm_ctx *ctx);
 int spkm_ctx_sync(spkm_ctx *ctx); /* block until everything enqueued on the context's stream is done */
+/* The library's A/B switches (environment variables SPKM_NO_SCREEN, SPKM_NO_BOUNDS, ...: DESIGN.md section 6.1; none
+ * changes an output) are read ONCE, by spkm_ctx_create.  This re-reads them: for tests and A/B tools that toggle a
+ * switch inside one process. */
+int spkm_ctx_reload_switches(spkm_ctx *ctx);
 /* device facts used by the host driver / bench: [0]=CU count, [1]=LDS bytes per workgroup,
  * [2]=device memory bytes, [3]=wavefront size */
 int spkm_device_info(spkm_ctx *ctx, int64_t info[4]);
@@ -110,6 +114,19 @@ int spkm_shard_create_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t nnz, c
  * centres are about to jump -- a new replicate, a new start -- so that the first call does not run in a mode
  * tuned for the previous, converged centres.  Outputs never depend on it. */
 int spkm_shard_reset_policy(spkm_shard *s);
+/* Lazy statistics (on != 0).  kmeans_sparsified.m:471 evaluates obj = sqrt(sum(distances.^2)) in every iteration but
+ * uses it only for Display='iter' (:472-475) and, after the loop, for the iteration that turned out to be the last
+ * (:489-503); [~,iMax] = max(distances) (:436) only when a cluster is empty.  A host that does not display per iteration
+ * says so here, and fused calls (spkm_assign_accumulate_dev / spkm_lloyd_iter with d_mind == NULL) may then leave the
+ * exact pass out: the per-cluster sums and counts are moved by the points that CHANGED cluster (each read twice: out of
+ * its old cluster's sums, into its new one's) instead of re-accumulated over every member, the library's upper bounds
+ * come from the screen's certificate.  Assignments, counts, cluster sizes: as before, bit for bit.  Sums: the members'
+ * sums, to rounding (an add and a subtract per move instead of a fresh summation; bar 1e-6 relative).  In such a call
+ *     d_reduce[2pK + K] (obj2) and d_stats[0..2] are NaN -- not evaluated --
+ * and the host obtains them for the iteration it needs from spkm_distances_stats_dev.  The library decides per call
+ * (few points moved in the previous call, its caches describe the previous call, ...); a call that runs the full pass
+ * returns the statistics as always.  SPKM_NO_INCREMENTAL=1 switches the incremental calls off. */
+int spkm_shard_set_lazy_stats(spkm_shard *s, int on);
 void spkm_shard_destroy(spkm_shard *s);
 int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
 
@@ -181,6 +198,10 @@ int spkm_assign_accumulate_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, c
  * kernel.  Blocks on the stream once. */
 int spkm_distances_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers, double gamma,
                        const int32_t *d_assign, double *d_mind);
+/* The same, and d_stats double[3] (device, may be NULL) = { obj2 = sum_i d_mind[i]^2, max_i d_mind[i], its first index }:
+ * what a fused call hands over in d_stats -- for hosts that asked for lazy statistics (spkm_shard_set_lazy_stats). */
+int spkm_distances_stats_dev(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, const double *d_centers, double gamma,
+                             const int32_t *d_assign, double *d_mind, double *d_stats);
 /* info[0] = path taken by the last spkm_assign_accumulate_dev (0 = exact tiles, 1 = screen + exact
  * confirmation), info[1] = points the screen could not certify.  Blocks on the stream. */
 int spkm_last_path_info(spkm_ctx *ctx, int64_t info[2]);
@@ -196,8 +217,7 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * (a bound: over-counts in the two-phase forms), (16-point step, centroid tile) pairs finished early by the
  * hinted form, 16-point steps skipped altogether on the bounds carried from the previous call (see
  * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context;
- * info[6] = of info[4], the steps skipped only because the centroids that moved most were bounded explicitly
- * (a narrow screen tile over the 8 largest movers; opt-in with SPKM_JUMPERS=1); info[7] = 1 if that tile ran, 2 if the
+ * info[6] = 0 (reserved); info[7] = 2 if the
  * bounds were applied point by point (the list then names points; info[4] still counts the steps whose 16 points all
  * passed): the library switches to that form when the previous call's test passed >= 90 % of the points and whole
  * steps would leave several times as many points on the screen as failed, so that data in arbitrary order -- where a 16-point

@@ -40,19 +40,62 @@ struct devbuf {
     size_t cap = 0;
 };
 
+// A/B switches.  None changes an output; each turns one work-saving layer off so that its share
+// can be measured and so that the tests can hold every layer against the all-exact kernels.  Read from the environment
+// ONCE, when the context is created (spkm_ctx_reload_switches re-reads them: tests and A/B tools that toggle a switch
+// inside one process).
+struct spkm_switches {
+    bool no_screen = false;       // SPKM_NO_SCREEN: all-exact f64 kernels instead of screen + confirmation
+    bool screen_v1 = false;       // SPKM_SCREEN_V1: the 16-lanes-per-point screen kernel for every shape
+    bool no_fuse = false;         // SPKM_NO_FUSE: a remainder of <= 4 centroids gets a narrow tile of its own
+    bool no_prune = false;        // SPKM_NO_PRUNE: never a two-phase form
+    bool no_hint = false;         // SPKM_NO_HINT: no hinted two-phase form
+    bool no_bounds = false;       // SPKM_NO_BOUNDS: carried bounds are maintained but nothing is skipped on them
+    bool no_sort_reuse = false;   // SPKM_NO_SORT_REUSE: the counting sort is redone in every call
+    bool no_rec = false;          // SPKM_NO_REC: no record layout (the exact pass reads the two separate arrays)
+    bool no_point_list = false;   // SPKM_NO_POINT_LIST: the carried bounds always settle whole 16-point steps
+    bool no_cluster_skip = false; // SPKM_NO_CLUSTER_SKIP: every cluster is planned, placed and streamed in every call
+    bool pts_no_rec = false;      // SPKM_PTS_NO_REC: point lists read the step-major f32 copy, not the records
+    bool no_late_split = false;   // SPKM_NO_LATE_SPLIT: the hinted screen always asks after a quarter of the rounds
+    bool no_dist1 = false;        // SPKM_NO_DIST1: K = 1 calls go through the tiled exact kernel
+    bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
+    bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
+};
+static spkm_switches read_switches()
+{
+    auto on = [](const char* name) { const char* v = getenv(name); return v != nullptr && *v != 0; };
+    spkm_switches w;
+    w.no_screen = on("SPKM_NO_SCREEN");
+    w.screen_v1 = on("SPKM_SCREEN_V1");
+    w.no_fuse = on("SPKM_NO_FUSE");
+    w.no_prune = on("SPKM_NO_PRUNE");
+    w.no_hint = on("SPKM_NO_HINT");
+    w.no_bounds = on("SPKM_NO_BOUNDS");
+    w.no_sort_reuse = on("SPKM_NO_SORT_REUSE");
+    w.no_rec = on("SPKM_NO_REC");
+    w.no_point_list = on("SPKM_NO_POINT_LIST");
+    w.no_cluster_skip = on("SPKM_NO_CLUSTER_SKIP");
+    w.pts_no_rec = on("SPKM_PTS_NO_REC");
+    w.no_late_split = on("SPKM_NO_LATE_SPLIT");
+    w.no_dist1 = on("SPKM_NO_DIST1");
+    w.no_incremental = on("SPKM_NO_INCREMENTAL");
+    w.no_support_drift = on("SPKM_NO_SUPPORT_DRIFT");
+    return w;
+}
+
 struct spkm_ctx {
     int device = 0;
+    spkm_switches sw;
     hipStream_t stream = nullptr;
     int num_cus = 0;
     size_t lds_max = 0;
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, todo2, bmapj, t32j, bstat;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
-    int bmapj_key = -1, bmapj_blocks = 0; // block map of the one-tile jumper screen
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     // optional per-launch timing log of the dominant assignment kernel (bench.py)
@@ -71,6 +114,9 @@ struct spkm_ctx {
     unsigned last_listed = 0;        // points sent to the exact list by the last screen (read lazily)
     bool last_hint_late = false; // the last hinted call used the late split
     int last_rounds_all = 0, last_rounds = 0; // rounds for all centroids / total rounds of the last 4-lane screen call
+    bool sort_perm_valid = false;    // ... and perm / offs / items really hold that call's counting sort (not after an incremental call)
+    bool last_lib_valid = false;     // the last screen call could compare with the library's previous assignment (movers counted)
+    bool last_incremental = false;   // the last screen call updated the sums by events (no exact pass)
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
     bool last_pt_mode = false;       // ... and listed points instead of 16-point steps
@@ -127,7 +173,6 @@ struct spkm_shard {
     double hb_gamma = 0.0;
     bool hb_valid = false;
     bool skip_pending = false; // the call whose counters are pending ran the bounds test
-    bool j_on = true;          // explicit bounds for the largest movers (k_pick_jumpers): on until the plain test suffices
     // unchanged-cluster shortcut of the exact pass (screen.hip, k_cluster_need): per-cluster cache of the LOCAL sums and
     // counts (2 p K doubles), obj2 / max distance / its index (3 K), flags need | touched | same | ibeg | icnt (5 K ints)
     double* hb_cum = nullptr;  // [2]: drift accumulated since the lower bounds were stored (screen.hip, k_bounds_steps), by call parity
@@ -138,6 +183,16 @@ struct spkm_shard {
     int cl_K = 0;
     bool cl_valid = false;     // the cache describes this shard's previous screen call completely
     bool pt_next = false;      // the next bounds test lists POINTS, not 16-point steps (the last one passed >= 90 % of the points)
+    // lazy statistics + incremental sums (spkm_shard_set_lazy_stats): the caller does not need obj2 / the largest distance
+    // from every fused call, so a call may leave the exact pass out and move the per-cluster sums by the points that
+    // changed cluster only (events: run_screen, k_accumulate_events)
+    bool lazy = false;
+    bool cl_stats_valid = false; // cl_cache's obj2 / max / argmax describe the previous call (false after an incremental call)
+    int* ev_pt = nullptr;        // events of the current call: point | key (K + old cluster, or new cluster); 2 n each
+    int* ev_k = nullptr;
+    size_t ev_cap = 0;
+    bool movers_known = false, mov_pending_valid = false; // last_movers = points that changed cluster in the last counted call
+    unsigned long long last_movers = 0;
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -219,6 +274,7 @@ extern "C" int spkm_ctx_create(int device, void* stream, spkm_ctx** out)
         return SPKM_ERR_NO_DEVICE;
     spkm_ctx* ctx = new spkm_ctx();
     ctx->device = device;
+    ctx->sw = read_switches();
     ctx->stream = (hipStream_t)stream;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
@@ -246,12 +302,19 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->mscr, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->todo2, &ctx->bmapj, &ctx->t32j, &ctx->bstat};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->bstat, &ctx->nk_ev};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
+}
+
+extern "C" int spkm_ctx_reload_switches(spkm_ctx* ctx)
+{
+    if (!ctx) return SPKM_ERR_NULL_ARG;
+    ctx->sw = read_switches();
+    return SPKM_OK;
 }
 
 extern "C" int spkm_ctx_sync(spkm_ctx* ctx)
@@ -396,6 +459,8 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->irs) (void)hipFree(s->irs);
     if (s->hb) (void)hipFree(s->hb);
     if (s->hintu) (void)hipFree(s->hintu);
+    if (s->ev_pt) (void)hipFree(s->ev_pt);
+    if (s->ev_k) (void)hipFree(s->ev_k);
     if (s->hb_centers) (void)hipFree(s->hb_centers);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
     if (s->ev_nlist) (void)hipEventDestroy(s->ev_nlist);
@@ -420,11 +485,20 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->hint_late = true; // a run starts with loose hints
     s->hint_late_left = 3;
     s->skip_pending = false;
-    s->j_on = true;
     s->pt_next = false;
     s->cl_valid = false;
+    s->cl_stats_valid = false;
+    s->movers_known = false;
+    s->mov_pending_valid = false;
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
+    return SPKM_OK;
+}
+
+extern "C" int spkm_shard_set_lazy_stats(spkm_shard* s, int on)
+{
+    if (!s) return SPKM_ERR_NULL_ARG;
+    s->lazy = on != 0;
     return SPKM_OK;
 }
 
@@ -499,13 +573,13 @@ static int build_blockmap(spkm_ctx* ctx, int G)
 // c % NX) in the same order, so a chunk is fetched from HBM once and re-read from that XCD's L2.
 //   entry: tile, stream = index among the tile's workgroups on this XCD, nstreams = their number,
 //          pad = NX | xcd << 8 | pairs-per-lane << 16
-static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bool jumper_slot = false)
+static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
 {
-    devbuf& buf = jumper_slot ? ctx->bmapj : ctx->bmapq;
-    int& slot_key = jumper_slot ? ctx->bmapj_key : ctx->bmapq_key;
-    int& slot_blocks = jumper_slot ? ctx->bmapj_blocks : ctx->bmapq_blocks;
+    devbuf& buf = ctx->bmapq;
+    int& slot_key = ctx->bmapq_key;
+    int& slot_blocks = ctx->bmapq_blocks;
     const int NB = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    const int key = G * 64 + pl_last * 8 + 1000003 * rounds + (getenv("SPKM_QUAD_W") ? 7 : 0);
+    const int key = G * 64 + pl_last * 8 + 1000003 * rounds;
     if (slot_key == key && slot_blocks == NB) return SPKM_OK;
     const int NX = (NB % 8 == 0) ? 8 : 1;
     const int per = NB / NX;
@@ -518,9 +592,43 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bo
         if (pl == 5) return (double)rounds * (32.0 + 128.0 + 12.0 + 60.0) + 580.0;
         return (double)rounds * (32.0 + 32.0 * pl + (pl == 4 ? 12.0 : 0.0)) + 560.0;
     };
+    std::vector<spkm_blockmap> bm(NB, spkm_blockmap{-1, 0, 1, 0});
+    if (pl_last >= 4) {
+        // TEAMS: every tile costs the same per chunk (full tiles; with pl_last = 5 the remainder of <= 4 centroids is
+        // carried by the G tiles in turn, chunk by chunk -- screen_quad.hip, `rot`).  A team is one workgroup per tile on
+        // ONE XCD; team t takes chunks t, t + nteams, ...; its members sweep them in the same order at the same pace, so
+        // a chunk is fetched from HBM once and met in that XCD's L2 by the other tiles (half the traffic of tiles that
+        // drift apart, and with it a higher sustained clock for this power-bound kernel: 1.77 -> 1.98 GHz measured).
+        // The per % G workgroups an XCD has left over form teams ACROSS XCDs (no L2 sharing, a few per cent of the
+        // chunks) instead of idling.
+        const int T = per / G, spare = per - T * G;
+        const int F = (NX * spare) / G;          // floating teams
+        const int nteams = NX * T + F;
+        const int rot = pl_last == 5 ? G : 0;
+        std::vector<int> spares;
+        for (int x = 0; x < NX; x++)
+            for (int i = 0; i < per; i++) {
+                const int b = i * NX + x; // workgroup b runs on XCD b % NX
+                if (i < T * G) {
+                    spkm_blockmap& e = bm[b];
+                    e.tile = i % G;
+                    e.stream = x + NX * (i / G);
+                    e.nstreams = nteams;
+                    e.pad = 1 | (0 << 8) | (pl_last << 16) | (rot << 24);
+                } else
+                    spares.push_back(b);
+            }
+        for (int f = 0; f < F; f++)
+            for (int g = 0; g < G; g++) {
+                spkm_blockmap& e = bm[spares[f * G + g]];
+                e.tile = g;
+                e.stream = NX * T + f;
+                e.nstreams = nteams;
+                e.pad = 1 | (0 << 8) | (pl_last << 16) | (rot << 24);
+            }
+    } else {
     std::vector<double> w(G, cost(4));
     w[G - 1] = cost(pl_last);
-    if (const char* ev = getenv("SPKM_QUAD_W")) w[G - 1] = cost(4) * atof(ev); // tuning aid
     // apportionment of the XCD's workgroups, at least one per tile, minimising the makespan
     std::vector<int> cnt(G, 1);
     for (int left = per - G; left > 0; left--) {
@@ -530,7 +638,6 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bo
             if (w[g] / cnt[g] > worst) { worst = w[g] / cnt[g]; best = g; }
         cnt[best]++;
     }
-    std::vector<spkm_blockmap> bm(NB, spkm_blockmap{-1, 0, 1, 0});
     for (int x = 0; x < NX; x++) {
         int i = 0;
         for (int g = 0; g < G; g++)
@@ -541,6 +648,7 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds, bo
                 e.nstreams = cnt[g];
                 e.pad = NX | (x << 8) | ((g == G - 1 ? pl_last : 4) << 16);
             }
+    }
     }
     int rc = ensure(ctx, buf, NB * sizeof(spkm_blockmap));
     if (rc) return rc;
@@ -642,7 +750,7 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
         return SPKM_OK;
     }
     // K = 1 on a fixed-stride shard (the k-means++ rounds): a plain stream over X, no tiles, no partials
-    if (K == 1 && s->fixed_s > 0 && s->nnz > 0 && !getenv("SPKM_NO_DIST1")) {
+    if (K == 1 && s->fixed_s > 0 && s->nnz > 0 && !ctx->sw.no_dist1) {
         const int threads = 1024, nw = threads / 64;
         const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
         const size_t fixed_lds = (size_t)p * 8;
@@ -850,7 +958,7 @@ extern "C" int spkm_timing_read(spkm_ctx* ctx, double* ms, int cap, int* count)
 // ------------------------------------------------------------------------------------------
 // counting-sort placement; reads the assignment with 16-B loads when the caller's pointer allows it
 static void launch_scatter(spkm_ctx* ctx, int sb, size_t sc_lds, const int* d_assign, long long n, int K, const unsigned* gate,
-                           const int* need)
+                           const int* need, const unsigned* n_dev = nullptr, const int* ids = nullptr)
 {
     if (sc_lds > 48 * 1024) { // (K in the thousands: beyond the default dynamic-LDS allowance)
         (void)allow_lds(ctx, (const void*)k_scatter_by_cluster<true>, sc_lds);
@@ -858,10 +966,10 @@ static void launch_scatter(spkm_ctx* ctx, int sb, size_t sc_lds, const int* d_as
     }
     if (((uintptr_t)d_assign & 15) == 0)
         hipLaunchKernelGGL(k_scatter_by_cluster<true>, dim3(sb), dim3(256), sc_lds, ctx->stream, d_assign, n, K,
-                           (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate, need);
+                           (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate, need, n_dev, ids);
     else
         hipLaunchKernelGGL(k_scatter_by_cluster<false>, dim3(sb), dim3(256), sc_lds, ctx->stream, d_assign, n, K,
-                           (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate, need);
+                           (unsigned long long*)ctx->cursor.p, (int*)ctx->perm.p, gate, need, n_dev, ids);
 }
 
 static constexpr int SEG_POINTS = 2048;
@@ -869,7 +977,6 @@ static constexpr int SEG_POINTS = 2048;
 // 2048 to 8192 points) as long as every workgroup still gets >= 16 of them
 static int seg_points(long long n, int blocks)
 {
-    if (const char* e = getenv("SPKM_SEG")) return std::max(256, atoi(e));
     const long long want = n / ((long long)std::max(1, blocks) * 16);
     return (int)std::max<long long>(SEG_POINTS, std::min<long long>(8192, want));
 }
@@ -941,24 +1048,24 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
 // ------------------------------------------------------------------------------------------
 // The 4-lanes-per-point screen keeps a point's entries in registers (up to 64); longer columns use the
 // first-generation 16-lanes-per-point kernel.  SPKM_SCREEN_V1 forces the latter (A/B runs).
-static bool screen_use_quad(const spkm_shard* s)
+static bool screen_use_quad(const spkm_ctx* ctx, const spkm_shard* s)
 {
-    return s->fixed_s <= 64 && !getenv("SPKM_SCREEN_V1");
+    return s->fixed_s <= 64 && !ctx->sw.screen_v1;
 }
 
 static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
 {
-    if (getenv("SPKM_NO_SCREEN")) return false;
+    if (ctx->sw.no_screen) return false;
     if (s->fixed_s <= 0 || s->slack < 48 || s->nnz == 0) return false; // the screen reads up to 33 entries past a column
     // K <= 16 fits one exact tile that streams X once; the 4-lanes-per-point screen (one narrow tile) + exact
     // confirmation is still ~13 % faster per iteration there (K = 10, N = 2e7: 4.6 vs 5.2 ms).  K = 1 has nothing to screen.
-    if (K < 2 || (K <= 16 && !screen_use_quad(s))) return false;
+    if (K < 2 || (K <= 16 && !screen_use_quad(ctx, s))) return false;
     if ((s->p + 1) * (uint64_t)SCREEN_KT * 4 + 16 > ctx->lds_max) return false;
     const int nb = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const int tiles = (K + SCREEN_KT - 1) / SCREEN_KT;
     if (tiles > nb) return false;
     // the 4-lanes-per-point kernel gives every tile at least one workgroup per XCD
-    if (screen_use_quad(s) && tiles > ((nb % 8 == 0) ? nb / 8 : nb)) return false;
+    if (screen_use_quad(ctx, s) && tiles > ((nb % 8 == 0) ? nb / 8 : nb)) return false;
     // phase 2 needs the centroid column + slab + at least 8 staged points per wave
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     if (s->p * 20 + 1024 + 16 * 8 * per_pt > ctx->lds_max) return false;
@@ -972,7 +1079,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
-    const bool quad = screen_use_quad(s);
+    const bool quad = screen_use_quad(ctx, s);
     const int G = (K + SCREEN_KT - 1) / SCREEN_KT;
     const size_t pk = (size_t)p * K;
     double* sums = d_reduce;
@@ -1013,10 +1120,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // narrow tile with 1 or 2 centroid pairs per lane instead of 4.  Gs = tiles that have workgroups / result slots.
     const int k_last = K - (G - 1) * SCREEN_KT;
     int pl_last = !quad ? 4 : (k_last <= 8 ? 1 : (k_last <= 16 ? 2 : 4));
-    if (quad && G >= 2 && k_last <= 4 && !getenv("SPKM_NO_FUSE") &&
+    if (quad && G >= 2 && k_last <= 4 && !ctx->sw.no_fuse &&
         (size_t)(p + 1) * (SCREEN_KT * 4 + 16) + 16 <= ctx->lds_max)
         pl_last = 5;
-    if (quad && getenv("SPKM_QUAD_EQUAL")) pl_last = 4; // A/B aid: every tile full width, equal workgroup counts (lock-step)
     const int Gs = pl_last == 5 ? G - 1 : G;
     const int q_rounds = (s->fixed_s + 3) / 4;
     if (quad) rc = build_blockmap_quad(ctx, Gs, pl_last, q_rounds);
@@ -1050,23 +1156,22 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                            ctx->stream, zj);
         zj.n = 0;
     };
-    zero_later(ctx->cmax.p, 16);                       // [0] all tiles, [1] the jumper tile
+    zero_later(ctx->cmax.p, 16);
     zero_later(ctx->nlist.p, 32);
     zero_later((char*)ctx->nlist.p + 40, 128 - 40);    // (not the running total at [8..9])
     zero_later(d_reduce, (2 * pk + K + 1) * 8);
     // bounds carried from this shard's previous screen call (screen.hip, k_center_drift): steps whose points
     // provably keep their centroids are skipped.  SPKM_NO_BOUNDS=1: A/B switch (bounds are still maintained).
     const long long npad = (n + 63) / 64 * 64;
-    const double* cum_prev_p = nullptr; // accumulated drift before this call's bounds test (only set when it ran)
     int bstat_n = 0; // workgroups of k_bounds_steps whose statistics wait in ctx->bstat
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
-    bool skipping = false, jumpers = false, hinted = false, pt_mode = false, bounds_ok = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
+    bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
             if (sm->hb) (void)hipFree(sm->hb);
             sm->hb = nullptr;
             sm->hb_valid = false;
-            HIP_TRY(hipMalloc((void**)&sm->hb, ((size_t)3 * npad + 65536 + 2 + NJUMP + 6) * 4));
+            HIP_TRY(hipMalloc((void**)&sm->hb, ((size_t)3 * npad + HB_TAIL) * 4));
             sm->hb_npad = npad;
         }
         if (sm->hb_centers_len < pk) {
@@ -1085,7 +1190,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // hinted two-phase form: needs the carried bounds (the hints are ub + drift) and a split that saves rounds
         hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds;
         if (hinted) {
-            const bool late = sm->hint_late && quad_split_late(q_rounds) > quad_split(q_rounds) && !getenv("SPKM_NO_LATE_SPLIT");
+            const bool late = sm->hint_late && quad_split_late(q_rounds) > quad_split(q_rounds) && !ctx->sw.no_late_split;
             prune_a = late ? quad_split_late(q_rounds) : quad_split(q_rounds);
             ctx->last_hint_late = late;
             if (sm->hint_late_left > 0) sm->hint_late_left--;
@@ -1097,12 +1202,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                 sm->hintu_len = npad;
             }
         }
-        const bool skip_enabled = bounds_ok && !getenv("SPKM_NO_BOUNDS");
-        const bool want_jump = K >= 3 * NJUMP && sm->j_on && getenv("SPKM_JUMPERS") && !getenv("SPKM_NO_JUMPERS") &&
-                               (size_t)(p + 1) * SCREEN_KT * 4 + 16 <= ctx->lds_max;
+        const bool skip_enabled = bounds_ok && !ctx->sw.no_bounds;
         // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 90 % of the points
         // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
-        pt_mode = skip_enabled && !want_jump && sm->pt_next && !getenv("SPKM_NO_POINT_LIST");
+        pt_mode = skip_enabled && sm->pt_next && !ctx->sw.no_point_list;
         // per-cluster cache / flags of the unchanged-cluster shortcut
         if (!sm->cl_cache || sm->cl_pk != pk || sm->cl_K != K) {
             if (sm->cl_cache) (void)hipFree(sm->cl_cache);
@@ -1113,12 +1216,43 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             sm->cl_pk = pk; sm->cl_K = K;
         }
         if (sm->cl_flags) zero_later(sm->cl_flags + K, (size_t)K * 4); // touched[] (k_combine_screen / k_assign_list mark, k_cluster_need reads)
+        // the context's cluster sizes (and, unless the last call was incremental, its sort buffers) still describe this
+        // shard's previous screen call
+        kept = bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n;
+        // Incremental call (spkm_shard_set_lazy_stats; SPKM_NO_INCREMENTAL=1: A/B switch): no exact pass -- the per-cluster
+        // sums are moved by the points that change cluster (events), upper bounds come from the screen's certificate.
+        // Needs the caller's permission (lazy, no distances asked for), the library's previous assignment and sums
+        // (kept, cl_valid), and pays while few points move: the previous counted call saw at most a sixth of them change
+        // (an event pair reads the point twice, through a gather).  Whatever is chosen, the sums are the members' sums.
+        ev_path = sm->lazy && d_mind == nullptr && kept && sm->cl_valid && !ctx->sw.no_incremental &&
+                  !ctx->sw.no_sort_reuse && sm->movers_known && sm->last_movers * 6 <= (unsigned long long)n &&
+                  (size_t)p * 12 <= 64 * 1024;
+        if (ev_path && sm->ev_cap < (size_t)2 * n) {
+            if (sm->ev_pt) (void)hipFree(sm->ev_pt);
+            if (sm->ev_k) (void)hipFree(sm->ev_k);
+            sm->ev_pt = sm->ev_k = nullptr;
+            sm->ev_cap = 0;
+            if (hipMalloc((void**)&sm->ev_pt, (size_t)2 * n * 4 + 64) != hipSuccess ||
+                hipMalloc((void**)&sm->ev_k, (size_t)2 * n * 4 + 64) != hipSuccess) {
+                (void)hipGetLastError();
+                if (sm->ev_pt) (void)hipFree(sm->ev_pt);
+                sm->ev_pt = sm->ev_k = nullptr;
+                ev_path = false; // (no room: the full pass)
+            } else
+                sm->ev_cap = (size_t)2 * n;
+        }
+        if (ev_path) {
+            if ((rc = ensure(ctx, ctx->nk_ev, (size_t)2 * K * 8))) return rc;
+            zero_later(ctx->nk_ev.p, (size_t)2 * K * 8);
+        }
         if (skip_enabled || hinted) {
             zero_later(sm->hb + 3 * npad + K, 4);
             zero_flush();
             drift_ran = true;
             hipLaunchKernelGGL(k_center_drift, dim3(K), dim3(256), 0, ctx->stream, (const double*)sm->hb_centers,
-                               d_centers, K, p, gamma, sm->hb + 3 * npad, sm->cl_flags + 2 * K);
+                               d_centers, K, p, gamma, sm->hb + 3 * npad, sm->cl_flags + 2 * K,
+                               ctx->sw.no_support_drift ? 0 : s->fixed_s, 2.0f * (float)s->fixed_s / (float)p,
+                               sm->hb + 3 * npad + HB_HTERM);
             // settle the steps (points) the bounds certify, list the others for the screen; write the hints
             if ((rc = ensure(ctx, ctx->todo, pt_mode ? (size_t)(npad + 64) * 4 : (size_t)(npad / 16 + 1) * 4))) return rc;
             // (small shards: shorter spans, so that the launch still has >= 8 workgroups per CU)
@@ -1131,29 +1265,19 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
-                               (getenv("SPKM_HINT_W") ? (float)atof(getenv("SPKM_HINT_W")) : 2.0f) * (float)s->fixed_s / (float)p,
                                pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1),
-                               (int)span, (unsigned*)ctx->bstat.p);
+                               (int)span, (unsigned*)ctx->bstat.p, ev_path ? 1 : 0);
             bstat_n = (int)std::min<long long>((npad + span - 1) / span, bgrid);
-            if (skip_enabled) { cum_prev_p = sm->hb_cum + sm->cum_par; sm->cum_par ^= 1; } // the drift has been added
+            if (skip_enabled) sm->cum_par ^= 1; // the drift has been added
         }
-        if (skip_enabled) {
-            skipping = true;
-            // while a few centres still jump and the rest have settled, bound the jumpers explicitly (screen.hip,
-            // k_pick_jumpers): a narrow screen tile over them on the steps the plain test left, then a second test.
-            // On until the plain test alone skips most steps (lagging counters).  OPT-IN (SPKM_JUMPERS=1): it brings
-            // the skipping forward by two or three iterations, but the points it settles keep their old, eroding
-            // lower bounds instead of fresh ones from the screen and come back later -- measured net gain 2 % of a
-            // run at N = 1e8, a loss on small shards.
-            jumpers = want_jump;
-        }
+        skipping = skip_enabled;
         sm->hb_valid = false; // until this call has gone through
     } else
         sm->hb_valid = false;
     zero_flush();
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
                        0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
-                       (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0, (const int*)nullptr);
+                       (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0);
     hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0,
                        ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
     // 1. screen
@@ -1161,7 +1285,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     long long chunk = n / ((long long)(quad ? ctx->bmapq_blocks / 4 : ctx->bmap_streams) * 8);
     chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
     chunk = (chunk / sweep) * sweep;
-    if (const char* ev = getenv("SPKM_CHUNK")) chunk = std::max<long long>(sweep, (atoll(ev) / sweep) * sweep); // tuning aid
     {
         const size_t lds = (size_t)(p + 1) * (SCREEN_KT * 4 + (pl_last == 5 ? 16 : 0)) + 16;
         const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0 ? prune_a : (s->fixed_s + 3) / 4, pt_mode) : (const void*)k_screen_tile<IR>;
@@ -1169,48 +1292,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         HIP_TRY(timing_begin(ctx));
         const IR* a_ir = quad ? (const IR*)s->irs : (const IR*)s->ir;
         const float* a_xf = quad ? (const float*)s->xfs : (const float*)s->xf;
-        if (jumpers) {
-            // the jumper tile: pick, lay out (one narrow tile of NJUMP centroids), screen the listed steps with the
-            // PLAIN kernel, test again, commit the shorter list.  Results go through tile 0's slots, which the main
-            // screen overwrites afterwards for the steps that stay.
-            unsigned* cn = (unsigned*)ctx->nlist.p;
-            float* dl = sm->hb + 3 * npad;
-            hipLaunchKernelGGL(k_pick_jumpers, dim3(1), dim3(256), 0, ctx->stream, dl, K, cn);
-            hipLaunchKernelGGL(k_jumper_list_length, dim3(1), dim3(1), 0, ctx->stream, cn, 28, (unsigned)((n + 15) / 16));
-            const size_t jfloats = (size_t)(p + 1) * SCREEN_KT;
-            if ((rc = ensure(ctx, ctx->t32j, jfloats * 4))) return rc;
-            if ((rc = ensure(ctx, ctx->todo2, (size_t)(npad / 16 + 1) * 4))) return rc;
-            hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((jfloats + 255) / 256, 2048)), dim3(256), 0,
-                               ctx->stream, d_centers, p, K, 1, gamma, (float*)ctx->t32j.p,
-                               (unsigned long long*)ctx->cmax.p + 1, 1, 1, (const int*)(dl + K + 2));
-            if ((rc = build_blockmap_quad(ctx, 1, 1, q_rounds, true))) return rc;
-            const void* kj = screen_quad_kernel<IR>(q_rounds, q_rounds); // plain form
-            const size_t ldsj = (size_t)(p + 1) * SCREEN_KT * 4 + 16;
-            HIP_TRY(allow_lds(ctx, kj, std::max(lds, ldsj)));
-            const float* j_t = (const float*)ctx->t32j.p;
-            int j_p = p, j_n = (int)n, j_s = s->fixed_s, j_K = NJUMP, j_chunk = (int)chunk, j_extra = 0;
-            const spkm_blockmap* j_bm = (const spkm_blockmap*)ctx->bmapj.p;
-            float* j_m1 = (float*)ctx->scr_m1.p;
-            float* j_m2 = (float*)ctx->scr_m2.p;
-            int* j_k = (int*)ctx->scr_k.p;
-            const float* j_hint = nullptr;
-            float j_hc = 0.f;
-            unsigned* j_cnt = cn + 24; // its list length sits at [24 + 4]
-            const int* j_todo = (const int*)ctx->todo.p;
-            int j_tp = 0;
-            const char* j_rec = nullptr;
-            int j_recR = 0;
-            void* jargs[] = {&a_ir, &a_xf, &j_t, &j_p, &j_n, &j_s, &j_K, &j_bm, &j_chunk, &j_m1, &j_m2, &j_k, &j_extra,
-                             &j_hint, &j_hc, &j_cnt, &j_todo, &j_tp, &j_rec, &j_recR};
-            HIP_TRY(hipLaunchKernel(kj, dim3(ctx->bmapj_blocks), dim3(1024), jargs, ldsj, ctx->stream));
-            hipLaunchKernelGGL(k_bounds_steps2, dim3(2048), dim3(256), 0, ctx->stream, sm->hb, npad, n, K,
-                               (const int*)ctx->todo.p, (int*)ctx->todo2.p, cn, (const float*)ctx->scr_m1.p,
-                               (const double*)s->xn1, (const double*)s->xn2,
-                               (const unsigned long long*)ctx->cmax.p + 1, s->fixed_s, (int*)d_assign,
-                               cum_prev_p ? cum_prev_p : (const double*)(sm->hb_cum + sm->cum_par),
-                               (const double*)(sm->hb_cum + sm->cum_par));
-            hipLaunchKernelGGL(k_commit_list, dim3(1), dim3(1), 0, ctx->stream, cn);
-        }
         const float* a_t = (const float*)ctx->t32.p;
         int a_p = p, a_n = (int)n, a_s = s->fixed_s, a_K = K, a_chunk = (int)chunk;
         const spkm_blockmap* a_bm = (const spkm_blockmap*)(quad ? ctx->bmapq.p : ctx->bmap.p);
@@ -1226,13 +1307,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const float* a_hint = (hinted && a_rounds < q_rounds) ? sm->hintu : nullptr; // nullptr: every step is finished for the leaders only
         float a_hc = 1.5f; // the other centroids' partial sums must exceed 1.5 x the hinted distance squared
         ctx->last_hinted = a_hint != nullptr;
-        if (const char* ev = getenv("SPKM_HINT_C")) a_hc = (float)atof(ev);
         unsigned* a_cnt = (unsigned*)ctx->nlist.p;
-        const int* a_todo = skipping ? (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p) : nullptr;
+        const int* a_todo = skipping ? (const int*)ctx->todo.p : nullptr;
         int a_tp = pt_mode ? 1 : 0;
         // point lists: the listed points' entries come from the record layout of the exact pass when this shard has one
         // (built in an earlier call: point lists only appear once most points pass the bounds); SPKM_PTS_NO_REC=1: A/B
-        const char* a_rec = (pt_mode && sm->rec && !getenv("SPKM_PTS_NO_REC")) ? sm->rec : (const char*)nullptr;
+        const char* a_rec = (pt_mode && sm->rec && !ctx->sw.pts_no_rec) ? sm->rec : (const char*)nullptr;
         int a_recR = sm->rec_R;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
                         &a_hint, &a_hc, &a_cnt, &a_todo, &a_tp, &a_rec, &a_recR};
@@ -1255,8 +1335,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
     if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
     // (the exact pass's geometry is needed here already: the plan below depends on which kernel runs)
-    int threads = 1024;
-    if (const char* ev = getenv("SPKM_ACC_THREADS")) threads = atoi(ev) == 512 ? 512 : 1024; // A/B aid
+    const int threads = 1024;
     const int nw = threads / 64;
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     const size_t fixed_lds = (size_t)p * 20 + 16;
@@ -1264,7 +1343,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // when the device has room for it (n * R bytes: 51 GB at N = 1e8, s = 51).  With the points of a cluster scattered
     // over the shard (data in arbitrary order) it takes a third off this pass; in cluster-contiguous order it is
     // neutral.  SPKM_NO_REC=1: the two separate arrays (A/B switch, and what runs when memory is short).
-    if (!sm->rec && !sm->rec_tried && !getenv("SPKM_NO_REC")) {
+    if (!sm->rec && !sm->rec_tried && !ctx->sw.no_rec) {
         sm->rec_tried = true;
         const int R = (int)(((size_t)s->fixed_s * (8 + sizeof(IR)) + 15) / 16 * 16);
         size_t free_b = 0, total_b = 0;
@@ -1280,8 +1359,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     }
     const bool use_rec = sm->rec != nullptr;
     // software-pipelined record kernel (k_exact_accumulate_rec): batches of exactly 16 points per wave, columns of up
-    // to 64 entries; SPKM_NO_REC_PIPE=1 keeps k_exact_accumulate on the records (A/B switch)
-    const bool pipe = use_rec && !getenv("SPKM_NO_REC_PIPE") && s->fixed_s <= 64 &&
+    // to 64 entries
+    const bool pipe = use_rec && s->fixed_s <= 64 &&
                       fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
     // Unchanged-cluster shortcut (screen.hip, k_cluster_need): clusters whose centroid is bitwise the previous call's and
     // that no point left or entered are not streamed again -- their sums, counts, distances, bounds and statistics are
@@ -1289,19 +1368,17 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // the previous assignment (bounds_ok) and a complete cache; not when the caller wants the distances written.
     // SPKM_NO_CLUSTER_SKIP=1: A/B switch.
     const bool cl_on = quad && pipe && sm->cl_cache != nullptr;
-    const bool cl_skip = cl_on && bounds_ok && drift_ran && sm->cl_valid && d_mind == nullptr && !getenv("SPKM_NO_CLUSTER_SKIP");
+    const bool cl_skip = cl_on && bounds_ok && drift_ran && sm->cl_valid && sm->cl_stats_valid && d_mind == nullptr && !ctx->sw.no_cluster_skip && !ev_path;
     int* cl_need = cl_on ? sm->cl_flags : nullptr;
     int* cl_touched = cl_on ? sm->cl_flags + K : nullptr;
     int* cl_same = cl_on ? sm->cl_flags + 2 * K : nullptr;
     int* cl_ibeg = cl_on ? sm->cl_flags + 3 * K : nullptr;
     int* cl_icnt = cl_on ? sm->cl_flags + 4 * K : nullptr;
-    // the context's sort buffers / cluster sizes still describe this shard's previous screen call
-    const bool kept = quad && bounds_ok && ctx->sort_owner == (const void*)sm && ctx->sort_K == K && ctx->sort_n == n;
-    const bool reuse = kept && ctx->sort_seg == seg && !ctx->sort_partial && !getenv("SPKM_NO_SORT_REUSE");
+    const bool reuse = kept && ctx->sort_perm_valid && ctx->sort_seg == seg && !ctx->sort_partial && !ctx->sw.no_sort_reuse;
     const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
     // cluster sizes: updated by the points that moved (k_combine_screen / k_assign_list see every change against the
     // library's copy of the previous assignment) instead of a histogram over all points; SPKM_NO_SORT_REUSE=1 recounts
-    const bool nk_incr = kept && !getenv("SPKM_NO_SORT_REUSE");
+    const bool nk_incr = kept && !ctx->sw.no_sort_reuse;
     // 2. certification, 3. exact evaluation of the uncertified points.  Both kernels also keep the library's own copy of
     // the assignment (hb + 2 npad; the caller's buffer may change between calls) up to date IN PLACE -- only they can
     // change an assignment -- and, against the previous call's value, mark the clusters a point left or entered and move
@@ -1312,16 +1389,75 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
-                       skipping ? 1 : 0, (const int*)(jumpers ? ctx->todo2.p : ctx->todo.p), pt_mode ? 1 : 0,
+                       skipping ? 1 : 0, (const int*)ctx->todo.p, pt_mode ? 1 : 0,
                        quad ? (const double*)(sm->hb_cum + sm->cum_par) : (const double*)nullptr,
                        bounds_ok ? 1 : 0, cl_skip ? cl_touched : (int*)nullptr, K,
-                       nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr);
+                       nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
+                       ev_path ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
                        a_lib, bounds_ok ? 1 : 0, (unsigned*)ctx->nlist.p + 5, cl_skip ? cl_touched : (int*)nullptr,
-                       nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr);
+                       nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
+                       ev_path ? sm->hb : (float*)nullptr, ev_path ? sm->ev_pt : (int*)nullptr,
+                       ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
+    ctx->last_lib_valid = bounds_ok;
+    ctx->last_incremental = ev_path;
+    if (ev_path) {
+        // ---- incremental call: the per-cluster sums move by the points that changed cluster; no exact pass ----
+        // events (point, key) are sorted by key over 2 K keys (K + k: leaves cluster k; k: enters it) with the same
+        // histogram / plan / placement kernels as the points of a full pass, their number read on the device
+        const unsigned* ev_n = (const unsigned*)ctx->nlist.p + 16;
+        const int K2 = 2 * K;
+        const int seg_ev = SEG_POINTS;
+        const int max_items_ev = (int)((2 * n) / seg_ev) + K2 + 1;
+        if ((rc = ensure(ctx, ctx->perm, (size_t)2 * n * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->offs, (size_t)(K2 + 1) * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->cursor, (size_t)K2 * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->items, (size_t)max_items_ev * 16))) return rc;
+        // (sized by what usually moves, not by the worst case: every kernel strides over the device-side count)
+        const long long ev_est = std::max<long long>(4096, (long long)std::min<unsigned long long>(4 * sm->last_movers + 4096, (unsigned long long)2 * n));
+        const int hb_ = (int)std::min<long long>(1024, (ev_est + 1023) / 1024);
+        hipLaunchKernelGGL(k_hist, dim3(hb_), dim3(256), (size_t)K2 * 4, ctx->stream, (const int*)sm->ev_k, (long long)0, K2,
+                           (unsigned long long*)ctx->nk_ev.p, (const unsigned*)nullptr, ev_n);
+        hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk_ev.p, K2,
+                           seg_ev, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                           (int*)ctx->nitems.p, (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+        const size_t sc_lds_ev = (size_t)((K2 + 1) & ~1) * 4 + (size_t)K2 * 12;
+        launch_scatter(ctx, hb_, sc_lds_ev, (const int*)sm->ev_k, 0, K2, (const unsigned*)nullptr, (const int*)nullptr, ev_n,
+                       (const int*)sm->ev_pt);
+        double* cache_s = sm->cl_cache;
+        double* cache_c = cache_s + pk;
+        const size_t slab = (size_t)p * 12;
+        const int ab_ev = (int)std::min<long long>(max_items_ev, std::max<long long>(std::max(1, ctx->num_cus) * 8, 1));
+        if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
+        hipLaunchKernelGGL((k_accumulate_events<IR>), dim3(ab_ev), dim3(256), slab, ctx->stream, (const char*)sm->rec,
+                           sm->rec_R, (const IR*)s->ir, (const double*)s->x, (const int*)ctx->perm.p,
+                           (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)ctx->nitems.p, p,
+                           s->fixed_s, K, cache_s, cache_c);
+        if (ctx->tlog_both) HIP_TRY(timing_end(ctx));
+        HIP_TRY(hipGetLastError());
+        // the call's sums and counts ARE the cache (rows that no member stores any more: exactly 0)
+        hipLaunchKernelGGL(k_sums_from_cache, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 1024)), dim3(256), 0, ctx->stream,
+                           cache_s, (const double*)cache_c, pk, sums, counts);
+        hipLaunchKernelGGL(k_call_tail, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
+                           (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p, 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sm->hb_centers, d_centers, pk * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        sm->hb_K = K;
+        sm->hb_gamma = gamma;
+        sm->hb_valid = true;
+        sm->cl_stats_valid = false; // obj2 / largest distance per cluster were not evaluated
+        ctx->sort_owner = sm;       // (the cluster sizes in ctx->nk stay this shard's; its sort buffers do not)
+        ctx->sort_K = K;
+        ctx->sort_n = n;
+        ctx->sort_perm_valid = false;
+        ctx->sort_partial = false;
+        ctx->last_path = 1;
+        return SPKM_OK;
+    }
     if (!nk_incr) {
         hipLaunchKernelGGL(k_zero_u64_gated, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
                            (unsigned long long*)ctx->nk.p, K, gate);
@@ -1337,7 +1473,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (int*)ctx->nitems.p, cl_on ? (const unsigned*)nullptr : gate, (const int*)cl_need, cl_ibeg, cl_icnt);
     // (two passes over 4 B per point are latency bound: 8192 workgroups at N = 1e8 -- 0.23 -> 0.12 ms against 1024)
     int sb = (int)std::max<long long>(std::min<long long>(1024, (n + 1023) / 1024), std::min<long long>(8192, n / 4096));
-    if (const char* ev = getenv("SPKM_SCATTER_BLOCKS")) sb = std::max(1, std::min(atoi(ev), (int)((n + 1023) / 1024))); // tuning aid
     const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
     // (with the shortcut on the scatter is never gated either -- a cluster may need its part of the permutation again
     //  without any assignment having changed -- and places only the points of clusters that will be streamed)
@@ -1348,22 +1483,16 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         ctx->sort_K = K;
         ctx->sort_n = n;
         ctx->sort_seg = seg;
+        ctx->sort_perm_valid = true;
     }
     // 5. exact distance to the assigned centroid + per-cluster accumulation
     // 1 KB headroom: the kernel also has 384 B of static LDS (per-wave partial statistics)
     int pts = (int)std::min<size_t>(64, (ctx->lds_max - fixed_lds - 1024) / nw / per_pt);
     pts = std::max(8, pts & ~7);
-    if (const char* ev = getenv("SPKM_PTS")) pts = std::max(8, atoi(ev) & ~7);
     const size_t lds2 = fixed_lds + (size_t)nw * pts * per_pt;
-    int per_cu = 1;
-    if (const char* ev = getenv("SPKM_ACC_BLOCKS")) per_cu = std::max(1, atoi(ev));
-    const bool nt = getenv("SPKM_ACC_NT") != nullptr;
+    const int per_cu = 1;
     // 16 points' loads in flight per wave; 4 waves per SIMD (2 with 512-thread workgroups)
-    const void* k2 = threads == 512
-        ? (use_rec ? (nt ? (const void*)k_exact_accumulate<IR, 16, 2, true, true> : (const void*)k_exact_accumulate<IR, 16, 2, false, true>)
-                   : (nt ? (const void*)k_exact_accumulate<IR, 16, 2, true, false> : (const void*)k_exact_accumulate<IR, 16, 2, false, false>))
-        : (use_rec ? (nt ? (const void*)k_exact_accumulate<IR, 16, 4, true, true> : (const void*)k_exact_accumulate<IR, 16, 4, false, true>)
-                   : (nt ? (const void*)k_exact_accumulate<IR, 16, 4, true, false> : (const void*)k_exact_accumulate<IR, 16, 4, false, false>));
+    const void* k2 = use_rec ? (const void*)k_exact_accumulate<IR, 16, 4, false, true> : (const void*)k_exact_accumulate<IR, 16, 4, false, false>;
     HIP_TRY(allow_lds(ctx, (const void*)k2, lds2));
     const int ab = std::min(max_items, std::max(1, ctx->num_cus) * per_cu);
     // statistics: per workgroup (k_exact_accumulate) or per work item (k_exact_accumulate_rec)
@@ -1422,8 +1551,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                            (const int*)cl_icnt, (const double*)ctx->blk_obj.p, (const double*)ctx->blk_max.p,
                            (const long long*)ctx->blk_imax.p, cl_obj, cl_max, cl_imax, (double*)ctx->stats.p);
         sm->cl_valid = true;
+        sm->cl_stats_valid = true;
     } else {
         sm->cl_valid = false;
+        sm->cl_stats_valid = false;
         if (pipe) { // per-item statistics without the per-cluster stage: the items are simply reduced as blocks were
             // (nitems lives on the device; unused slots are not read: reduce over the items the plan emitted)
             hipLaunchKernelGGL(k_reduce_stats_n, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
@@ -1465,10 +1596,9 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     if (sm->nlist_pending && hipEventQuery(sm->ev_nlist) == hipSuccess) {
         sm->nlist_pending = false;
         ctx->last_listed = sm->h_nlist[0];
+        if (sm->mov_pending_valid) { sm->last_movers = sm->h_nlist[14]; sm->movers_known = true; }
         const double listed = (double)sm->h_nlist[0], ambig = (double)sm->h_nlist[1], nn = (double)s->n;
         if (listed > 0.05 * nn) sm->exact_cooldown = 8;
-        // explicit bounds for the largest movers: worth their pass until the plain test alone skips most steps
-        if (sm->skip_pending) sm->j_on = ((double)sm->h_nlist[3] - (double)sm->h_nlist[6]) < 0.5 * (nn / 16.0);
         // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed
         // (in cluster-contiguous order the failing points sit together and whole steps are as good)
         // (entered at 4x, left below 2.5x: the two forms leave slightly different bounds behind, and a choice that flips
@@ -1514,12 +1644,12 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     if (cooling) sm->exact_cooldown--;
     if (s->n > 0 && !cooling && screen_eligible(ctx, s, (int)K64)) {
         ctx->ev_valid = false;
-        int prune_a = getenv("SPKM_NO_PRUNE") ? 0 : sm->prune_next_a;
+        int prune_a = ctx->sw.no_prune ? 0 : sm->prune_next_a;
         // Hinted two-phase screen: when the unconditional two-phase form is not chosen and hints are not paused, the
         // screen compares the competition's partial sums with per-point upper bounds taken from the carried bounds
         // (run_screen / k_bounds_steps); needs this shard's previous call to have been a screen call.
-        const bool want_hint = prune_a == 0 && !getenv("SPKM_NO_PRUNE") && !getenv("SPKM_NO_HINT") &&
-                               sm->hint_cooldown == 0 && screen_use_quad(s);
+        const bool want_hint = prune_a == 0 && !ctx->sw.no_prune && !ctx->sw.no_hint &&
+                               sm->hint_cooldown == 0 && screen_use_quad(ctx, s);
         rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint, d_stats, d_nk_u64)
                                 : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint, d_stats, d_nk_u64);
         if (rc) return rc;
@@ -1536,6 +1666,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             sm->hint_pending = ctx->last_hinted;
             sm->hint_late_pending = ctx->last_hinted && ctx->last_hint_late;
             sm->skip_pending = ctx->last_skipping;
+            sm->mov_pending_valid = ctx->last_lib_valid;
         }
         return SPKM_OK; // (statistics and cluster sizes were handed over by run_screen's last kernel)
     }
@@ -1552,48 +1683,68 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
 
 template <typename IR>
 static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d_centers, double gamma,
-                         const int32_t* d_assign, double* d_mind)
+                         const int32_t* d_assign, double* d_mind, double* d_stats)
 {
     const int p = (int)s->p;
     const long long n = (long long)s->n;
     int rc;
-    // fast path: the counting sort kept from this shard's last fused call still describes d_assign (checked against
-    // the library's own copy of that assignment) and the record layout exists -> the pipelined exact pass without its
-    // sums (the same loads, the same storage-order additions)
+    if ((rc = ensure(ctx, ctx->stats, 4 * 8))) return rc;
+    // Streaming path: the pipelined exact pass without its sums (the same loads, the same storage-order additions) over a
+    // counting sort of d_assign -- the one kept from this shard's last fused call when it still describes d_assign
+    // (checked against the library's own copy of that assignment), else one made here (three small kernels).  Needs
+    // the record layout; per-item statistics give obj2 / the largest distance / its first index for d_stats.
     const long long npad = (n + 63) / 64 * 64;
     const int threads = 1024, nw = threads / 64;
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     const size_t fixed_lds = (size_t)p * 20 + 16;
-    bool fast = ctx->sort_owner == (const void*)s && ctx->sort_K == K && ctx->sort_n == n && s->rec && s->hb && s->hb_valid &&
-                s->hb_npad == npad && s->fixed_s > 0 && s->fixed_s <= 64 && fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
-    if (fast) {
-        if ((rc = ensure(ctx, ctx->nlist, 256))) return rc;
-        unsigned* cnt = (unsigned*)ctx->nlist.p + 20;
-        HIP_TRY(hipMemsetAsync(cnt, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_count_diff_i32, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const int*)d_assign, (const int*)(s->hb + 2 * npad), n, cnt);
-        unsigned diff = 1;
-        HIP_TRY(hipMemcpyAsync(&diff, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream)); // an end-of-run call, not the hot path
-        fast = diff == 0;
-    }
-    if (fast) {
-        const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4, false>; // (distance-only variant: no sums / counts)
-        const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
-        HIP_TRY(allow_lds(ctx, k3, lds3));
-        const int max_items = (int)(n / ctx->sort_seg) + K + 1;
-        const int ab = std::min(max_items, std::max(1, ctx->num_cus));
-        // the kept plan may cover only the clusters the last call had to process: plan all of them again (the
-        // permutation and the offsets stand; the scatter cursors it rewrites are not used any more)
-        hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
-                           ctx->sort_seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
-                           (int*)ctx->nitems.p, (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
-        if (ctx->sort_partial) { // ... and so may the kept permutation: place every point again
-            const int sb = (int)std::min<long long>(1024, (n + 1023) / 1024);
+    const bool stream_ok = s->rec && s->fixed_s > 0 && s->fixed_s <= 64 && K <= 16384 &&
+                           fixed_lds + (size_t)nw * 16 * per_pt + 1024 <= ctx->lds_max;
+    if (stream_ok) {
+        bool have_sort = ctx->sort_owner == (const void*)s && ctx->sort_perm_valid && ctx->sort_K == K && ctx->sort_n == n &&
+                         s->hb && s->hb_valid && s->hb_npad == npad;
+        if (have_sort) {
+            if ((rc = ensure(ctx, ctx->nlist, 256))) return rc;
+            unsigned* cnt = (unsigned*)ctx->nlist.p + 20;
+            HIP_TRY(hipMemsetAsync(cnt, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_count_diff_i32, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const int*)d_assign, (const int*)(s->hb + 2 * npad), n, cnt);
+            unsigned diff = 1;
+            HIP_TRY(hipMemcpyAsync(&diff, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream)); // an end-of-run call, not the hot path
+            have_sort = diff == 0;
+        }
+        const int seg = have_sort ? ctx->sort_seg : seg_points(n, ctx->num_cus);
+        const int max_items = (int)(n / seg) + K + 1;
+        const unsigned long long* nk_src = (const unsigned long long*)ctx->nk.p;
+        if (!have_sort) {
+            // a counting sort of the caller's assignment: histogram, plan, placement
+            ctx->sort_owner = nullptr;
+            if ((rc = ensure(ctx, ctx->dn_nk, (size_t)K * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->perm, (size_t)n * 4))) return rc;
+            if ((rc = ensure(ctx, ctx->offs, (size_t)(K + 1) * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
+            if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
+            HIP_TRY(hipMemsetAsync(ctx->dn_nk.p, 0, (size_t)K * 8, ctx->stream));
+            hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K * 4,
+                               ctx->stream, (const int*)d_assign, n, K, (unsigned long long*)ctx->dn_nk.p, (const unsigned*)nullptr);
+            nk_src = (const unsigned long long*)ctx->dn_nk.p;
+        }
+        // (a kept plan may cover only the clusters the last call had to process: plan all of them again -- the
+        //  permutation and the offsets stand; the scatter cursors it rewrites are used only when placing below)
+        hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, nk_src, K, seg, (long long*)ctx->offs.p,
+                           (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p, (int*)ctx->nitems.p,
+                           (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+        if (!have_sort || ctx->sort_partial) { // ... and so may the kept permutation: place every point (again)
+            const int sb = (int)std::max<long long>(std::min<long long>(1024, (n + 1023) / 1024), std::min<long long>(8192, n / 4096));
             const size_t sc_lds = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
             launch_scatter(ctx, sb, sc_lds, (const int*)d_assign, n, K, (const unsigned*)nullptr, (const int*)nullptr);
             ctx->sort_partial = false;
         }
+        const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4, false>; // (distance-only variant: no sums / counts)
+        const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
+        HIP_TRY(allow_lds(ctx, k3, lds3));
+        const int ab = std::min(max_items, std::max(1, ctx->num_cus));
         // scratch for the per-item statistics: the plan above emits at most n / seg + K + 1 items for THIS segment length
         if ((rc = ensure(ctx, ctx->blk_dff, (size_t)std::max(max_items, FIN_BLOCKS_MAX) * 24))) return rc;
         const char* a_rec = s->rec;
@@ -1611,6 +1762,12 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
         void* args[] = {&a_rec, &a_R, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s,
                         &a_mind, &a_ub, &a_sums, &a_counts, &a_bo, &a_bm, &a_bi};
         HIP_TRY(hipLaunchKernel(k3, dim3(ab), dim3(threads), args, lds3, ctx->stream));
+        if (d_stats) {
+            hipLaunchKernelGGL(k_reduce_stats_n, dim3(1), dim3(64), 0, ctx->stream, (const double*)a_bo, (const double*)a_bm,
+                               (const long long*)a_bi, (const int*)ctx->nitems.p, (double*)ctx->stats.p);
+            HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        HIP_TRY(hipGetLastError());
         return SPKM_OK;
     }
     if ((rc = ensure(ctx, ctx->ct, (size_t)p * K * 8))) return rc;
@@ -1619,19 +1776,40 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
     hipLaunchKernelGGL((k_point_distances<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K, n,
                        s->fixed_s, (const int*)d_assign, d_mind);
+    if (d_stats) {
+        // obj2, the largest distance and its first index from the distances just written (fixed reduction order)
+        const int cb = (int)std::min<long long>(COMBINE_BLOCKS, (n + 255) / 256);
+        if ((rc = ensure(ctx, ctx->blk_obj, (size_t)cb * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->blk_max, (size_t)cb * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->blk_imax, (size_t)cb * 8))) return rc;
+        hipLaunchKernelGGL(k_mind_stats, dim3(cb), dim3(256), 0, ctx->stream, (const double*)d_mind, n, (double*)ctx->blk_obj.p,
+                           (double*)ctx->blk_max.p, (long long*)ctx->blk_imax.p);
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_obj.p,
+                           (const double*)ctx->blk_max.p, (const long long*)ctx->blk_imax.p, cb, (double*)ctx->stats.p);
+        HIP_TRY(hipMemcpyAsync(d_stats, ctx->stats.p, 3 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     HIP_TRY(hipGetLastError());
     return SPKM_OK;
+}
+
+extern "C" int spkm_distances_stats_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const double* d_centers, double gamma,
+                                        const int32_t* d_assign, double* d_mind, double* d_stats)
+{
+    if (!ctx || !s || !d_centers || !d_assign || !d_mind) return SPKM_ERR_NULL_ARG;
+    if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (s->n == 0) {
+        if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
+        return SPKM_OK;
+    }
+    return s->ir_bits == 16 ? run_distances<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_stats)
+                            : run_distances<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_stats);
 }
 
 extern "C" int spkm_distances_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64, const double* d_centers, double gamma,
                                   const int32_t* d_assign, double* d_mind)
 {
-    if (!ctx || !s || !d_centers || !d_assign || !d_mind) return SPKM_ERR_NULL_ARG;
-    if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (s->n == 0) return SPKM_OK;
-    return s->ir_bits == 16 ? run_distances<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind)
-                            : run_distances<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind);
+    return spkm_distances_stats_dev(ctx, s, K64, d_centers, gamma, d_assign, d_mind, nullptr);
 }
 
 extern "C" int spkm_exact_pass_points(spkm_ctx* ctx, int64_t info[2])
@@ -1672,7 +1850,7 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         for (int j = 0; j < 4; j++) info[1 + j] = v[j];
         info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
         info[6] = v[6];
-        info[7] = v[7] ? 1 : (ctx->last_pt_mode ? 2 : 0); // 1: the jumper tile ran in the last call; 2: point-granular list
+        info[7] = ctx->last_pt_mode ? 2 : 0; // 2: point-granular list
     }
     return SPKM_OK;
 }

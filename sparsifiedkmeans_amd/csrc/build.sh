@@ -20,5 +20,7 @@ done
 rc=0
 for pid in "${pids[@]}"; do wait "$pid" || rc=1; done
 [ $rc -eq 0 ] || { echo "build.sh: a translation unit failed to compile" >&2; exit 1; }
-g++ -shared -o ../libspkm.so api.o sq_16_0.o sq_16_1.o sq_32_0.o sq_32_1.o -Wl,-z,undefs
+# SPKM_BUILD_OUT: write the library somewhere else (compile checks while a GPU job may be snapshotting the tree)
+OUT=${SPKM_BUILD_OUT:-../libspkm.so}
+g++ -shared -o "$OUT" api.o sq_16_0.o sq_16_1.o sq_32_0.o sq_32_1.o -Wl,-z,undefs
 rm -f api.o sq_16_0.o sq_16_1.o sq_32_0.o sq_32_1.o

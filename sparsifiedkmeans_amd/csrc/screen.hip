@@ -34,7 +34,12 @@
 #include "common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
-#define NJUMP 8      // centroids bounded explicitly when they move much more than the rest (k_pick_jumpers)
+// tail of a shard's bounds buffer (floats) behind ub[npad] | lb[npad] | assignment[npad]:
+//   delta[K] | dmax              drift of every centroid on a point's support (k_center_drift) and its maximum
+//   hterm[K] at HB_HTERM         hint_w x (full 2-norm drift)^2 per centroid: the hints' estimate, not a bound
+#define HB_KMAX 65536
+#define HB_HTERM (HB_KMAX + 16)
+#define HB_TAIL (2 * HB_KMAX + 32)
 
 // T32[g][r][kk] = -fl32(C[(g*32+kk)*p + r] / gamma), row p zero; cmax_bits = max |C/gamma| (f64 bits, atomicMax).
 // 4-lanes-per-point kernel only:
@@ -46,10 +51,8 @@
 //    q ^ ((r >> 1) & 3) (the kernel's stored row ids carry the same two bits, k_screen_reorder).
 __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
                                  float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits, int pl_last,
-                                 int swz, const int* __restrict__ kmap)
+                                 int swz)
 {
-    // kmap != nullptr (one narrow tile, G = 1, pl_last = 1): slot kk < NJUMP holds centroid kmap[kk] -- the tile of
-    // the centroids that moved most since the previous call (k_pick_jumpers)
     const size_t total = (size_t)G * (p + 1) * SCREEN_KT;
     double mx = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -66,7 +69,6 @@ __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int
         } else if (g == G - 1 && pl_last < 4) {
             kk &= 15;
             k = g * SCREEN_KT + kk;
-            if (kmap != nullptr) k = kk < NJUMP ? kmap[kk] : K;
         }
         float v = 0.f;
         if (r < p && k < K) {
@@ -431,18 +433,31 @@ __global__ __launch_bounds__(1024) void k_screen_tile(
 // and (ub + delta_a)(1+nu) < (lb - dmax)(1-nu) proves -- without touching the point -- that the reference's argmin
 // is unchanged (strictly: no tie).  A 16-point step whose points all pass is skipped by the screen; phase 2 still
 // evaluates every point's exact distance to its centroid and the sums, so every output stays exact.
-// Buffer layout (floats): ub[npad] | lb[npad] | a[npad] (int32) | delta[K] | dmax | flag   (npad = n rounded up to 64)
+// Buffer layout (floats): ub[npad] | lb[npad] | a[npad] (int32) | delta[K] | dmax | ... | hterm[K] at HB_HTERM
 //
 // delta_k (rounded up, f32) for all k; delta[K] = max (bit pattern atomicMax: the values are >= 0).
+// SUPPORT-AWARE DRIFT (top_s > 0: every point of the shard stores exactly top_s entries).  What the triangle inequality
+// needs is || (c'_k - c_k)/gamma ||_S for the point's support S, |S| = s, and for ANY set of s rows that is at most the
+// root of the sum of the s LARGEST squared entries of the difference -- a quantity of the centroid alone, about half of
+// the full 2-norm for a difference spread over p = 1024 rows at s = 51, and far below it once a centroid only moves in
+// a few coordinates.  Exact selection: the s-th largest square is found by a radix search over the high 32 bits of the
+// (non-negative) doubles, entries above it are added up, the rest of the s slots are charged the upper end of its
+// bucket -- an upper bound that is tight to 2^-20.  top_s <= 0 or >= p (ragged shards, SPKM_NO_SUPPORT_DRIFT): the
+// full 2-norm, as before.
 // The reference divides each entry by gamma in f64 first: 2^-50 (|c| + |c'|)/gamma covers those roundings.
+// hterm[k] = hint_w x (full 2-norm drift)^2: the screen's hints estimate sqrt(ub^2 + hterm) (k_bounds_steps) -- an
+// estimate of the typical support, not a bound, hence the full norm scaled by s / p.
 // same != nullptr: same[k] = 1 iff centroid k is BITWISE the one of the previous call (the unchanged-cluster shortcut of
 // the exact pass, k_cluster_need)
 __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__ prev, const double* __restrict__ cur,
                                                       int K, int p, double gamma, float* __restrict__ delta,
-                                                      int* __restrict__ same)
+                                                      int* __restrict__ same, int top_s, float hint_w,
+                                                      float* __restrict__ hterm)
 {
-    __shared__ double sh[3][4];
+    __shared__ double sh[4][4];
     __shared__ int s_diff;
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_prefix, s_need;
     const int k = blockIdx.x;
     const double g = gamma > 0.0 ? gamma : 1.0;
     double d2 = 0.0, a2 = 0.0, b2 = 0.0;
@@ -460,15 +475,62 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
     for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off); a2 += __shfl_down(a2, off); b2 += __shfl_down(b2, off); }
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = d2; sh[1][threadIdx.x >> 6] = a2; sh[2][threadIdx.x >> 6] = b2; }
     __syncthreads();
+    d2 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]; // (every thread: the full sums)
+    a2 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    b2 = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    double sel2 = d2; // sum of the top_s largest squared differences (upper bound); the full sum when not applicable
+    if (top_s > 0 && top_s < p && d2 > 0.0 && d2 < __builtin_inf()) { // (NaN / inf: the full norm, which fails every test)
+        // radix search, 8 bits at a time from the top, for the high word T of the top_s-th largest square:
+        // prefix = bits fixed so far, need = how many of the top_s are still to be found among the entries matching it
+        if (threadIdx.x == 0) { s_prefix = 0u; s_need = (unsigned)top_s; }
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            s_hist[threadIdx.x] = 0u;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            const unsigned mask_hi = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+            for (int r = threadIdx.x; r < p; r += blockDim.x) {
+                const double e = cur[(size_t)k * p + r] - prev[(size_t)k * p + r];
+                const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(e * e) >> 32);
+                if ((hi & mask_hi) == (prefix & mask_hi)) atomicAdd(&s_hist[(hi >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned need = s_need, b = 255u;
+                for (;; b--) { // from the largest digit down: the digit in which the need-th largest entry falls
+                    if (s_hist[b] >= need || b == 0u) break;
+                    need -= s_hist[b];
+                }
+                s_prefix = prefix | (b << shift);
+                s_need = need;
+            }
+            __syncthreads();
+        }
+        const unsigned T = s_prefix;  // high word of the top_s-th largest square
+        const unsigned ties = s_need; // how many entries with exactly this high word belong to the top_s
+        double above = 0.0;
+        for (int r = threadIdx.x; r < p; r += blockDim.x) {
+            const double e = cur[(size_t)k * p + r] - prev[(size_t)k * p + r];
+            const double e2 = e * e;
+            if ((unsigned)((unsigned long long)__double_as_longlong(e2) >> 32) > T) above += e2;
+        }
+        for (int off = 32; off > 0; off >>= 1) above += __shfl_down(above, off);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[3][threadIdx.x >> 6] = above;
+        __syncthreads();
+        above = sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3];
+        const double bucket_top = __longlong_as_double((long long)(((unsigned long long)T << 32) | 0xffffffffull));
+        sel2 = fmin(d2, above * (1.0 + 1e-12) + (double)ties * bucket_top);
+    }
     if (threadIdx.x == 0) {
-        d2 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-        a2 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-        b2 = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
-        const double d = (sqrt(d2) * (1.0 + 1e-9) + 0x1p-50 * (sqrt(a2) + sqrt(b2))) / g * (1.0 + 1e-9);
+        const double d = (sqrt(sel2) * (1.0 + 1e-9) + 0x1p-50 * (sqrt(a2) + sqrt(b2))) / g * (1.0 + 1e-9);
         float f = __double2float_ru(d);
         if (!(f >= 0.f)) f = __builtin_inff(); // NaN centres: nothing is skipped
         delta[k] = f;
         atomicMax(reinterpret_cast<unsigned*>(delta + K), __builtin_bit_cast(unsigned, f));
+        if (hterm) {
+            const float full = (float)(sqrt(d2) / g);
+            hterm[k] = hint_w * full * full;
+        }
         if (same) same[k] = s_diff ? 0 : 1;
     }
 }
@@ -477,140 +539,6 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
 // test (k_center_drift's comment) is settled here: assignment = the previous one, lower bound moved by the largest
 // drift.  Every other step is appended to todo[] (its index; order within the list does not matter) -- the list
 // the screen kernel and k_combine_screen iterate; counters[4] = length, counters[3] = steps skipped.
-// The carried bounds use ONE drift for "all other centroids"; while a few centres still jump and the rest have
-// settled, that single maximum keeps every point on the screen.  So the NJUMP largest movers are singled out:
-//     delta[K + 1] = largest drift among the others,  jlist = (int*)(delta + K + 2)[0..NJUMP),
-//     flags[7]     = 1 when that is worth it: the others' maximum is at most a quarter of the overall maximum.
-// A narrow screen tile over the jumpers (k_screen_quad on the list of steps the plain test left) then gives every
-// point a certified lower bound of its distance to each of them, and k_bounds_steps2 repeats the test with
-// min(lb - delta[K + 1], that bound).  One workgroup.
-__global__ __launch_bounds__(256) void k_pick_jumpers(float* __restrict__ delta, int K, unsigned* __restrict__ flags)
-{
-    __shared__ float sv[256];
-    __shared__ int si[256];
-    __shared__ int chosen[NJUMP];
-    int* jl = reinterpret_cast<int*>(delta + K + 2);
-    const int tid = threadIdx.x;
-    for (int r = 0; r <= NJUMP; r++) { // round NJUMP: the maximum of what is left
-        float bv = -1.f;
-        int bi = 0x7fffffff;
-        for (int k = tid; k < K; k += 256) {
-            bool taken = false;
-            for (int q = 0; q < r && q < NJUMP; q++) taken |= chosen[q] == k;
-            const float v = delta[k];
-            if (!taken && (v > bv || (v == bv && k < bi))) { bv = v; bi = k; }
-        }
-        sv[tid] = bv;
-        si[tid] = bi;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off && (sv[tid + off] > sv[tid] || (sv[tid + off] == sv[tid] && si[tid + off] < si[tid]))) {
-                sv[tid] = sv[tid + off];
-                si[tid] = si[tid + off];
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            if (r < NJUMP) { chosen[r] = si[0]; jl[r] = si[0] < K ? si[0] : 0; }
-            else {
-                const float rest = sv[0] >= 0.f ? sv[0] : 0.f, all = delta[K];
-                delta[K + 1] = rest;
-                flags[7] = (K >= 3 * NJUMP && all > 0.f && rest <= 0.25f * all) ? 1u : 0u; // false for NaN / inf rest
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// after k_bounds_steps: the jumper tile runs over the whole list of remaining steps, or -- when there are no
-// outliers among the drifts, or the first test left less than an eighth of the steps -- over nothing (decided here,
-// on the device: a host that queues many calls ahead sees the counters too late to decide)
-__global__ void k_jumper_list_length(unsigned* __restrict__ counters, int to, unsigned nsteps)
-{
-    const bool use = counters[7] != 0u && (unsigned long long)counters[4] * 8ull > nsteps;
-    counters[7] = use ? 1u : 0u;
-    counters[to] = use ? counters[4] : 0u;
-}
-__global__ void k_commit_list(unsigned* __restrict__ counters) { counters[4] = counters[20]; }
-
-// Second test of the steps on todo[] (16 threads per step), with the jumpers bounded by the narrow tile's result
-// m1J (smallest f32 estimate over the NJUMP jumpers; r - eps(r) is a certified lower bound of the distance to each of
-// them, k_combine_screen's error bound with the jumpers' own max |c|): steps that pass are settled as in
-// k_bounds_steps, the others go to todo2[] (length in counters[20]).  Without flags[7] every step goes to todo2.
-__global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, long long npad, long long n, int K,
-                                                       const int* __restrict__ todo, int* __restrict__ todo2,
-                                                       unsigned* __restrict__ counters, const float* __restrict__ m1J,
-                                                       const double* __restrict__ xn1, const double* __restrict__ xn2,
-                                                       const unsigned long long* __restrict__ cmaxJ_bits, int fixed_s,
-                                                       int* __restrict__ assign, const double* __restrict__ cum_in,
-                                                       const double* __restrict__ cum_out)
-{
-    // (lower bounds are stored relative to the accumulated drift: k_bounds_steps)
-    const double cum_prev = *cum_in, cum_now = *cum_out;
-    constexpr int CH = 1024; // steps per workgroup pass: one global atomic each
-    __shared__ int s_todo[CH];
-    __shared__ unsigned s_cnt, s_pos, s_skip;
-    const unsigned ntodo = counters[4];
-    if (counters[7] == 0u) { // nothing to bound explicitly: the list stays as it is
-        for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < ntodo; q += gridDim.x * 256u) todo2[q] = todo[q];
-        if (blockIdx.x == 0 && threadIdx.x == 0) counters[20] = ntodo;
-        return;
-    }
-    const float rest = bnd[3 * npad + K + 1];
-    const double cmax = __builtin_bit_cast(double, *cmaxJ_bits);
-    const double u = 0x1p-24, eu = (2.0 * u + u * u) * (1.0 + 1e-9), gacc = (double)(fixed_s + 1) * u * (1.0 + 1e-4),
-                 nu = 0x1p-45;
-    const int lane = threadIdx.x & 63;
-    for (unsigned c0 = blockIdx.x * CH; c0 < ntodo; c0 += gridDim.x * CH) {
-        if (threadIdx.x == 0) { s_cnt = 0; s_skip = 0; }
-        __syncthreads();
-        for (unsigned q0 = c0; q0 < c0 + CH && q0 < ntodo; q0 += 16) {
-            const unsigned q = q0 + (threadIdx.x >> 4);
-            const bool live = q < ntodo && q < c0 + CH;
-            const long long step = live ? todo[q] : 0;
-            const long long i = step * 16 + (threadIdx.x & 15);
-            bool keep = true;
-            float newlb = 0.f;
-            int ap = 0;
-            if (live && i < n) {
-                const float ubi = bnd[i], lbi = bnd[npad + i];
-                ap = reinterpret_cast<const int*>(bnd)[2 * npad + i];
-                const float da = bnd[3 * npad + ap];
-                const double W = (xn2[i] + 2.0 * cmax * xn1[i] + (double)fixed_s * cmax * cmax) * (1.0 + 1e-9);
-                const double E = eu * sqrt(W) * (1.0 + 1e-9);
-                const double r = sqrt((double)m1J[i]);
-                const double mj = (r - (E + gacc * r + 1e-20)) * (1.0 - nu);
-                const double lo = fmin(((double)lbi - cum_prev) - (double)rest, mj); // NaN mj: guarded below
-                keep = mj == mj && (double)(ubi + da) * 1.000001 < lo * 0.999999;
-                newlb = __double2float_rd(lo * (1.0 - 0x1p-20) + cum_now);
-            }
-            const unsigned long long b = __ballot(keep);
-            const unsigned grp = (unsigned)(b >> (lane & 48)) & 0xffffu;
-            const bool skip = live && grp == 0xffffu;
-            if (skip && i < n) {
-                assign[i] = ap;
-                bnd[npad + i] = newlb;
-            }
-            if (live && (threadIdx.x & 15) == 0) {
-                if (skip) atomicAdd(&s_skip, 1u);
-                else s_todo[atomicAdd(&s_cnt, 1u)] = (int)step;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_pos = s_cnt ? atomicAdd(counters + 20, s_cnt) : 0u;
-            if (s_skip) {
-                atomicAdd(counters + 3, s_skip);
-                atomicAdd(counters + 6, s_skip);
-                atomicAdd(reinterpret_cast<unsigned long long*>(counters + 8), (unsigned long long)s_skip);
-            }
-        }
-        __syncthreads();
-        for (unsigned j = threadIdx.x; j < s_cnt; j += 256) todo2[s_pos + j] = s_todo[j];
-        __syncthreads();
-    }
-}
-
 #define BOUNDS_SPAN 16384   // points per workgroup of k_bounds_steps (1024 steps)
 #define BOUNDS_SPAN_PT 4096 // ... when it lists points
 // pt_mode: the bounds are applied POINT BY POINT -- a point that passes keeps its assignment (and gets its lower
@@ -624,11 +552,15 @@ __global__ __launch_bounds__(256) void k_bounds_steps2(float* __restrict__ bnd, 
 __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
                                                       int* __restrict__ assign,
                                                       int* __restrict__ todo, unsigned* __restrict__ counters,
-                                                      float* __restrict__ hintu, int skip_enabled, float hint_w,
+                                                      float* __restrict__ hintu, int skip_enabled,
                                                       int pt_mode, const double* __restrict__ cum_in,
                                                       double* __restrict__ cum_out, int span,
-                                                      unsigned* __restrict__ blkstat)
+                                                      unsigned* __restrict__ blkstat, int erode)
 {
+    // erode != 0 (a call whose exact pass will not run: spkm_shard_set_lazy_stats, api.hip): a point that passes keeps
+    // its centroid but gets no fresh upper bound from anybody, so the bound is moved by its centroid's drift here,
+    // ub <- ub + delta_a rounded up (Hamerly's update).  A store only where the centroid moved at all: the members of
+    // settled clusters (delta_a = 0) are not written.
     // span: points per list flush (<= BOUNDS_SPAN_PT when points are listed, <= 16 BOUNDS_SPAN_PT for steps; a multiple
     // of 1024) -- the host shortens it on small shards so that every CU still gets several workgroups
     // Lower bounds are stored RELATIVE to the drift accumulated so far: bnd[npad + i] = lb_i + cum at the time lb_i was
@@ -640,8 +572,8 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     // hintu != nullptr: every point's ESTIMATE of its distance to its previous centroid under the NEW centroids --
     // the hint of the two-phase screen (k_screen_quad), what the competition's partial sums are compared with.  Not
     // the rigorous ub + delta_a (far too pessimistic: a centroid's move is almost orthogonal to x - c, and only its
-    // part on the point's support counts) but sqrt(ub^2 + hint_w delta_a^2), hint_w = 2 s / p: hints steer work,
-    // they prove nothing.  skip_enabled == 0: that is all this kernel does (SPKM_NO_BOUNDS).
+    // part on the point's support counts) but sqrt(ub^2 + hterm_a), hterm = (2 s / p) x (full-norm drift)^2
+    // (k_center_drift): hints steer work, they prove nothing.  skip_enabled == 0: that is all this kernel does (SPKM_NO_BOUNDS).
     // the steps that stay are collected per workgroup in LDS and appended with ONE global atomic, the skipped ones
     // counted per workgroup (wave-level atomics on one address cost ~8 ms at N = 1e8 when nothing can be skipped)
     __shared__ int s_todo[BOUNDS_SPAN_PT]; // >= BOUNDS_SPAN / 16
@@ -649,7 +581,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     const float dmx = bnd[3 * npad + K];
     // rounded UP explicitly: once cum is much larger than dmx the 1e-12 guard on dmx is below the rounding of the addition
     // itself, and cum must stay an upper bound of the total drift.  NaN / inf drift: nothing passes
-    const double cum_now = __dadd_ru(*cum_in, __dmul_ru((double)dmx, 1.0 + 1e-12));
+    // (x + |x| 2^-52 >= the next double above x: one ulp more than the rounded sum can have lost)
+    const double cum_rn = *cum_in + (double)dmx * (1.0 + 1e-12);
+    const double cum_now = cum_rn + fabs(cum_rn) * 0x1p-52;
     if (skip_enabled && blockIdx.x == 0 && threadIdx.x == 0) *cum_out = cum_now;
     const int lane = threadIdx.x & 63;
     unsigned nskip = 0, nkept = 0;
@@ -681,7 +615,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
 #pragma unroll
             for (int u = 0; u < UN; u++) {
                 const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
-                if (i < n) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
+                if (i < n) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
             }
         }
         if (!skip_enabled) continue;
@@ -692,9 +626,10 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const bool keep = !(i < n) || (double)(ubv[u] + dav[u]) * 1.000001 < ((double)lbv[u] - cum_now) * 0.999999; // false for NaN
             const unsigned long long b = __ballot(keep);
             nkept += (unsigned)__popcll(__ballot(keep && i < n));
+            if (erode && keep && i < n && dav[u] > 0.f) bnd[i] = __double2float_ru((double)ubv[u] + (double)dav[u]);
             if (pt_mode) {
                 if (keep && i < n && curv[u] != apv[u]) assign[i] = apv[u]; // (see the step mode below)
-                if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
+                if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
                 const unsigned long long lm = ~b; // (lanes past n count as kept)
                 if (lm) {
                     unsigned basepos = 0;
@@ -713,7 +648,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             // a caller that passes the same buffer call after call already holds this value: a 4-B read instead of a
             // 4-B store (a gigabyte of stores costs as much as several of loads here)
             if (skip && i < n && curv[u] != apv[u]) assign[i] = apv[u];
-            if (!skip && i < n && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + hint_w * dav[u] * dav[u]);
+            if (!skip && i < n && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
             const bool lead = (lane & 15) == 0 && live_step && !skip;
             const unsigned long long lm = __ballot(lead);
             if (lm) {
@@ -869,8 +804,18 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         const int* __restrict__ todo, int pt_mode,
                                                         const double* __restrict__ cum, int lib_valid,
                                                         int* __restrict__ touched, int K,
-                                                        unsigned long long* __restrict__ nk)
+                                                        unsigned long long* __restrict__ nk,
+                                                        int lazy, int* __restrict__ ev_pt, int* __restrict__ ev_k)
 {
+    // lazy != 0 (the exact pass will not run in this call, api.hip): a certified point's upper bound is written here,
+    // (r1 + eps1) rounded up -- rigorous, if a few 1e-6 looser than the exact distance the pass would have stored -- and
+    // every point that changes cluster is recorded as two EVENTS, (point, K + old cluster) and (point, new cluster), for
+    // the incremental update of the per-cluster sums (k_accumulate_events).  Events are staged in LDS and appended with
+    // one global atomic per ~1500 (half the points move in a run's first iterations: an atomic per wave on one address
+    // would take tens of milliseconds).  nlist[14] counts the movers in every mode, nlist[16] the events.
+    constexpr int EVCAP = 2048;
+    __shared__ int s_evp[EVCAP], s_evk[EVCAP];
+    __shared__ unsigned s_evn, s_evbase, s_mov;
     const double cum_now = cum ? *cum : 0.0; // lower bounds are stored relative to the accumulated drift (k_bounds_steps)
     // The library's own copy of the assignment (bnd + 2 npad) is kept up to date here and in k_assign_list -- the only
     // two places an assignment can change: a CERTIFIED point's new cluster is written at once; an uncertified one keeps
@@ -896,13 +841,25 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     const long long total = skipping ? (pt_mode ? (long long)nlist[4] : (long long)nlist[4] * 16) : n;
     __shared__ unsigned s_amb, s_chg;
     if ((long long)blockIdx.x * blockDim.x >= total) return; // (whole workgroup)
-    if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; }
+    if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; }
     if (nk) for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
     __syncthreads();
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-         q += (long long)gridDim.x * blockDim.x) {
-        const long long i = skipping ? (pt_mode ? (long long)todo[q] : (long long)todo[q >> 4] * 16 + (q & 15)) : q;
-        if (i >= n) continue;
+    unsigned nmov = 0;
+    auto flush_events = [&]() { // (whole workgroup)
+        if (threadIdx.x == 0) s_evbase = atomicAdd(nlist + 16, s_evn);
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < s_evn; j += blockDim.x) { ev_pt[s_evbase + j] = s_evp[j]; ev_k[s_evbase + j] = s_evk[j]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_evn = 0u;
+        __syncthreads();
+    };
+    for (long long q0 = (long long)blockIdx.x * blockDim.x; q0 < total; q0 += (long long)gridDim.x * blockDim.x) {
+      const long long q = q0 + threadIdx.x;
+      bool mover = false;
+      int mv_old = -1, mv_new = 0;
+      long long i = n;
+      if (q < total) i = skipping ? (pt_mode ? (long long)todo[q] : (long long)todo[q >> 4] * 16 + (q & 15)) : q;
+      if (i < n) {
         float b1 = __builtin_inff(), b2 = __builtin_inff();
         int bk = -1;
         for (int g = 0; g < G; g++) {
@@ -932,9 +889,12 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                     const bool vo = (unsigned)old < (unsigned)K;
                     if (touched) { if (vo) touched[old] = 1; touched[newk] = 1; }
                     if (nk) { if (vo) atomicAdd(&delta[old], -1); atomicAdd(&delta[newk], 1); }
+                    mover = true; mv_old = vo ? old : -1; mv_new = newk;
+                    nmov++;
                 }
             }
         }
+        if (lazy && certified && bnd) bnd[i] = __double2float_ru((r1 + e1) * (1.0 + nu) * (1.0 + 1e-12));
         if (lbv) lbv[i] = __double2float_rd((certified ? fmax(0.0, (r2 - e2) * (1.0 - nu)) : 0.0) + cum_now);
         if (!certified) {
             // one atomic per wave, not per point: atomics on one address are served one after the other (~12 ns each --
@@ -950,7 +910,30 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         // quarter of the rounds: 5x in the squares leaves a margin) 
         // could not separate; the host decides from this count whether the next call may use the two-phase screen
         if (!(r2 >= 2.25 * r1)) nambig++;
+      }
+      if (ev_pt) { // (every thread of the workgroup gets here in every trip)
+        const int cnt = mover ? (mv_old >= 0 ? 2 : 1) : 0;
+        // exclusive prefix of cnt inside the wave, one LDS atomic per wave for its total
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if ((int)(threadIdx.x & 63) >= off) incl += t; }
+        const int wtot = __shfl(incl, 63);
+        unsigned wbase = 0;
+        if (wtot) {
+            if ((threadIdx.x & 63) == 0) wbase = atomicAdd(&s_evn, (unsigned)wtot);
+            wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+        }
+        if (mover) {
+            unsigned at = wbase + (unsigned)(incl - cnt);
+            if (mv_old >= 0) { s_evp[at] = (int)i; s_evk[at] = K + mv_old; at++; }
+            s_evp[at] = (int)i; s_evk[at] = mv_new;
+        }
+        __syncthreads();
+        if (s_evn + 2u * 256u > (unsigned)EVCAP) flush_events();
+      }
     }
+    if (ev_pt) { __syncthreads(); if (s_evn) flush_events(); }
+    for (int off = 32; off > 0; off >>= 1) nmov += __shfl_down(nmov, off);
+    if ((threadIdx.x & 63) == 0 && nmov) atomicAdd(&s_mov, nmov);
     // per workgroup: with a short list nearly every wave holds an ambiguous point (the listed points ARE the ones near a
     // boundary), and one atomic per wave on one address took longer than the rest of the kernel
     for (int off = 32; off > 0; off >>= 1) nambig += __shfl_down(nambig, off);
@@ -960,6 +943,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     if (threadIdx.x == 0) {
         if (s_amb) atomicAdd(nlist + 1, s_amb);
         if (s_chg) atomicAdd(nlist + 5, 1u);
+        if (s_mov) atomicAdd(nlist + 14, s_mov);
     }
     if (nk)
         for (int k = threadIdx.x; k < K; k += blockDim.x)
@@ -975,10 +959,14 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      const unsigned int* __restrict__ nlist,
                                                      int* __restrict__ assign, int* __restrict__ alib, int lib_valid,
                                                      unsigned* __restrict__ changed, int* __restrict__ touched,
-                                                     unsigned long long* __restrict__ nk)
+                                                     unsigned long long* __restrict__ nk,
+                                                     float* __restrict__ ubv, int* __restrict__ ev_pt,
+                                                     int* __restrict__ ev_k, unsigned* __restrict__ counters)
 {
     // alib / lib_valid / touched / nk: the library's copy of the assignment and what follows from a change, as in
     // k_combine_screen (these points kept their previous value there); few points: global atomics
+    // ubv != nullptr (lazy calls): the point's upper bound = its exact distance, rounded up; ev_pt / ev_k: the two
+    // events of a point that changes cluster (k_combine_screen); counters[14] movers, counters[16] events
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -1025,15 +1013,22 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
         if (lane == 0) {
             if ((unsigned)bk >= (unsigned)K) bk = 0; // non-finite distances: MATLAB's min() gives index 1; never an out-of-range cluster
             assign[i] = bk;
+            if (ubv) ubv[i] = __double2float_ru(best * (1.0 + 1e-12)); // (inf / NaN: the point fails every later test)
             if (alib) {
                 const int old = lib_valid ? alib[i] : -1;
                 if (old != bk) {
                     alib[i] = bk;
                     if (lib_valid) {
                         atomicAdd(changed, 1u);
+                        atomicAdd(counters + 14, 1u);
                         const bool vo = (unsigned)old < (unsigned)K;
                         if (touched) { if (vo) touched[old] = 1; touched[bk] = 1; }
                         if (nk) { if (vo) atomicAdd(&nk[old], ~0ull); atomicAdd(&nk[bk], 1ull); }
+                        if (ev_pt) {
+                            const unsigned at = atomicAdd(counters + 16, vo ? 2u : 1u);
+                            if (vo) { ev_pt[at] = (int)i; ev_k[at] = K + old; }
+                            ev_pt[at + (vo ? 1u : 0u)] = (int)i; ev_k[at + (vo ? 1u : 0u)] = bk;
+                        }
                     }
                 }
             }
@@ -1043,11 +1038,14 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
 
 // gate != nullptr: the kernel does nothing when *gate == 0 (no assignment changed since the call whose counting sort
 // is still in the context's buffers -- spkm_assign_accumulate_dev)
+// n_dev != nullptr: the number of entries is *n_dev (an event list whose length only the device knows)
 __global__ __launch_bounds__(256) void k_hist(const int* __restrict__ assign, long long n, int K,
-                                              unsigned long long* __restrict__ nk, const unsigned* __restrict__ gate)
+                                              unsigned long long* __restrict__ nk, const unsigned* __restrict__ gate,
+                                              const unsigned* __restrict__ n_dev = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gate != nullptr && *gate == 0u) return;
+    if (n_dev != nullptr) n = (long long)*n_dev;
     unsigned int* hist = reinterpret_cast<unsigned int*>(smem);
     for (int k = threadIdx.x; k < K; k += blockDim.x) hist[k] = 0;
     __syncthreads();
@@ -1499,9 +1497,11 @@ template __global__ void k_screen_tile<unsigned short>(const unsigned short*, co
 template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const float*, const float*, int, int, int,
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*);
+    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
+    float*, int*, int*, unsigned*);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*);
+    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
+    float*, int*, int*, unsigned*);
 
 // ============================================================================================
 // K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through

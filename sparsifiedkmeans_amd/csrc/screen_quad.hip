@@ -6,6 +6,7 @@
 // Each TU exports one dispatcher, spkm_sq_kernel_<bits>_<pts>(rounds, a_rounds) -> kernel (host stub address).
 #include "common.h"
 #include "quad_steps.inc"
+#include <type_traits>
 
 #ifndef SPKM_SQ_IRBITS
 #error "build with -DSPKM_SQ_IRBITS=16|32 -DSPKM_SQ_PTS=0|1 (csrc/build.sh)"
@@ -64,7 +65,7 @@ __device__ __forceinline__ float quad_min_f32(float v)
     return v;
 }
 
-template <int NR, typename IR, int PL, int A, bool PTS>
+template <int NR, typename IR, int PL0, int A, bool PTS>
 __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, const float* __restrict__ xval, int p, int n,
                                                  int nv, int fixed_s, int K, const spkm_blockmap bm, int chunk_points,
                                                  float* __restrict__ m1o, float* __restrict__ m2o,
@@ -84,11 +85,16 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     // The two point pairs of a 16-lane LDS phase start on opposite halves of their rows (PL = 4), or read
     // different copies of a narrow tile's row (PL < 4).
     const bool swp = (ps & 2) != 0;
-    const int off0 = l4 * (PL == 1 ? 8 : 16) + (swp ? 64 : 0), off1 = l4 * 16 + (swp ? 0 : 64);
-    const bool tile_full = (PL >= 4 ? k0 + SCREEN_KT <= K : k0 + 8 * PL <= K) && (PL != 5 || extra_k0 + 4 <= K);
     // PL = 5: the lane's extra centroid extra_k0 + l4 sits in a table of 16-B rows at extra_base:
     // its address is (a >> 7) * 16 + ce for a = row * 128 + ...
     const int ce = extra_base + l4 * 4;
+    // ROTATING REMAINDER (PL0 = 5 with rot > 0, build_blockmap_quad's team layout): the <= 4 centroids that have no tile
+    // of their own are carried by the rot tiles IN TURN -- tile g carries them for the chunks ci of its team with
+    // ci % rot == g -- so that every tile costs the same per chunk: the workgroups of a team (one per tile, same XCD)
+    // stay in lock-step, a chunk is fetched from HBM once and met in L2 by the others, and the clock that this
+    // power-bound kernel sustains goes up with the halved traffic.  A step is then evaluated by the PL = 5 code when
+    // this tile carries its chunk's remainder and by the PL = 4 code otherwise.
+    const int rot = PL0 == 5 ? (bm.pad >> 24) & 0xff : 0;
     // todo != nullptr: only the steps listed there are processed (k_bounds_steps: the others were skipped on the
     // carried bounds); tickets and chunks then number the LIST -- nv = 16 x its length stands in for n
     const int nchunks = (nv + chunk_points - 1) / chunk_points;
@@ -180,6 +186,12 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             }
 #undef SPKM_QUAD_LOAD
 #undef SPKM_QUAD_LOAD_REC
+            auto evaluate_step = [&](auto pl_tag) {
+            constexpr int PL = decltype(pl_tag)::value;
+            // The two point pairs of a 16-lane LDS phase start on opposite halves of their rows (PL = 4), or read
+            // different copies of a narrow tile's row (PL < 4).
+            const int off0 = l4 * (PL == 1 ? 8 : 16) + (swp ? 64 : 0), off1 = l4 * 16 + (swp ? 0 : 64);
+            const bool tile_full = (PL >= 4 ? k0 + SCREEN_KT <= K : k0 + 8 * PL <= K) && (PL != 5 || extra_k0 + 4 <= K);
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; // two f32 sums each (bit pattern 0 = (0.f, 0.f))
             float acc4 = 0.f;                                       // PL = 5: the lane's extra centroid
             // the last round broadcasts only the nvl = fixed_s - 4 (NR - 1) entries the column still has
@@ -320,6 +332,13 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                 m2o[at] = none ? __builtin_inff() : m2;
                 ko[at] = none ? -1 : klo;
             }
+            }; // evaluate_step
+            if constexpr (PL0 == 5) {
+                // (t / R = the team's chunk counter: the same for the workgroups of a team, whatever the tile)
+                if (rot > 0 && (t / R) % rot != bm.tile) evaluate_step(std::integral_constant<int, 4>{});
+                else evaluate_step(std::integral_constant<int, 5>{});
+            } else
+                evaluate_step(std::integral_constant<int, PL0>{});
         }
     }
     // (per workgroup, not per wave: 4096 waves finishing together queued 4096 atomics on one address -- ~50 us at the

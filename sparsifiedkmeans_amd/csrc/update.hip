@@ -99,6 +99,47 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ part
         if (hist[k]) atomicAdd(&nk[k], (unsigned long long)hist[k]);
 }
 
+// Per-block statistics of a vector of distances (spkm_distances_stats_dev on shards without a record layout): the same
+// partials k_combine produces -- sum of squares, largest value, its first index -- over contiguous slabs.
+__global__ __launch_bounds__(256) void k_mind_stats(const double* __restrict__ mind, long long n,
+                                                    double* __restrict__ blk_obj2, double* __restrict__ blk_max,
+                                                    long long* __restrict__ blk_imax)
+{
+    __shared__ double s_obj[4], s_max[4];
+    __shared__ long long s_imax[4];
+    const int tid = threadIdx.x;
+    double obj2 = 0.0, dmax = -1.0;
+    long long imax = 0x7fffffffffffffffLL;
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = (lo + per < n) ? lo + per : n;
+    for (long long i = lo + tid; i < hi; i += blockDim.x) {
+        const double d = mind[i];
+        obj2 += d * d;
+        if (d > dmax) { dmax = d; imax = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        obj2 += __shfl_down(obj2, off);
+        const double om = __shfl_down(dmax, off);
+        const long long oi = __shfl_down(imax, off);
+        if (om > dmax || (om == dmax && oi < imax)) { dmax = om; imax = oi; }
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, m = -1.0;
+        long long im = 0x7fffffffffffffffLL;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+            o += s_obj[w];
+            if (s_max[w] > m || (s_max[w] == m && s_imax[w] < im)) { m = s_max[w]; im = s_imax[w]; }
+        }
+        blk_obj2[blockIdx.x] = o;
+        blk_max[blockIdx.x] = m;
+        blk_imax[blockIdx.x] = im;
+    }
+}
+
 // stats[0] = sum_b blk_obj2[b] (fixed order: lane-strided partials, then a fixed shuffle tree),
 // stats[1] = max mind, stats[2] = its first index (as double).  One wave.
 __global__ void k_reduce_stats(const double* __restrict__ blk_obj2, const double* __restrict__ blk_max,
@@ -228,8 +269,13 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restrict__ assign, long long n, int K,
                                                             unsigned long long* __restrict__ cursor,
                                                             int* __restrict__ perm, const unsigned* __restrict__ gate,
-                                                            const int* __restrict__ need)
+                                                            const int* __restrict__ need,
+                                                            const unsigned* __restrict__ n_dev = nullptr,
+                                                            const int* __restrict__ ids = nullptr)
 {
+    // n_dev != nullptr: the number of entries is *n_dev (an event list whose length only the device knows);
+    // ids != nullptr: entry i stands for point ids[i] (perm receives ids[i], not i)
+    if (n_dev != nullptr) n = (long long)*n_dev;
     // need != nullptr: only the points of clusters with need[k] != 0 are placed (the exact pass will not read the
     // others' part of the permutation: screen.hip, k_cluster_need); the rest of perm[] is then stale
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -276,7 +322,7 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
             r = (unsigned)__builtin_amdgcn_readfirstlane((int)first) + rank;
         } else
             r = atomicAdd(&cnt[k], 1u);
-        perm[base[k] + r] = (int)i;
+        perm[base[k] + r] = ids != nullptr ? ids[i] : (int)i;
     };
     if constexpr (VEC) {
         const long long hv = lo + ((hi - lo) & ~3LL); // whole groups of four
@@ -388,6 +434,109 @@ __global__ __launch_bounds__(256) void k_accumulate_sorted(const long long* __re
     }
 }
 
+// Incremental update of the per-cluster sums and counts (kmeans_sparsified.m:447-448's S and Cnt) by the points that
+// CHANGED cluster: an event (point, key) with key = k adds the point to cluster k, key = K + k takes it out.  The events
+// were sorted by key (k_hist / k_plan_segments / k_scatter_by_cluster over 2K keys), so a work item is a run of points
+// that enter -- or leave -- one cluster: accumulated in an LDS slab exactly as k_accumulate_sorted does, then added to
+// or subtracted from the cluster's row of the table with one f64 atomic per touched row.  Counts are integers held in
+// doubles: exact under + and -.  Sums pick up one rounding per update, relative to the table entry at that time -- the
+// same order of magnitude as the summation-order noise of a full pass (1e-16 relative per operation; bar: 1e-6).
+// A cluster no point entered or left is not touched at all: its sums, and with them its centroid, stay bitwise the same.
+// Fixed-stride shards only; rec != nullptr: the record layout (x | ir side by side), else the two arrays.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_accumulate_events(const char* __restrict__ rec, int R,
+                                                           const IR* __restrict__ ir, const double* __restrict__ x,
+                                                           const int* __restrict__ perm,
+                                                           const long long* __restrict__ offs,
+                                                           const int4* __restrict__ items,
+                                                           const int* __restrict__ nitems, int p, int s, int K,
+                                                           double* __restrict__ sums, double* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ssum = reinterpret_cast<double*>(smem);
+    unsigned int* scnt = reinterpret_cast<unsigned int*>(ssum + p);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    for (int item = blockIdx.x; item < *nitems; item += gridDim.x) {
+        const int4 it = items[item];
+        const int key = it.x;
+        const int k = key >= K ? key - K : key;
+        const double sign = key >= K ? -1.0 : 1.0;
+        const long long start = offs[key] + it.y;
+        const int len = it.z;
+        for (int r = tid; r < p; r += blockDim.x) { ssum[r] = 0.0; scnt[r] = 0u; }
+        __syncthreads();
+        for (int qb = wave * 64; qb < len; qb += nwaves * 64) {
+            const int have = (len - qb < 64) ? len - qb : 64;
+            int my_i = 0;
+            if (lane < have) my_i = perm[start + qb + lane];
+            for (int u = 0; u < have; u += 4) {
+                double xv[4];
+                int rv[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int src = (u + v < have) ? u + v : u;
+                    const long long i = (long long)(unsigned)__builtin_amdgcn_readlane(my_i, src);
+                    const bool ok = (u + v < have) && lane < s;
+                    if (rec != nullptr) {
+                        const char* b = rec + (size_t)i * (size_t)R;
+                        xv[v] = ok ? reinterpret_cast<const double*>(b)[lane] : 0.0;
+                        rv[v] = ok ? (int)reinterpret_cast<const IR*>(b + (size_t)s * 8)[lane] : -1;
+                    } else {
+                        xv[v] = ok ? x[i * s + lane] : 0.0;
+                        rv[v] = ok ? (int)ir[i * s + lane] : -1;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    if (rv[v] >= 0) {
+                        unsafeAtomicAdd(&ssum[rv[v]], xv[v]);
+                        atomicAdd(&scnt[rv[v]], 1u);
+                    }
+                    if (s > 64 && u + v < have) { // columns longer than one wave: the rest, 64 entries at a time
+                        const long long i = (long long)(unsigned)__builtin_amdgcn_readlane(my_i, u + v);
+                        for (int j = 64 + lane; j < s; j += 64) {
+                            double xe;
+                            int re;
+                            if (rec != nullptr) {
+                                const char* b = rec + (size_t)i * (size_t)R;
+                                xe = reinterpret_cast<const double*>(b)[j];
+                                re = (int)reinterpret_cast<const IR*>(b + (size_t)s * 8)[j];
+                            } else { xe = x[i * s + j]; re = (int)ir[i * s + j]; }
+                            unsafeAtomicAdd(&ssum[re], xe);
+                            atomicAdd(&scnt[re], 1u);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < p; r += blockDim.x) {
+            const unsigned int c = scnt[r];
+            if (c) {
+                unsafeAtomicAdd(&sums[(size_t)k * p + r], sign * ssum[r]);
+                unsafeAtomicAdd(&counts[(size_t)k * p + r], sign * (double)c);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// After the events: the call's sums and counts ARE the cache.  One repair on the way: a row of a cluster that no member
+// stores any more (count 0) must have the sum EXACTLY 0 -- a fresh summation gives that, an add-and-subtract history
+// leaves a residual of rounding noise, and kmeans_sparsified.m:448 divides it by 1e-16.
+__global__ __launch_bounds__(256) void k_sums_from_cache(double* __restrict__ cache_s, const double* __restrict__ cache_c,
+                                                         size_t pk, double* __restrict__ sums, double* __restrict__ counts)
+{
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pk; t += (size_t)gridDim.x * blockDim.x) {
+        const double c = cache_c[t];
+        double v = cache_s[t];
+        if (c == 0.0 && v != 0.0) { v = 0.0; cache_s[t] = 0.0; }
+        sums[t] = v;
+        counts[t] = c;
+    }
+}
+
 // centers(:,k) = (gamma*S(:,k)) ./ (Cnt(:,k) + 1e-16) for non-empty clusters (kmeans_sparsified.m:448);
 // empty clusters keep their old column (the host applies EmptyAction, :432-445).
 // blk_dff2[b] = partial sum of (old - new)^2, reduced in fixed order by k_reduce_dff.
@@ -444,8 +593,10 @@ __global__ void k_nk_to_f64(const unsigned long long* __restrict__ nk, int K, do
 __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, double* __restrict__ nk_f,
                             const double* __restrict__ stats, double* __restrict__ obj2, double* __restrict__ d_stats,
                             unsigned long long* __restrict__ d_nk, const unsigned* __restrict__ bstat, int bstat_n,
-                            unsigned* __restrict__ counters)
+                            unsigned* __restrict__ counters, int lazy = 0)
 {
+    // lazy != 0: this call did not evaluate the objective, the largest distance and its index (spkm_shard_set_lazy_stats):
+    // NaN in their places, so that a caller that reads them anyway cannot mistake them for values
     // bstat: (points kept, steps skipped) per workgroup of k_bounds_steps -> counters[12], counters[3] and the running
     // total at counters[8..9] (read by the host one call later)
     if (blockIdx.x == 0 && bstat_n > 0) {
@@ -470,8 +621,9 @@ __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, do
         nk_f[k] = (double)v;
         if (d_nk) d_nk[k] = v;
     }
-    if (k == 0) *obj2 = stats[0];
-    if (k < 3 && d_stats) d_stats[k] = stats[k];
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (k == 0) *obj2 = lazy ? nan : stats[0];
+    if (k < 3 && d_stats) d_stats[k] = lazy ? nan : stats[k];
 }
 
 template __global__ void k_accumulate_atomic<unsigned short>(const long long*, const unsigned short*, const double*,

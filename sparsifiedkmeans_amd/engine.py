@@ -60,6 +60,12 @@ class Shard:
                                                     C.byref(h)), "spkm_shard_create_dev")
         return cls(ctx, h, keep=(jc, ir, x))
 
+    def set_lazy_stats(self, on: bool = True):
+        """Allow fused calls without distances to leave obj2 / the largest distance unevaluated (NaN) and to move the
+        per-cluster sums by the points that changed cluster (spkm_shard_set_lazy_stats); LloydEngine.distances() then
+        delivers them for the iteration that needs them."""
+        _lib.check(_lib.lib().spkm_shard_set_lazy_stats(self.handle, 1 if on else 0), "spkm_shard_set_lazy_stats")
+
     def reset_policy(self):
         """New start / new replicate: drop the adaptive state of the fused call (spkm_shard_reset_policy)."""
         _lib.check(_lib.lib().spkm_shard_reset_policy(self.handle), "spkm_shard_reset_policy")
@@ -223,11 +229,13 @@ class LloydEngine:
 
     def distances(self, centers_used: torch.Tensor) -> torch.Tensor:
         """self.mind <- the reference's distance of every point to centroid self.assign[i] under ``centers_used``
-        (the centres the last assignment was computed with, i.e. BEFORE their update) -- spkm_distances_dev."""
+        (the centres the last assignment was computed with, i.e. BEFORE their update), and self.stats <- [sum of their
+        squares (LOCAL obj2), the largest, its first index] -- spkm_distances_stats_dev."""
         assert centers_used.dtype == torch.float64 and centers_used.is_contiguous() and tuple(centers_used.shape) == (self.K, self.p)
         g = self.gamma if self.unbiased else 0.0
-        _lib.check(_lib.lib().spkm_distances_dev(self.ctx.handle, self.shard.handle, self.K, _p(centers_used), g,
-                                                 _p(self.assign), _p(self.mind)), "spkm_distances_dev")
+        _lib.check(_lib.lib().spkm_distances_stats_dev(self.ctx.handle, self.shard.handle, self.K, _p(centers_used), g,
+                                                       _p(self.assign), _p(self.mind), _p(self.stats)),
+                   "spkm_distances_stats_dev")
         return self.mind
 
     def last_path_info(self) -> tuple[int, int]:

@@ -301,6 +301,12 @@ def kmeans_sparsified(X, K, **options):
             raise ValueError("X must be finite (Inf / NaN entries found)")
         shard = Shard.from_scipy(ctx, Y)
         nnz = Y.nnz
+    # obj = sqrt(sum(distances.^2)) is evaluated in every iteration (:471) but used only by Display='iter' (:472-475) and,
+    # after the loop, for the iteration that turned out to be the last (:489-503): unless it is displayed per iteration
+    # the library may leave it (and the exact pass that produces it) out of a fused call; it is then obtained on demand
+    # together with the distances (spkm_shard_set_lazy_stats, LloydEngine.distances)
+    lazy_stats = Display != "iter"
+    shard.set_lazy_stats(lazy_stats)
     if Display in ("iter", "final"):
         print(f"Randomly mixing of type {sk}")
         print(f"Randomly taking {100 * gamma:.1f}% of the data; actual dataset is {100 * nnz / (p2 * n):.1f}% sparse")
@@ -429,8 +435,17 @@ def kmeans_sparsified(X, K, **options):
             # ONE small device-to-host read per iteration: [dff^2 | obj^2 | cluster sizes]
             host = torch.cat([dff2_t, eng.reduce[2 * pk_ + Kc: 2 * pk_ + Kc + 1], eng.reduce[2 * pk_: 2 * pk_ + Kc]]).cpu().numpy()
             dff2, obj2, nk = float(host[0]), float(host[1]), host[2:]
-            obj = float(np.sqrt(obj2))                                           # sqrt(sum(distances.^2)) (:471)
             empty = np.flatnonzero(nk == 0)
+            if empty.size and np.isnan(obj2) and mind_pending:
+                # a lazy call (no objective, no largest distance) and EmptyAction is about to need them: this iteration's
+                # distances now, under the centres its assignment was computed with
+                eng.distances(old)
+                mind_pending, dist_t = False, eng.mind
+                o2 = eng.stats[0:1].clone()
+                if dist_on:
+                    torch.distributed.all_reduce(o2, op=torch.distributed.ReduceOp.SUM)
+                obj2 = float(o2.item())
+            obj = float(np.sqrt(obj2))                                           # sqrt(sum(distances.^2)) (:471); NaN: not evaluated yet
             dropped = False
             if empty.size:
                 warnings.warn("cluster has lost all its members")                # :433
@@ -473,15 +488,21 @@ def kmeans_sparsified(X, K, **options):
                 break                                                            # :476-478
             if not np.isfinite(dff2) and bool(torch.isnan(centers).any().item()):
                 raise RuntimeError("Found NaN in centers")                       # :480-484 (a NaN centre makes dff NaN)
+        last_path = eng.last_path_info()[0] if fused_iters else 0
+        if its > 0 and mind_pending:
+            eng_used.distances(centers_used)                                     # `distances` of the last iteration (:420)
+            dist_t = eng_used.mind
+            if np.isnan(obj):                                                    # ... and its objective (:471), left out by a lazy call
+                o2 = eng_used.stats[0:1].clone()
+                if dist_on:
+                    torch.distributed.all_reduce(o2, op=torch.distributed.ReduceOp.SUM)
+                obj = float(np.sqrt(o2.item()))
         OUTPUT["replicateTimes"][trial] = time.time() - t1
         OUTPUT["stoppingDiff"][trial], OUTPUT["objectives"][trial], OUTPUT["iterations"][trial] = dff, obj, its
         # (not reference fields) how many iterations went through the fused call, and which path the library took for
         # the last of them: 1 = certified screen + exact confirmation, 0 = all-exact kernels
         OUTPUT.setdefault("fusedIterations", np.zeros(Replicates, int))[trial] = fused_iters
-        OUTPUT.setdefault("lastPath", np.zeros(Replicates, int))[trial] = eng.last_path_info()[0] if fused_iters else 0
-        if its > 0 and mind_pending:
-            eng_used.distances(centers_used)                                     # `distances` of the last iteration (:420)
-            dist_t = eng_used.mind
+        OUTPUT.setdefault("lastPath", np.zeros(Replicates, int))[trial] = last_path
         distances = dist_t.cpu().numpy()
         if obj < best["obj"]:                                                    # :493-503
             best = dict(obj=obj, K=Kc, centers=centers.clone(),

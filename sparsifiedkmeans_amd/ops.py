@@ -29,6 +29,10 @@ class Context:
     def sync(self):
         _lib.check(_lib.lib().spkm_ctx_sync(self.handle), "spkm_ctx_sync")
 
+    def reload_switches(self):
+        """re-read the SPKM_* A/B switches from the environment (they are read once, when the context is created)"""
+        _lib.check(_lib.lib().spkm_ctx_reload_switches(self.handle), "spkm_ctx_reload_switches")
+
     def device_info(self) -> dict:
         a = (C.c_int64 * 4)()
         _lib.check(_lib.lib().spkm_device_info(self.handle, a))

@@ -29,3 +29,13 @@ def gpu_ctx():
     from sparsifiedkmeans_amd.engine import torch_context
 
     return torch_context(0)
+
+
+@pytest.fixture(autouse=True)
+def _restore_switches(request, monkeypatch):
+    """after every -m gpu test: environment back to what it was, and the session context's switches re-read"""
+    yield
+    if request.node.get_closest_marker("gpu") is None or "gpu_ctx" not in request.fixturenames:
+        return
+    monkeypatch.undo()
+    request.getfixturevalue("gpu_ctx").reload_switches()

@@ -15,6 +15,8 @@ import numpy as np
 import pytest
 import torch
 
+from util import set_switch
+
 pytestmark = pytest.mark.gpu
 
 
@@ -39,20 +41,20 @@ def workload(gpu_ctx):
     centers0[:, :p] = c0
     from sparsifiedkmeans_amd.engine import mix_device
     centers0 = mix_device(gpu_ctx, centers0, d["p2"], d["sign"], 1.0, sq)
-    return dict(n=n, K=K, p2=d["p2"], gamma=d["gamma"], shard=shard, centers0=centers0, keep=d)
+    return dict(n=n, K=K, p2=d["p2"], gamma=d["gamma"], shard=shard, centers0=centers0, keep=d, ctx=gpu_ctx)
 
 
 def _one_pass(w, centers, no_screen):
     from sparsifiedkmeans_amd.engine import LloydEngine
     if no_screen:
-        os.environ["SPKM_NO_SCREEN"] = "1"
+        set_switch(None, w["ctx"], "SPKM_NO_SCREEN")
     try:
         eng = LloydEngine(w["shard"], w["K"], w["gamma"])
         eng.assign_accumulate_step(centers)
         torch.cuda.synchronize()
         path, listed = eng.last_path_info()
     finally:
-        os.environ.pop("SPKM_NO_SCREEN", None)
+        set_switch(None, w["ctx"], "SPKM_NO_SCREEN", False)
     return eng, path, listed
 
 
@@ -122,12 +124,12 @@ def test_lloyd_run_with_every_layer_equals_exact_kernels_each_iteration(workload
         m = eng.last_screen_mode()
         forms.append(m[0])
         skipped.append(m[4])
-        os.environ["SPKM_NO_SCREEN"] = "1"
+        set_switch(None, w["ctx"], "SPKM_NO_SCREEN")
         try:
             exact.assign_accumulate_step(c_in)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("SPKM_NO_SCREEN", None)
+            set_switch(None, w["ctx"], "SPKM_NO_SCREEN", False)
         assert exact.last_path_info()[0] == 0
         assert torch.equal(eng.assign, exact.assign), f"iteration {it}"
         assert torch.equal(eng.mind, exact.mind), f"iteration {it}"

@@ -107,7 +107,7 @@ def test_counting_sort_with_n_not_a_multiple_of_four(gpu_ctx, oracle, n, fused):
     import scipy.sparse as sp
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
 
-    p, s, K, gamma = 64, 3, 5, 3 / 64
+    p, s, K, gamma = 32, 3, 5, 3 / 32
     rng = np.random.default_rng(n)
     rows = np.sort(np.argsort(rng.random((n, p)), axis=1)[:, :s], axis=1)          # s distinct ascending rows per point
     vals = rng.standard_normal((n, s)) * 2.0

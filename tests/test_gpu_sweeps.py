@@ -6,7 +6,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from util import parts, random_csc, sample_rows_reference
+from util import parts, random_csc, sample_rows_reference, set_switch
 
 pytestmark = pytest.mark.gpu
 
@@ -205,8 +205,6 @@ def test_screen_equals_exact_kernels_midsize(gpu_ctx, seed, monkeypatch):
     """1e5 .. 6e5 points (many chunks per workgroup, ragged last chunk, every tile / round variant by chance):
     the screen path against the all-exact kernels, every point, bit for bit.  No CPU oracle at this size."""
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
-    if seed % 2:
-        monkeypatch.setenv("SPKM_JUMPERS", "1")                 # the opt-in explicit bounds for the largest movers too
     rng = np.random.default_rng(9000 + seed)
     p = int(rng.choice([64, 128, 256, 512, 1000, 1024]))
     s = int(rng.integers(1, min(64, p) + 1))
@@ -234,7 +232,7 @@ def test_screen_equals_exact_kernels_midsize(gpu_ctx, seed, monkeypatch):
     e1.assign_accumulate_step(centers)
     torch.cuda.synchronize()
     assert e1.last_path_info()[0] == 1
-    monkeypatch.setenv("SPKM_NO_SCREEN", "1")
+    set_switch(monkeypatch, gpu_ctx, "SPKM_NO_SCREEN")
     e0 = LloydEngine(shard, K, gamma)
     e0.assign_accumulate_step(centers)
     torch.cuda.synchronize()
@@ -277,17 +275,17 @@ def test_adaptive_policy_soak(gpu_ctx, monkeypatch):
         else:
             c = torch.randn(planted.shape, generator=g, device="cuda", dtype=torch.float64) * 0.05   # everything ambiguous
         c = c.contiguous()
-        os.environ.pop("SPKM_NO_SCREEN", None)
+        set_switch(None, gpu_ctx, "SPKM_NO_SCREEN", False)
         eng.assign_accumulate_step(c)
         torch.cuda.synchronize()
         path, listed = eng.last_path_info()
         ra, rn = eng.last_screen_rounds()
         modes.add("exact" if path == 0 else ("two-phase" if ra < rn else "plain"))
         skipped += eng.last_screen_mode()[4]
-        os.environ["SPKM_NO_SCREEN"] = "1"
+        set_switch(None, gpu_ctx, "SPKM_NO_SCREEN")
         ref.assign_accumulate_step(c)
         torch.cuda.synchronize()
-        os.environ.pop("SPKM_NO_SCREEN", None)
+        set_switch(None, gpu_ctx, "SPKM_NO_SCREEN", False)
         assert torch.equal(eng.assign, ref.assign), f"call {it}"
         assert torch.equal(eng.mind, ref.mind), f"call {it}"
     assert "two-phase" in modes and "plain" in modes           # the policy really moved between modes

@@ -96,3 +96,21 @@ def mix_start(oracle, S, d, p2):
     Z = np.zeros((p2, K))
     Z[:p] = S.T
     return oracle.fwht(Z * d[:, None]) / np.sqrt(np.float64(p2))
+
+
+def set_switch(monkeypatch, ctx, name, on=True):
+    """Toggle one of the library's SPKM_* A/B switches for the rest of the test: the environment variable AND the
+    context's copy (the library reads its switches once, in spkm_ctx_create; spkm_ctx_reload_switches).  conftest's
+    autouse fixture restores both after the test.  monkeypatch = None: plain os.environ (module-scoped fixtures)."""
+    import os
+
+    if monkeypatch is not None:
+        if on:
+            monkeypatch.setenv(name, "1")
+        else:
+            monkeypatch.delenv(name, raising=False)
+    elif on:
+        os.environ[name] = "1"
+    else:
+        os.environ.pop(name, None)
+    ctx.reload_switches()

@@ -30,10 +30,12 @@ for it in range(iters):
 print("list modes per call (2 = point list):", modes)
 a_fused, d_fused = eng.assign.clone(), eng.mind.clone()
 os.environ["SPKM_NO_SCREEN"] = "1"
+ctx.reload_switches()
 ex = LloydEngine(shard, K, gamma)
 ex.assign_accumulate_step(used)
 torch.cuda.synchronize()
 os.environ.pop("SPKM_NO_SCREEN")
+ctx.reload_switches()
 assert ex.last_path_info()[0] == 0
 na = int((a_fused != ex.assign).sum().item()); nd = int((d_fused != ex.mind).sum().item())
 print(f"N = {n}: assignments differing from the all-exact kernels: {na}; distances differing: {nd}")

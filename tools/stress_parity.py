@@ -27,14 +27,16 @@ while time.time() < t_end:
     noise = float(rng.choice([0.1, 0.3, 0.6]))
     shuffled = bool(rng.integers(0, 2))
     iters = int(rng.integers(6, 26))
-    # the library's A/B switches (read at call time; none may change an output): each on in about one case of six
-    switches = ["SPKM_NO_REC", "SPKM_NO_REC_PIPE", "SPKM_NO_CLUSTER_SKIP", "SPKM_NO_POINT_LIST", "SPKM_NO_LATE_SPLIT",
-                "SPKM_PTS_NO_REC", "SPKM_NO_HINT", "SPKM_NO_PRUNE", "SPKM_NO_BOUNDS", "SPKM_NO_SORT_REUSE", "SPKM_NO_FUSE"]
+    # the library's A/B switches (none may change an output): each on in about one case of six
+    switches = ["SPKM_NO_REC", "SPKM_NO_CLUSTER_SKIP", "SPKM_NO_POINT_LIST", "SPKM_NO_LATE_SPLIT", "SPKM_NO_INCREMENTAL",
+                "SPKM_PTS_NO_REC", "SPKM_NO_HINT", "SPKM_NO_PRUNE", "SPKM_NO_BOUNDS", "SPKM_NO_SORT_REUSE", "SPKM_NO_FUSE",
+                "SPKM_NO_SUPPORT_DRIFT"]
     on = [w for w in switches if rng.random() < 1 / 6]
     for w in switches:
         os.environ.pop(w, None)
     for w in on:
         os.environ[w] = "1"
+    ctx.reload_switches()                                    # (the library reads its switches once per context)
     X, centres, labels = synth.gmm_dense(p, n, K, seed=int(rng.integers(1 << 30)), noise=noise)
     if shuffled:
         X = X[:, rng.permutation(n)]
@@ -47,6 +49,9 @@ while time.time() < t_end:
     eng = LloydEngine(shard, K, gam)
     c = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
     want_mind = bool(rng.integers(0, 2))
+    lazy = bool(rng.integers(0, 2))                          # lazy statistics: incremental sums once few points move
+    shard.set_lazy_stats(lazy)
+    on = on + (["lazy"] if lazy else [])
     ok = True
     for it in range(iters):
         used = c.cpu().numpy().T.copy()
@@ -65,12 +70,19 @@ while time.time() < t_end:
         Cnt = (Yones @ ind.T).toarray()
         refc = np.where(np.bincount(ra, minlength=K)[None, :] > 0, gam * S / (Cnt + 1e-16), used)
         scale = max(1e-300, np.abs(refc).max())
+        # objective of the call: the oracle's, or NaN when a lazy call left it out
+        o2 = float(eng.out[1].item())
+        if not (np.isnan(o2) and lazy and not want_mind) and abs(o2 - np.sum(rd * rd)) > 1e-9 * np.sum(rd * rd):
+            ok = False; print("OBJECTIVE MISMATCH", dict(p=p, n=n, K=K, s=s, it=it, on=on, got=o2, want=float(np.sum(rd * rd)))); break
         if np.abs(got - refc).max() > 1e-9 * scale:
             ok = False; print("CENTRE MISMATCH", dict(p=p, n=n, K=K, s=s, it=it, on=on, err=np.abs(got - refc).max() / scale)); break
     if ok and not want_mind:
         eng.distances(torch.tensor(np.ascontiguousarray(used.T), device="cuda"))
         if not np.array_equal(eng.mind.cpu().numpy(), rd):
             ok = False; print("DISTANCES-ON-DEMAND MISMATCH", dict(p=p, n=n, K=K, s=s, on=on))
+        st = eng.stats.cpu().numpy()
+        if abs(st[0] - np.sum(rd * rd)) > 1e-9 * np.sum(rd * rd) or st[1] != rd.max() or int(st[2]) != int(np.argmax(rd)):
+            ok = False; print("STATS-ON-DEMAND MISMATCH", dict(p=p, n=n, K=K, s=s, on=on, st=st.tolist()))
     cases += 1; fails += (not ok)
     del shard, eng
 print(f"{cases} random cases, {fails} failures")
