@@ -1222,10 +1222,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // Incremental call (spkm_shard_set_lazy_stats; SPKM_NO_INCREMENTAL=1: A/B switch): no exact pass -- the per-cluster
         // sums are moved by the points that change cluster (events), upper bounds come from the screen's certificate.
         // Needs the caller's permission (lazy, no distances asked for), the library's previous assignment and sums
-        // (kept, cl_valid), and pays while few points move: the previous counted call saw at most a sixth of them change
-        // (an event pair reads the point twice, through a gather).  Whatever is chosen, the sums are the members' sums.
+        // (kept, cl_valid), and pays while not too many points move: the previous counted call saw at most a third of them
+        // change (an event pair reads the point twice, through a gather: 0.2 ms per million movers at s = 51 against
+        // 10.4 ms for a full pass over 1e8 points).  Whatever is chosen, the sums are the members' sums.
         ev_path = sm->lazy && d_mind == nullptr && kept && sm->cl_valid && !ctx->sw.no_incremental &&
-                  !ctx->sw.no_sort_reuse && sm->movers_known && sm->last_movers * 6 <= (unsigned long long)n &&
+                  !ctx->sw.no_sort_reuse && sm->movers_known && sm->last_movers * 3 <= (unsigned long long)n &&
                   (size_t)p * 12 <= 64 * 1024;
         if (ev_path && sm->ev_cap < (size_t)2 * n) {
             if (sm->ev_pt) (void)hipFree(sm->ev_pt);
