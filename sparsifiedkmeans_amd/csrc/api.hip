@@ -1224,9 +1224,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // Needs the caller's permission (lazy, no distances asked for), the library's previous assignment and sums
         // (kept, cl_valid), and pays while not too many points move: the previous counted call saw at most a third of them
         // change (an event pair reads the point twice, through a gather: 0.2 ms per million movers at s = 51 against
-        // 10.4 ms for a full pass over 1e8 points).  Whatever is chosen, the sums are the members' sums.
+        // 10.4 ms for a full pass over 1e8 points); no count yet (a run's second call): taken as few -- at worst every
+        // point moves and the events cost what the full pass would have.  Whatever is chosen, the sums are the members' sums.
         ev_path = sm->lazy && d_mind == nullptr && kept && sm->cl_valid && !ctx->sw.no_incremental &&
-                  !ctx->sw.no_sort_reuse && sm->movers_known && sm->last_movers * 3 <= (unsigned long long)n &&
+                  !ctx->sw.no_sort_reuse && (!sm->movers_known || sm->last_movers * 3 <= (unsigned long long)n) &&
                   (size_t)p * 12 <= 64 * 1024;
         if (ev_path && sm->ev_cap < (size_t)2 * n) {
             if (sm->ev_pt) (void)hipFree(sm->ev_pt);
@@ -1418,7 +1419,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         if ((rc = ensure(ctx, ctx->cursor, (size_t)K2 * 8))) return rc;
         if ((rc = ensure(ctx, ctx->items, (size_t)max_items_ev * 16))) return rc;
         // (sized by what usually moves, not by the worst case: every kernel strides over the device-side count)
-        const long long ev_est = std::max<long long>(4096, (long long)std::min<unsigned long long>(4 * sm->last_movers + 4096, (unsigned long long)2 * n));
+        const long long ev_est = std::max<long long>(4096, (long long)std::min<unsigned long long>(sm->movers_known ? 4 * sm->last_movers + 4096 : (unsigned long long)n, (unsigned long long)2 * n));
         const int hb_ = (int)std::min<long long>(1024, (ev_est + 1023) / 1024);
         hipLaunchKernelGGL(k_hist, dim3(hb_), dim3(256), (size_t)K2 * 4, ctx->stream, (const int*)sm->ev_k, (long long)0, K2,
                            (unsigned long long*)ctx->nk_ev.p, (const unsigned*)nullptr, ev_n);

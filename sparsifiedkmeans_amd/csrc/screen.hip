@@ -494,14 +494,21 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
                 if ((hi & mask_hi) == (prefix & mask_hi)) atomicAdd(&s_hist[(hi >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned need = s_need, b = 255u;
-                for (;; b--) { // from the largest digit down: the digit in which the need-th largest entry falls
-                    if (s_hist[b] >= need || b == 0u) break;
-                    need -= s_hist[b];
-                }
-                s_prefix = prefix | (b << shift);
-                s_need = need;
+            {
+                // the digit in which the need-th largest entry falls: the largest b whose suffix count (entries with digit
+                // >= b) reaches `need`.  Thread b owns bin b; suffix sums by a shuffle scan per wave + the totals of the
+                // waves above (one thread walking 256 bins paid an LDS latency per bin: 46 us per call for four passes)
+                const unsigned need = s_need;
+                const unsigned h = s_hist[threadIdx.x];
+                const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+                unsigned suf = h;
+                for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_down(suf, off); if (ln + off < 64) suf += t; }
+                __shared__ unsigned s_wtot[4];
+                if (ln == 0) s_wtot[wv] = suf;
+                __syncthreads();
+                for (int w = wv + 1; w < 4; w++) suf += s_wtot[w];
+                const unsigned suf_next = suf - h; // entries with a larger digit
+                if (suf >= need && suf_next < need) { s_prefix = prefix | ((unsigned)threadIdx.x << shift); s_need = need - suf_next; }
             }
             __syncthreads();
         }
