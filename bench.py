@@ -242,13 +242,30 @@ def main():
     nnz_local = int(shard.nnz)
     # algorithmic bytes of one Lloyd iteration over this GPU's points ...
     b_iter = nnz_local * 12 + (n_local + 1) * 8 + n_local * 12 + 24 * p2 * K
+    # ... of which the assignment kernel is credited what IT moves when that is less: on single-tile shapes (K <= 32) the
+    # screen reads its own f32 / u16 copy of a point (6 B per stored-entry slot) and writes 12 B per point -- about half
+    # of SURVEY 8(d)'s 632 B -- so crediting it with the whole iteration would report more than the memory system moved
+    tiles = (K + 31) // 32
+    b_screen_own = n_local * (((s + 3) // 4) * 4 * 6 + 12 * tiles) + tiles * (p2 + 1) * 32 * 4
+    b_screen = min(b_iter, b_screen_own) if tiles == 1 else b_iter
     # ... and of the exact accumulation pass alone: values + row ids once, the sort permutation in (4 B), the library's
     # upper bound out (4 B; the 8-B min-distance is stored on demand only, once per run), the per-cluster sums and counts out
     b_acc = nnz_local * (8 + irb) + n_local * 8 + 16 * p2 * K
     steps_per_tile = (n_local + 15) // 16
 
+    # host copies for the CPU legs are taken now: the shard's CSC arrays are about to be released
+    cpu_data = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload != "config5":
+        cpu_data = cpu_sample_arrays(data, centers0, s, min(max(args.cpu_sample, 4_000_000), n_local))
     loop = Loop(shard, centers0)
-    loop.steps(args.warmup)
+    loop.steps(max(args.warmup, 1))                 # (at least one call: it builds the shard's record layout and screen copy)
+    # from here on the record layout is the only copy of the exact entries (spkm_shard_release_csc): 53 GB of the
+    # 146 GB a 1e8-point shard and its layouts occupy go back to the allocator
+    csc_released = shard.release_csc() if not os.environ.get("SPKM_BENCH_KEEP_CSC") else False
+    if csc_released:
+        data.pop("x", None)
+        data.pop("ir", None)
+        torch.cuda.empty_cache()
     loop.restart()                                  # the timed steps start a run, whatever W was
     loop.runs_completed, loop.run_lengths = 0, []
     skipped0 = loop.eng.last_screen_mode()[5] if args.warmup > 0 else 0   # running total of steps skipped so far
@@ -282,24 +299,30 @@ def main():
     # centroid did not move are not streamed again): it is credited with that share of its bytes only
     acc_share = (eng.exact_pass_points()[0] - acc_pts0) / (n_local * args.steps) if path == 1 and n_local else 1.0
     scr_name = dominant_kernel(path, s)
-    rl_screen = roofline_obj(scr_name, screen_ms, int(b_iter * done),
+    rl_screen = roofline_obj(scr_name, screen_ms, int(b_screen * done),
                              f"assignment kernel; mean over the timed launches, which processed {done:.3f} of their 16-point "
-                             "steps (the rest skipped on carried bounds; SURVEY 8(d) bytes of an iteration scaled by that "
-                             "share).  VALU-issue / LDS bound at K=100, not HBM bound (DESIGN.md section 4)")
+                             "steps (the rest skipped on carried bounds; "
+                             + ("SURVEY 8(d) bytes of an iteration" if b_screen == b_iter else
+                                "single centroid tile: the bytes of its own f32 / u16 copy + its 12-B results, less than SURVEY 8(d)'s 632 B per point")
+                             + " scaled by that share).  VALU-issue / LDS bound at K=100, not HBM bound (DESIGN.md section 4)")
     rl_acc = roofline_obj("k_exact_accumulate", acc_ms, int(b_acc * acc_share),
-                          f"mean over the timed launches, which streamed {acc_share:.3f} of the points (settled clusters are not "
-                          "streamed again; bytes scaled by that share).  "
+                          f"accumulation pass (k_exact_accumulate_rec over every member, or k_accumulate_stream on small K x p; in "
+                          "incremental calls k_accumulate_events over the points that changed cluster, credited 0 streamed points); "
+                          f"mean over the timed launches, which streamed {acc_share:.3f} of the points (bytes scaled by that share).  "
                           "HBM bound: one pass over the f64 values and row ids in counting-sort order, reference arithmetic "
                           "for each point's distance to its centroid fused with the per-cluster sums (DESIGN.md section 4.2); "
                           "bytes = nnz*(8+2) + n*8 + 16*p*K, all streamed in every launch") if acc_ms > 0 else None
     # top-level roofline: the kernel that took more of the timed region (both are always listed under by_kernel, each
     # with ONE byte model, so either can be followed from round to round)
     top = rl_acc if (rl_acc and acc_ms > screen_ms) else rl_screen
+    for rl in (rl_screen, rl_acc):
+        if rl:   # HBM bytes per launch from the committed PMC passes, and their ratio to the same launches' algorithmic bytes
+            rl["traffic"], rl["traffic_over_algorithmic"], rl["traffic_source"] = pmc_traffic(rl["kernel"], n_local, K, p2, args.start)
     roofline = dict(top)
-    roofline["traffic"] = pmc_traffic(top["kernel"], n_local, K, p2, args.start)
     roofline["by_kernel"] = {scr_name: rl_screen, **({"k_exact_accumulate": rl_acc} if rl_acc else {})}
     roofline["screen_steps_processed_share"] = done
     roofline["exact_pass_points_share"] = acc_share
+    free_b, total_b = torch.cuda.mem_get_info()
     ops = 3.0 * nnz_local * K
     final_obj = loop.objective_now() if loop.it > 0 else float("nan")   # (after the timed region; every rank calls it)
 
@@ -320,7 +343,9 @@ def main():
         "value_definition": "timed steps = consecutive iterations of kmeans_sparsified-style runs from the start centres "
                             f"to dff < {TOL:g} (MaxIter {MAXITER}), host reads dff every iteration; a converged run is "
                             "followed by the next one from the same start with the library's carried state reset; the timed "
-                            "region begins at a run's first (cold) iteration regardless of --warmup",
+                            "region begins at a run's first (cold) iteration regardless of --warmup.  As kmeans_sparsified() "
+                            "with Display off, the loop asks for the objective and the distances of a run's LAST iteration only "
+                            "(spkm_shard_set_lazy_stats; SPKM_BENCH_EAGER_STATS=1: every iteration)",
         "config": {"workload": f"sparsified GMM N={n_total} d={p} (p2={p2}) K={K} s={s} nnz/point, {args.order} point order, "
                                f"points sharded over {world} GPU(s), dense-centre Lloyd runs to convergence from a "
                                f"'{args.start}' start",
@@ -329,6 +354,7 @@ def main():
                    "gamma": gamma, "parallelism": f"dp{world} (1 RCCL all-reduce/iter)" if world > 1 else "single GPU",
                    "allreduce": allreduce_via,
                    "datagen_s": round(t_gen, 1), "final_obj": final_obj,
+                   "hbm_resident_GB": round((total_b - free_b) / 1e9, 1), "csc_released": bool(csc_released),
                    "runs_completed_in_timed_region": loop.runs_completed, "run_lengths": loop.run_lengths,
                    "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "
                                   "bit-identical to the all-exact kernels)" if path == 1 else "exact f64 tiles",
@@ -342,6 +368,7 @@ def main():
                  "f64_nonfused_peak_Tops": FP64_VALU_PEAK_TOPS,
                  "note": "op-equivalents of the exact f64 arithmetic the screen makes unnecessary; exceeds the f64 peak "
                          "whenever steps are skipped or finished early -- not a utilisation figure"},
+        # SURVEY 8(d)'s bytes of an iteration over the MEAN timed step (steps that skip work included: not a bandwidth)
         "whole_iter_gbs": b_iter / (elapsed / args.steps) / 1e9,
         "fwht": fw,
     }
@@ -355,37 +382,40 @@ def main():
                                                 f"{args.gen_chunk}-point chunks, copy stream + two staging buffers -> "
                                                 "spkm_widen_f64_dev -> spkm_mix_sample_dev -> resident sparse shard"}
     if not args.no_regimes and args.workload == "config5":
-        regimes = {args.order: traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)}
+        regimes = {args.order: traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name, b_screen)}
         result["regimes"] = regimes
-        cpu_data = None
     elif not args.no_regimes:
-        regimes = {args.order: traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)}
-        other = "shuffled" if args.order == "block" else "block"
-        cpu_data = None
-        if rank == 0 and world == 1 and args.cpu_sample > 0:
-            cpu_data = cpu_sample_arrays(data, centers0, s, min(max(args.cpu_sample, 4_000_000), n_local))
+        regimes = {args.order: traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name, b_screen)}
         del loop, eng
         shard.close()
         del data, shard
         torch.cuda.empty_cache()
-        data2, shard2, centers02, t_gen2 = make_dataset(other)
-        loop2 = Loop(shard2, centers02)
-        loop2.steps(1)                                     # set-up of the shard's screen copy happens on the first call
-        loop2.restart()
-        regimes[other] = traced_run(loop2, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name)
-        regimes[other]["datagen_s"] = round(t_gen2, 1)
+        # the same mixture in the other point order, and -- the worst case beside the best case -- with overlapping
+        # clusters (sigma raised until the sampled distances of neighbouring clusters overlap: the carried bounds keep
+        # failing, few clusters ever settle, the skip-dependent numbers above do not apply)
+        other = "shuffled" if args.order == "block" else "block"
+        for name, order_, sigma in ((other, other, None), ("overlap", args.order, args.overlap_noise)):
+            data2, shard2, centers02, t_gen2 = make_dataset(order_, sigma)
+            loop2 = Loop(shard2, centers02)
+            loop2.steps(1)                                     # set-up of the shard's screen copy happens on the first call
+            if csc_released and shard2.release_csc():
+                data2.pop("x", None)
+                data2.pop("ir", None)
+                torch.cuda.empty_cache()
+            loop2.restart()
+            regimes[name] = traced_run(loop2, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name, b_screen)
+            regimes[name]["datagen_s"] = round(t_gen2, 1)
+            if sigma is not None:
+                regimes[name]["noise_sigma"] = sigma
+            del loop2
+            shard2.close()
+            del data2, shard2
+            torch.cuda.empty_cache()
         result["regimes"] = regimes
-        # what a user waits for, independent of --steps / --warmup: iterations / time of one whole run to convergence
-        # (Tol 1e-6, MaxIter 100) from the cold start, on this data order and on the other one
-        result["run_to_convergence_iters_per_s"] = {o: regimes[o]["run_to_convergence_iters_per_s"] for o in regimes}
-        del loop2
-        shard2.close()
-        del data2, shard2
-        torch.cuda.empty_cache()
-    else:
-        cpu_data = None
-        if rank == 0 and world == 1 and args.cpu_sample > 0:
-            cpu_data = cpu_sample_arrays(data, centers0, s, min(max(args.cpu_sample, 4_000_000), n_local))
+        # what a user waits for, independent of --steps / --warmup: iterations / time of one whole run from the cold start
+        # (to dff < Tol 1e-6, or capped at MaxIter 100: `ended_by` says which) per dataset regime
+        result["whole_run_iters_per_s"] = {o: regimes[o]["whole_run_iters_per_s"] for o in regimes}
+        result["whole_run_ended_by"] = {o: regimes[o]["ended_by"] for o in regimes}
 
     if cpu_data is not None:
         result["cpu_baseline"] = cpu_baseline(cpu_data, p2, K, gamma, s, min(args.cpu_sample, n_local), n_total)
@@ -428,28 +458,31 @@ def roofline_obj(kernel, ms, nbytes, note):
 
 
 def pmc_traffic(kern, n_local, K, p2, start):
-    """HBM bytes per launch of ``kern`` from the committed PMC passes (profiles/pmc_latest.json: separate --pmc runs,
-    FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes), when a record for exactly this workload exists."""
+    """(HBM bytes per launch, that / the same launches' algorithmic bytes, which record) of ``kern`` from the committed PMC
+    passes (profiles/pmc_latest.json: separate --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes), when a
+    record for exactly this workload exists.  The ratio is taken inside the PMC record (same launches for both numbers):
+    the timed launches of THIS run process a different share of their steps."""
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(pmc):
-        return None
+        return None, None, None
     try:
         with open(pmc) as f:
             recs = json.load(f)
         for rec in (recs if isinstance(recs, list) else [recs]):
             if (rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2
-                    and (rec.get("start", "sample") == start or kern == "k_exact_accumulate")
-                    and str(rec.get("kernel", "")).startswith(kern)):
-                return rec.get("hbm_bytes_per_launch")
+                    and rec.get("headline_for") == kern):
+                hb, ab = rec.get("hbm_bytes_per_launch"), rec.get("algorithmic_bytes_per_launch")
+                return hb, (hb / ab if hb and ab else None), rec.get("kernel")
     except Exception:
-        return None
-    return None
+        return None, None, None
+    return None, None, None
 
 
-def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name):
+def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name, b_scr=None):
     """One complete run from the start centres to dff < Tol with a wall-clock stamp after every iteration's host read
     (max over ranks per iteration) and the two hot kernels' HIP-event times per launch."""
     loop.restart()
+    b_scr = b_iter if b_scr is None else b_scr
     _lib.check(L.spkm_timing_log(ctx.handle, 2))
     torch.cuda.synchronize()
     if world > 1:
@@ -475,10 +508,16 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
     acc = kms[1::2][:its] if kms.size >= 2 * its else np.array([])
     total = float(ms.sum()) * 1e-3
     tail = ms[-min(3, its):]
-    r = {"iterations": its, "converged": bool(dff < TOL), "final_dff": dff, "final_obj": objs[-1], "seconds": total,
-         "run_to_convergence_iters_per_s": its / total,
-         "run_to_convergence_mean_ms": float(ms.mean()),
+    r = {"iterations": its, "converged": bool(dff < TOL), "ended_by": "tol" if dff < TOL else "maxiter",
+         "final_dff": dff, "final_obj": objs[-1], "seconds": total,
+         # one whole run from the cold start: to dff < Tol if `converged`, else capped at MaxIter (then it is a
+         # MaxIter-iteration mean, not a time to convergence)
+         "whole_run_iters_per_s": its / total,
+         "whole_run_mean_ms": float(ms.mean()),
          "cold_no_carry_ms": float(ms[0]),
+         # the whole cold iteration against the HBM roofline: SURVEY 8(d)'s bytes of an iteration / its wall time
+         "whole_iter_cold": {"bytes": b_iter, "ms": float(ms[0]), "GBs": b_iter / (float(ms[0]) * 1e-3) / 1e9,
+                             "frac": b_iter / (float(ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
          "converged_ms": float(tail.mean()), "converged_iters_per_s": 1e3 / float(tail.mean()),
          # for comparison across rounds only: round 1 timed iterations W+1 .. W+K of ONE run (its --warmup 5 --steps 20 window)
          "r01_window_iters_6_to_25_per_s": (20.0 / (float(ms[5:25].sum()) * 1e-3)) if its >= 25 else None,
@@ -487,8 +526,9 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
     if scr.size:
         # one kernel per regime, one byte model each: the cold iteration is the assignment kernel over every step,
         # the converged one the exact accumulation pass
-        r["roofline_cold_no_carry"] = roofline_obj(scr_name, float(scr[0]), b_iter,
-                                                   "plain screen, every 16-point step, SURVEY 8(d) bytes of an iteration")
+        r["roofline_cold_no_carry"] = roofline_obj(scr_name, float(scr[0]), b_scr,
+                                                   "plain screen, every 16-point step; " + ("SURVEY 8(d) bytes of an iteration" if b_scr == b_iter
+                                                   else "single centroid tile: the bytes the kernel itself moves (f32 / u16 copy + results)"))
         last_pts = loop.eng.exact_pass_points()[1]
         share = last_pts / max(loop.shard.n, 1)
         r["exact_pass_points_share_last_iter"] = share

@@ -127,6 +127,16 @@ int spkm_shard_reset_policy(spkm_shard *s);
  * (few points moved in the previous call, its caches describe the previous call, ...); a call that runs the full pass
  * returns the statistics as always.  SPKM_NO_INCREMENTAL=1 switches the incremental calls off. */
 int spkm_shard_set_lazy_stats(spkm_shard *s, int on);
+/* Halve the resident footprint of a fixed-stride shard (every column has the same number of entries, at most 64): build
+ * now what the fused call would build on its first use -- the record layout (a point's values and row ids side by side)
+ * and the screen's f32 copy + norms -- and let go of the CSC value / row-id arrays.  A shard made by
+ * spkm_shard_create_host frees them; for an adopted one (spkm_shard_create_dev) the library merely stops referencing
+ * d_ir / d_x and the caller may free them.  jc stays.  From then on the fused call, spkm_distances_*_dev and the point
+ * lists read the records; an entry point that needs CSC (spkm_assign_dev, spkm_accumulate_dev, the sparse-centres
+ * assignment, SPKM_NO_SCREEN=1) re-materialises library-owned arrays from the records first (one streaming pass) --
+ * results never change.  N = 1e8, s = 51: 146 GB -> 93 GB resident.  SPKM_ERR_UNSUPPORTED: ragged shard, columns longer
+ * than 64, or no room for the records beside the arrays -- nothing was released. */
+int spkm_shard_release_csc(spkm_ctx *ctx, spkm_shard *s);
 void spkm_shard_destroy(spkm_shard *s);
 int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
 

@@ -135,6 +135,7 @@ def lib():
     L.spkm_distances_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp]
     L.spkm_distances_stats_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp, _vp]
     L.spkm_shard_set_lazy_stats.argtypes = [_vp, C.c_int]
+    L.spkm_shard_release_csc.argtypes = [_vp, _vp]
     L.spkm_ctx_reload_switches.argtypes = [_vp]
     L.spkm_widen_f64_dev.argtypes = [_vp, C.c_int, _u64, _vp, _vp]
     L.spkm_comm_unique_id.argtypes = [_vp]

@@ -134,7 +134,8 @@ struct spkm_shard {
     long long* jc = nullptr;
     void* ir = nullptr;
     double* x = nullptr;
-    bool owned = false;
+    bool owned = false;     // jc is the library's
+    bool owned_csc = false; // ir / x are the library's
     int fixed_s = 0;   // > 0: every column has exactly this many entries
     uint64_t slack = 0; // entries readable past nnz in ir / x
     float* xfs = nullptr;  // screen copy for the 4-lanes-per-point kernel: f32 values, columns partitioned by row parity
@@ -186,6 +187,7 @@ struct spkm_shard {
     // lazy statistics + incremental sums (spkm_shard_set_lazy_stats): the caller does not need obj2 / the largest distance
     // from every fused call, so a call may leave the exact pass out and move the per-cluster sums by the points that
     // changed cluster only (events: run_screen, k_accumulate_events)
+    bool csc_released = false;   // x / ir are gone (spkm_shard_release_csc): the record layout is the only copy of the entries
     bool lazy = false;
     bool cl_stats_valid = false; // cl_cache's obj2 / max / argmax describe the previous call (false after an incremental call)
     int* ev_pt = nullptr;        // events of the current call: point | key (K + old cluster, or new cluster); 2 n each
@@ -362,7 +364,7 @@ extern "C" int spkm_shard_create_host(spkm_ctx* ctx, uint64_t p, uint64_t n, con
     HIP_TRY(hipSetDevice(ctx->device));
     const uint64_t nnz = jc[n];
     spkm_shard* s = new spkm_shard();
-    s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->owned = true;
+    s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->owned = true; s->owned_csc = true;
     s->ir_bits = (p <= 65536) ? 16 : 32;
     s->slack = 48;
     if (n > 0 && nnz > 0 && nnz % n == 0) {
@@ -422,7 +424,7 @@ extern "C" int spkm_shard_create_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint
     HIP_TRY(hipSetDevice(ctx->device));
     spkm_shard* s = new spkm_shard();
     s->ctx = ctx; s->p = p; s->n = n; s->nnz = nnz; s->ir_bits = ir_bits;
-    s->jc = (long long*)d_jc; s->ir = (void*)d_ir; s->x = (double*)d_x; s->owned = false;
+    s->jc = (long long*)d_jc; s->ir = (void*)d_ir; s->x = (double*)d_x; s->owned = false; s->owned_csc = false;
     s->slack = capacity - nnz;
     if (n > 0 && nnz > 0 && nnz % n == 0 && nnz / n <= 0x7fffffffull) {
         int rc = ensure(ctx, ctx->nitems, 64);
@@ -464,8 +466,8 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->hb_centers) (void)hipFree(s->hb_centers);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
     if (s->ev_nlist) (void)hipEventDestroy(s->ev_nlist);
-    if (s->owned) {
-        if (s->jc) (void)hipFree(s->jc);
+    if (s->owned && s->jc) (void)hipFree(s->jc);
+    if (s->owned_csc) {
         if (s->ir) (void)hipFree(s->ir);
         if (s->x) (void)hipFree(s->x);
     }
@@ -495,6 +497,39 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     return SPKM_OK;
 }
 
+static bool screen_use_quad(const spkm_ctx* ctx, const spkm_shard* s);
+template <typename IR> static int build_records(spkm_ctx* ctx, spkm_shard* sm);
+template <typename IR> static int build_screen_copy(spkm_ctx* ctx, spkm_shard* sm);
+
+extern "C" int spkm_shard_release_csc(spkm_ctx* ctx, spkm_shard* s)
+{
+    if (!ctx || !s) return SPKM_ERR_NULL_ARG;
+    if (s->csc_released || s->nnz == 0) return SPKM_OK;
+    if (s->fixed_s <= 0 || s->fixed_s > 64 || s->slack < 48 || ctx->sw.no_rec) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    // everything that is derived from the CSC arrays, now: the records (from here on the only copy of the exact entries)
+    // and the screen's f32 copy + the certificate's norms
+    s->rec_tried = false;
+    rc = s->ir_bits == 16 ? build_records<unsigned short>(ctx, s) : build_records<unsigned int>(ctx, s);
+    if (rc) return rc;
+    if (!s->rec) return SPKM_ERR_UNSUPPORTED; // (no room for the records beside the arrays: nothing released)
+    if (screen_use_quad(ctx, s)) {
+        rc = s->ir_bits == 16 ? build_screen_copy<unsigned short>(ctx, s) : build_screen_copy<unsigned int>(ctx, s);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the builders read x / ir
+    if (s->owned_csc) {
+        if (s->ir) (void)hipFree(s->ir);
+        if (s->x) (void)hipFree(s->x);
+    }
+    s->ir = nullptr;
+    s->x = nullptr;
+    s->owned_csc = false;
+    s->csc_released = true;
+    return SPKM_OK;
+}
+
 extern "C" int spkm_shard_set_lazy_stats(spkm_shard* s, int on)
 {
     if (!s) return SPKM_ERR_NULL_ARG;
@@ -513,6 +548,82 @@ extern "C" int spkm_shard_info(const spkm_shard* s, uint64_t* p, uint64_t* n, ui
 }
 
 extern "C" uint64_t spkm_reduce_len(uint64_t p, uint64_t K) { return 2 * p * K + K + 1; }
+
+
+// ------------------------------------------------------------------------------------------
+// one-time layouts of a fixed-stride shard (built from its CSC arrays) and the way back
+// ------------------------------------------------------------------------------------------
+template <typename IR>
+static int build_records(spkm_ctx* ctx, spkm_shard* sm)
+{
+    // Record layout of the exact entries (screen.hip, k_build_records): built once per shard, when the device has room
+    // for it (n * R bytes: 51 GB at N = 1e8, s = 51).  SPKM_NO_REC=1: never (A/B switch, and what runs when memory is short).
+    if (sm->rec || sm->rec_tried || ctx->sw.no_rec || sm->fixed_s <= 0 || !sm->x) return SPKM_OK;
+    sm->rec_tried = true;
+    const long long n = (long long)sm->n;
+    const int R = (int)(((size_t)sm->fixed_s * (8 + sizeof(IR)) + 15) / 16 * 16);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (size_t)n * R + ((size_t)4 << 30) &&
+        hipMalloc((void**)&sm->rec, (size_t)n * R + 256) == hipSuccess) {
+        hipLaunchKernelGGL((k_build_records<IR>), dim3((unsigned)std::min<long long>((n + 3) / 4, 65536)), dim3(256), 0,
+                           ctx->stream, (const IR*)sm->ir, (const double*)sm->x, n, sm->fixed_s, R, sm->rec);
+        sm->rec_R = R;
+    } else {
+        (void)hipGetLastError();
+        sm->rec = nullptr;
+    }
+    return SPKM_OK;
+}
+
+template <typename IR>
+static int build_screen_copy(spkm_ctx* ctx, spkm_shard* sm)
+{
+    // f32 values + row ids in the 4-lanes-per-point kernel's step-major lane order, columns partitioned by row parity
+    // (k_screen_reorder), and the certificate's per-point norms on the same pass
+    const long long n = (long long)sm->n;
+    const int p = (int)sm->p;
+    if (!sm->xn1) {
+        HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
+        HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
+    }
+    if (sm->xfs) return SPKM_OK;
+    const size_t isz = sizeof(IR);
+    const size_t slots = (size_t)((n + 15) / 16) * ((sm->fixed_s + 3) / 4) * 64; // steps x rounds x lanes
+    HIP_TRY(hipMalloc((void**)&sm->xfs, slots * 4));
+    HIP_TRY(hipMalloc((void**)&sm->irs, slots * isz));
+    hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
+                       0, ctx->stream, (const IR*)sm->ir, (const double*)sm->x, n, sm->fixed_s, p, sm->xfs, (IR*)sm->irs,
+                       sm->norms_done ? (double*)nullptr : sm->xn1, sm->norms_done ? (double*)nullptr : sm->xn2);
+    sm->norms_done = true;
+    return SPKM_OK;
+}
+
+// CSC arrays back from the records, library-owned (an entry point that reads CSC was called after
+// spkm_shard_release_csc): one streaming pass.  The shard stays "released" in spirit -- the next release frees them again.
+static int ensure_csc(spkm_ctx* ctx, const spkm_shard* s)
+{
+    spkm_shard* sm = const_cast<spkm_shard*>(s);
+    if (sm->x != nullptr || sm->nnz == 0) return SPKM_OK;
+    if (!sm->rec) return SPKM_ERR_BAD_VALUE; // (cannot happen: release requires the records)
+    const size_t irb = (size_t)sm->ir_bits / 8;
+    HIP_TRY(hipMalloc(&sm->ir, (sm->nnz + 48) * irb));
+    HIP_TRY(hipMalloc((void**)&sm->x, (sm->nnz + 48) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync((char*)sm->ir + sm->nnz * irb, 0, 48 * irb, ctx->stream));
+    HIP_TRY(hipMemsetAsync(sm->x + sm->nnz, 0, 48 * sizeof(double), ctx->stream));
+    const long long n = (long long)sm->n;
+    const unsigned grid = (unsigned)std::min<long long>((n + 3) / 4, 65536);
+    if (sm->ir_bits == 16)
+        hipLaunchKernelGGL((k_unpack_records<unsigned short>), dim3(grid), dim3(256), 0, ctx->stream, (const char*)sm->rec, n,
+                           sm->fixed_s, sm->rec_R, (unsigned short*)sm->ir, sm->x);
+    else
+        hipLaunchKernelGGL((k_unpack_records<unsigned int>), dim3(grid), dim3(256), 0, ctx->stream, (const char*)sm->rec, n,
+                           sm->fixed_s, sm->rec_R, (unsigned int*)sm->ir, sm->x);
+    HIP_TRY(hipGetLastError());
+    sm->owned_csc = true;
+    sm->slack = 48;
+    sm->csc_released = false;
+    return SPKM_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // assignment
@@ -737,6 +848,7 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
     ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rcc = ensure_csc(ctx, s)) return rcc;
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;
     int rc;
@@ -859,6 +971,7 @@ extern "C" int spkm_assign_sparse_centers_dev(spkm_ctx* ctx, const spkm_shard* s
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
     ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rcc = ensure_csc(ctx, s)) return rcc;
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;
     int rc;
@@ -988,6 +1101,7 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
     if (K64 == 0 || K64 > 65536) return SPKM_ERR_UNSUPPORTED;
     ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rcc = ensure_csc(ctx, s)) return rcc;
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;
     const size_t pk = (size_t)p * K;
@@ -1088,32 +1202,25 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     double* obj2 = nk_f + K;
     int rc;
     spkm_shard* sm = const_cast<spkm_shard*>(s);
-    if (!sm->xn1) {
+    if (!quad && !sm->xn1) {
         HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
         HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
     }
+    if (!quad && (rc = ensure_csc(ctx, s))) return rc; // (the 16-lanes-per-point screen streams the CSC arrays themselves)
     if (!quad && !sm->xf) {
         // f32 copy of the values in storage order
         HIP_TRY(hipMalloc((void**)&sm->xf, (size_t)(s->nnz + 48) * 4));
         HIP_TRY(hipMemsetAsync(sm->xf, 0, (size_t)(s->nnz + 48) * 4, ctx->stream));
     }
-    if ((!sm->norms_done && !(quad && !sm->xfs)) || (!quad && !sm->xf_done)) { // (with the 4-lane screen the reorder pass below computes the norms)
+    if (!quad && (!sm->norms_done || !sm->xf_done)) {
         hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256), 0,
-                           ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2,
-                           quad ? (float*)nullptr : sm->xf);
+                           ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2, sm->xf);
         sm->norms_done = true;
-        if (!quad) sm->xf_done = true;
+        sm->xf_done = true;
     }
     if (quad && !sm->xfs) {
-        // f32 values + row ids in the kernel's step-major lane order, columns partitioned by row parity (k_screen_reorder)
-        const size_t isz = sizeof(IR);
-        const size_t slots = (size_t)((n + 15) / 16) * ((s->fixed_s + 3) / 4) * 64; // steps x rounds x lanes
-        HIP_TRY(hipMalloc((void**)&sm->xfs, slots * 4));
-        HIP_TRY(hipMalloc((void**)&sm->irs, slots * isz));
-        hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
-                           0, ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, p, sm->xfs, (IR*)sm->irs,
-                           sm->norms_done ? (double*)nullptr : sm->xn1, sm->norms_done ? (double*)nullptr : sm->xn2);
-        sm->norms_done = true;
+        if ((rc = ensure_csc(ctx, s))) return rc;
+        if ((rc = build_screen_copy<IR>(ctx, sm))) return rc;
     }
     // Last tile of the 4-lanes-per-point kernel.  <= 4 centroids: no tile of their own -- the workgroups of the
     // previous tile carry them as one extra centroid per lane (pl 5; needs (p+1) x 16 B more LDS); <= 16: a
@@ -1341,25 +1448,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const int nw = threads / 64;
     const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
     const size_t fixed_lds = (size_t)p * 20 + 16;
-    // Record layout of the exact entries (screen.hip, k_build_records): built once per shard on the first screen call,
-    // when the device has room for it (n * R bytes: 51 GB at N = 1e8, s = 51).  With the points of a cluster scattered
-    // over the shard (data in arbitrary order) it takes a third off this pass; in cluster-contiguous order it is
-    // neutral.  SPKM_NO_REC=1: the two separate arrays (A/B switch, and what runs when memory is short).
-    if (!sm->rec && !sm->rec_tried && !ctx->sw.no_rec) {
-        sm->rec_tried = true;
-        const int R = (int)(((size_t)s->fixed_s * (8 + sizeof(IR)) + 15) / 16 * 16);
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (size_t)n * R + ((size_t)4 << 30) &&
-            hipMalloc((void**)&sm->rec, (size_t)n * R + 256) == hipSuccess) {
-            hipLaunchKernelGGL((k_build_records<IR>), dim3((unsigned)std::min<long long>((n + 3) / 4, 65536)), dim3(256), 0,
-                               ctx->stream, (const IR*)s->ir, (const double*)s->x, n, s->fixed_s, R, sm->rec);
-            sm->rec_R = R;
-        } else {
-            (void)hipGetLastError();
-            sm->rec = nullptr;
-        }
-    }
+    // Record layout of the exact entries (build_records): built once per shard on the first screen call, when the device
+    // has room for it.  With the points of a cluster scattered over the shard (data in arbitrary order) it takes a third
+    // off the exact pass; in cluster-contiguous order it is neutral.  SPKM_NO_REC=1: the two separate arrays.
+    if ((rc = build_records<IR>(ctx, sm))) return rc;
     const bool use_rec = sm->rec != nullptr;
+    if (!use_rec && (rc = ensure_csc(ctx, s))) return rc;
     // software-pipelined record kernel (k_exact_accumulate_rec): batches of exactly 16 points per wave, columns of up
     // to 64 entries
     const bool pipe = use_rec && s->fixed_s <= 64 &&
@@ -1402,7 +1496,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        a_lib, bounds_ok ? 1 : 0, (unsigned*)ctx->nlist.p + 5, cl_skip ? cl_touched : (int*)nullptr,
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
                        ev_path ? sm->hb : (float*)nullptr, ev_path ? sm->ev_pt : (int*)nullptr,
-                       ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p);
+                       ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p,
+                       s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     ctx->last_lib_valid = bounds_ok;
     ctx->last_incremental = ev_path;
@@ -1772,6 +1867,7 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
         HIP_TRY(hipGetLastError());
         return SPKM_OK;
     }
+    if ((rc = ensure_csc(ctx, s))) return rc;
     if ((rc = ensure(ctx, ctx->ct, (size_t)p * K * 8))) return rc;
     hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>(((size_t)p * K + 255) / 256, 2048)), dim3(256), 0,
                        ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
@@ -2031,6 +2127,49 @@ extern "C" int spkm_lloyd_iter(spkm_ctx* ctx, const spkm_shard* s, uint64_t K, d
     // the ONE exchange of an iteration: 2 p K + K + 1 doubles (1.64 MB at p = 1024, K = 100), latency bound on xGMI
     if ((rc = spkm_allreduce_f64_dev(ctx, d_reduce, spkm_reduce_len(s->p, K)))) return rc;
     return spkm_finalize_dev(ctx, s->p, K, d_reduce, gamma, d_centers, d_out); // :448 scales by SparsityLevel either way
+}
+
+// ------------------------------------------------------------------------------------------
+// k-means++ seeding helpers (private/Arthur_initialization.m:38-69)
+// ------------------------------------------------------------------------------------------
+extern "C" int spkm_kpp_update_dev(spkm_ctx* ctx, uint64_t n64, const double* d_dist_new, double* d_run, int first_round,
+                                   double* d_cum, double* total)
+{
+    if (!ctx || (n64 && (!d_dist_new || !d_run || !d_cum))) return SPKM_ERR_NULL_ARG;
+    if (n64 > 0x7ff00000ull) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (total) *total = 0.0;
+    if (n64 == 0) return SPKM_OK;
+    const long long n = (long long)n64;
+    const int nb = (int)((n + KPP_BLOCK - 1) / KPP_BLOCK);
+    int rc;
+    if ((rc = ensure(ctx, ctx->tmp_mind, (size_t)(nb + 1) * 8))) return rc;
+    double* part = (double*)ctx->tmp_mind.p;
+    hipLaunchKernelGGL(k_kpp_min_partial, dim3(nb), dim3(256), 0, ctx->stream, d_dist_new, d_run, n, first_round ? 1 : 0, part);
+    hipLaunchKernelGGL(k_kpp_scan_partials, dim3(1), dim3(256), 0, ctx->stream, part, nb);
+    hipLaunchKernelGGL(k_kpp_block_scan, dim3(nb), dim3(256), 0, ctx->stream, (const double*)d_run, n, (const double*)part, d_cum);
+    HIP_TRY(hipGetLastError());
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(total, part + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return SPKM_OK;
+}
+
+extern "C" int spkm_kpp_draw_dev(spkm_ctx* ctx, uint64_t n64, const double* d_cum, double target, int64_t* index)
+{
+    if (!ctx || !d_cum || !index) return SPKM_ERR_NULL_ARG;
+    if (n64 == 0 || n64 > 0x7ff00000ull) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->tmp_assign, 64))) return rc;
+    hipLaunchKernelGGL(k_kpp_search, dim3(1), dim3(1), 0, ctx->stream, d_cum, (long long)n64, target, (long long*)ctx->tmp_assign.p);
+    HIP_TRY(hipGetLastError());
+    long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, ctx->tmp_assign.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *index = (int64_t)v;
+    return SPKM_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         // could not separate; the host decides from this count whether the next call may use the two-phase screen
         if (!(r2 >= 2.25 * r1)) nambig++;
       }
-      if (ev_pt) { // (every thread of the workgroup gets here in every trip)
+      if (ev_pt && __syncthreads_or(mover ? 1 : 0)) { // (every thread of the workgroup gets here in every trip; no mover: nothing to stage)
         const int cnt = mover ? (mv_old >= 0 ? 2 : 1) : 0;
         // exclusive prefix of cnt inside the wave, one LDS atomic per wave for its total
         int incl = cnt;
@@ -968,45 +968,60 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      unsigned* __restrict__ changed, int* __restrict__ touched,
                                                      unsigned long long* __restrict__ nk,
                                                      float* __restrict__ ubv, int* __restrict__ ev_pt,
-                                                     int* __restrict__ ev_k, unsigned* __restrict__ counters)
+                                                     int* __restrict__ ev_k, unsigned* __restrict__ counters,
+                                                     const char* __restrict__ rec, int rec_R)
 {
     // alib / lib_valid / touched / nk: the library's copy of the assignment and what follows from a change, as in
     // k_combine_screen (these points kept their previous value there); few points: global atomics
     // ubv != nullptr (lazy calls): the point's upper bound = its exact distance, rounded up; ev_pt / ev_k: the two
     // events of a point that changes cluster (k_combine_screen); counters[14] movers, counters[16] events
+    // rec != nullptr: the point's entries come from the record layout (x | ir side by side, R bytes per point) -- the
+    // only copy of the exact entries once the shard's CSC arrays have been released (spkm_shard_release_csc)
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const long long cnt = *nlist;
     for (long long q = wave; q < cnt; q += nwaves) {
         const long long i = list[q];
-        const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
-        const long long j1 = fixed_s > 0 ? j0 + fixed_s : jc[i + 1];
+        const double* xq;
+        const IR* rq;
+        int ne;
+        if (rec != nullptr) {
+            const char* b = rec + (size_t)i * (size_t)rec_R;
+            xq = reinterpret_cast<const double*>(b);
+            rq = reinterpret_cast<const IR*>(b + (size_t)fixed_s * 8);
+            ne = fixed_s;
+        } else {
+            const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
+            xq = xval + j0;
+            rq = ir + j0;
+            ne = fixed_s > 0 ? fixed_s : (int)(jc[i + 1] - j0);
+        }
         double best = __builtin_inf();
         int bk = 0x7fffffff;
         for (int k = lane; k < K; k += 64) {
             double acc = 0.0;
-            long long j = j0;
-            for (; j + 8 <= j1; j += 8) { // eight independent gathers in flight; the additions stay in storage order
+            int j = 0;
+            for (; j + 8 <= ne; j += 8) { // eight independent gathers in flight; the additions stay in storage order
                 double c[8], d[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) c[u] = Cs[(size_t)ir[j + u] * K + k];
+                for (int u = 0; u < 8; u++) c[u] = Cs[(size_t)rq[j + u] * K + k];
 #pragma unroll
-                for (int u = 0; u < 8; u++) d[u] = xval[j + u] - c[u];
+                for (int u = 0; u < 8; u++) d[u] = xq[j + u] - c[u];
 #pragma unroll
                 for (int u = 0; u < 8; u++) acc = acc + d[u] * d[u];
             }
-            for (; j + 4 <= j1; j += 4) {
-                const double c0 = Cs[(size_t)ir[j] * K + k], c1 = Cs[(size_t)ir[j + 1] * K + k],
-                             c2 = Cs[(size_t)ir[j + 2] * K + k], c3 = Cs[(size_t)ir[j + 3] * K + k];
-                const double d0 = xval[j] - c0, d1 = xval[j + 1] - c1, d2 = xval[j + 2] - c2, d3 = xval[j + 3] - c3;
+            for (; j + 4 <= ne; j += 4) {
+                const double c0 = Cs[(size_t)rq[j] * K + k], c1 = Cs[(size_t)rq[j + 1] * K + k],
+                             c2 = Cs[(size_t)rq[j + 2] * K + k], c3 = Cs[(size_t)rq[j + 3] * K + k];
+                const double d0 = xq[j] - c0, d1 = xq[j + 1] - c1, d2 = xq[j + 2] - c2, d3 = xq[j + 3] - c3;
                 acc = acc + d0 * d0;
                 acc = acc + d1 * d1;
                 acc = acc + d2 * d2;
                 acc = acc + d3 * d3;
             }
-            for (; j < j1; j++) {
-                const double d = xval[j] - Cs[(size_t)ir[j] * K + k];
+            for (; j < ne; j++) {
+                const double d = xq[j] - Cs[(size_t)rq[j] * K + k];
                 acc = acc + d * d;
             }
             const double dd = sqrt(acc);
@@ -1102,6 +1117,26 @@ __global__ __launch_bounds__(256) void k_build_records(const IR* __restrict__ ir
             dr[j] = ir[(size_t)i * s + j];
         }
         // (the few pad bytes behind the row ids are never read)
+    }
+}
+
+// The inverse of k_build_records: the CSC value / row-id arrays of a fixed-stride shard from its record layout (entry points
+// that read CSC after spkm_shard_release_csc re-materialise them first: api.hip, ensure_csc).
+template <typename IR>
+__global__ __launch_bounds__(256) void k_unpack_records(const char* __restrict__ rec, long long n, int s, int R,
+                                                        IR* __restrict__ ir, double* __restrict__ x)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long i = wave; i < n; i += nwaves) {
+        const char* src = rec + (size_t)i * R;
+        const double* sx = reinterpret_cast<const double*>(src);
+        const IR* sr = reinterpret_cast<const IR*>(src + (size_t)s * 8);
+        for (int j = lane; j < s; j += 64) {
+            x[(size_t)i * s + j] = sx[j];
+            ir[(size_t)i * s + j] = sr[j];
+        }
     }
 }
 
@@ -1505,10 +1540,10 @@ template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const 
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*);
+    float*, int*, int*, unsigned*, const char*, int);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*);
+    float*, int*, int*, unsigned*, const char*, int);
 
 // ============================================================================================
 // K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through

@@ -99,6 +99,99 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ part
         if (hist[k]) atomicAdd(&nk[k], (unsigned long long)hist[k]);
 }
 
+// ---------------- k-means++ seeding on the device (private/Arthur_initialization.m:38-69) ----------------
+// A round evaluates the distance of every point to the NEWEST centre only (spkm_assign_dev, K = 1) and keeps a running
+// minimum -- min() is exact and a (point, centre) distance does not depend on the other centres, so the vector equals
+// the reference's full recomputation bit for bit -- then draws the next centre with probability proportional to
+// dist.^2 (randsample(n,1,true,dist.^2), :50): inclusive prefix sums of dist.^2 in a fixed order (block partial sums,
+// one-block scan of the partials, per-block scan) and a search for the first index whose cumulative weight exceeds
+// u x total, u the HOST's uniform random number (the random stream stays the host's).
+#define KPP_BLOCK 1024
+// run[i] = min(run[i], dnew[i]) (first round: run = dnew); part[b] = sum over block b of run[i]^2
+__global__ __launch_bounds__(256) void k_kpp_min_partial(const double* __restrict__ dnew, double* __restrict__ run,
+                                                         long long n, int first_round, double* __restrict__ part)
+{
+    __shared__ double sh[4];
+    const long long base = (long long)blockIdx.x * KPP_BLOCK;
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < KPP_BLOCK; t += 256) {
+        const long long i = base + t;
+        if (i < n) {
+            double v = dnew[i];
+            if (!first_round) { const double r = run[i]; v = r < v ? r : v; }
+            run[i] = v;
+            acc += v * v;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// exclusive scan of the block partials in place (one workgroup, sequential over tiles of 256); part[nb] = total
+__global__ __launch_bounds__(256) void k_kpp_scan_partials(double* __restrict__ part, int nb)
+{
+    __shared__ double sh[256];
+    __shared__ double carry;
+    if (threadIdx.x == 0) carry = 0.0;
+    __syncthreads();
+    for (int t0 = 0; t0 < nb; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const double v = t < nb ? part[t] : 0.0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan
+            const double add = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (t < nb) part[t] = carry + sh[threadIdx.x] - v; // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[nb] = carry;
+}
+// cum[i] = part[block] + inclusive sum of run^2 inside the block (thread 0 of each block walks it: fixed order)
+__global__ __launch_bounds__(256) void k_kpp_block_scan(const double* __restrict__ run, long long n,
+                                                        const double* __restrict__ part, double* __restrict__ cum)
+{
+    __shared__ double sh[KPP_BLOCK];
+    __shared__ double seg[256];
+    const long long base = (long long)blockIdx.x * KPP_BLOCK;
+    for (int t = threadIdx.x; t < KPP_BLOCK; t += 256) { const long long i = base + t; const double v = i < n ? run[i] : 0.0; sh[t] = v * v; }
+    __syncthreads();
+    // each thread owns 4 consecutive elements; scan of the 256 thread totals, then the per-thread prefixes
+    const int e0 = threadIdx.x * 4;
+    const double a0 = sh[e0], a1 = a0 + sh[e0 + 1], a2 = a1 + sh[e0 + 2], a3 = a2 + sh[e0 + 3];
+    seg[threadIdx.x] = a3;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const double add = (int)threadIdx.x >= off ? seg[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        seg[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const double before = part[blockIdx.x] + (threadIdx.x ? seg[threadIdx.x - 1] : 0.0);
+    const long long i = base + e0;
+    if (i < n) cum[i] = before + a0;
+    if (i + 1 < n) cum[i + 1] = before + a1;
+    if (i + 2 < n) cum[i + 2] = before + a2;
+    if (i + 3 < n) cum[i + 3] = before + a3;
+}
+// out[0] = first index i with cum[i] > target (clamped to n - 1): searchsorted(cum, target, right)
+__global__ void k_kpp_search(const double* __restrict__ cum, long long n, double target, long long* __restrict__ out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    long long lo = 0, hi = n; // first index in [lo, hi) with cum > target
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (cum[mid] > target) hi = mid; else lo = mid + 1;
+    }
+    out[0] = lo < n ? lo : n - 1;
+}
+
 // Per-block statistics of a vector of distances (spkm_distances_stats_dev on shards without a record layout): the same
 // partials k_combine produces -- sum of squares, largest value, its first index -- over contiguous slabs.
 __global__ __launch_bounds__(256) void k_mind_stats(const double* __restrict__ mind, long long n,

@@ -66,6 +66,19 @@ class Shard:
         delivers them for the iteration that needs them."""
         _lib.check(_lib.lib().spkm_shard_set_lazy_stats(self.handle, 1 if on else 0), "spkm_shard_set_lazy_stats")
 
+    def release_csc(self) -> bool:
+        """Let go of the CSC value / row-id arrays once the record layout and the screen copy exist
+        (spkm_shard_release_csc): the tensors an adopted shard was built from are dropped here, so that their memory
+        returns to the allocator unless the caller still holds them.  Returns False when the shard does not qualify
+        (ragged, columns longer than 64, no room for the records) -- nothing changes then."""
+        st = _lib.lib().spkm_shard_release_csc(self.ctx.handle, self.handle)
+        if st == _lib.ERR_UNSUPPORTED:
+            return False
+        _lib.check(st, "spkm_shard_release_csc")
+        if self._keep:
+            self._keep = (self._keep[0],)      # jc stays referenced by the library; ir / x do not
+        return True
+
     def reset_policy(self):
         """New start / new replicate: drop the adaptive state of the fused call (spkm_shard_reset_policy)."""
         _lib.check(_lib.lib().spkm_shard_reset_policy(self.handle), "spkm_shard_reset_policy")

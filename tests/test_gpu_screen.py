@@ -669,3 +669,61 @@ def test_lazy_statistics_incremental_sums_stay_the_members_sums(gpu_ctx, oracle,
     #  edge -- their sums differ in the last bits -- so: the same run, but for a handful of points at most)
     for a1, a0 in zip(runs[True][0], runs[False][0]):
         assert np.count_nonzero(a1 != a0) <= max(2, n // 10000)
+
+
+@pytest.mark.parametrize("adopted", [False, True])
+def test_releasing_the_csc_arrays_changes_nothing_but_the_footprint(gpu_ctx, oracle, adopted):
+    """spkm_shard_release_csc: the record layout becomes the only copy of the exact entries.  Fused calls, distances on
+    demand and the exact list keep giving the oracle's outputs; an entry point that needs CSC (spkm_assign_dev: all-exact
+    kernels, K = 1 stream) re-materialises library-owned arrays from the records and is the oracle's too; a second
+    release lets them go again.  For an adopted shard the caller's tensors are simply no longer referenced."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, s = 256, 20000, 37, 26
+    X = random_csc(p, n, s, seed=77)
+    gam = s / p
+    rng = np.random.default_rng(5)
+    if adopted:
+        pad = 48
+        ir = torch.zeros(n * s + pad, dtype=torch.int16, device="cuda")
+        xv = torch.zeros(n * s + pad, dtype=torch.float64, device="cuda")
+        ir[: n * s] = torch.tensor(X.indices.astype(np.int16), device="cuda")
+        xv[: n * s] = torch.tensor(X.data, device="cuda")
+        jc = torch.arange(0, (n + 1) * s, s, dtype=torch.int64, device="cuda")
+        shard = Shard.from_device(gpu_ctx, p, jc, ir, xv, nnz=n * s)
+        del ir, xv
+    else:
+        shard = Shard.from_scipy(gpu_ctx, X)
+    eng = LloydEngine(shard, K, gam)
+    Cm = rng.standard_normal((p, K)) * 0.3
+    Cm[:, 5] = Cm[:, 9]                                            # an exact tie: the exact list has work to do
+    c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+    eng.assign_accumulate_step(c)
+    _check(eng, oracle, X, Cm, gam)
+    assert shard.release_csc()
+    assert shard.release_csc()                                     # idempotent
+    torch.cuda.empty_cache()
+    for it in range(3):                                            # fused calls on the records alone
+        Cm = Cm + 0.01 * rng.standard_normal((p, K))
+        Cm[:, 5] = Cm[:, 9]
+        c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+        eng.assign_accumulate_step(c, want_mind=(it != 1))
+        if it == 1:
+            eng.distances(c)                                       # distances on demand, streamed from the records
+        _check(eng, oracle, X, Cm, gam)
+    # an entry point that reads CSC: the arrays come back from the records
+    eng.assign_step(c)
+    ra, rd = oracle.assign(p, n, *parts(X), Cm, gam)
+    assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)
+    eng.accumulate_step()
+    S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), ra)
+    red = eng.reduce.cpu().numpy()
+    assert np.array_equal(red[p * K:2 * p * K].reshape(K, p).T, Cnt)
+    e1 = LloydEngine(shard, 1, gam)                                # K = 1: the streaming kernel of the k-means++ rounds
+    c1 = torch.tensor(np.ascontiguousarray(Cm[:, :1].T), device="cuda")
+    e1.assign_step(c1)
+    _, d1 = oracle.assign(p, n, *parts(X), Cm[:, :1], gam)
+    assert np.array_equal(e1.mind.cpu().numpy(), d1)
+    assert shard.release_csc()                                     # ... and go again
+    eng.assign_accumulate_step(c)
+    _check(eng, oracle, X, Cm, gam)
