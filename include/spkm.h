@@ -137,6 +137,11 @@ int spkm_shard_set_lazy_stats(spkm_shard *s, int on);
  * results never change.  N = 1e8, s = 51: 146 GB -> 93 GB resident.  SPKM_ERR_UNSUPPORTED: ragged shard, columns longer
  * than 64, or no room for the records beside the arrays -- nothing was released. */
 int spkm_shard_release_csc(spkm_ctx *ctx, spkm_shard *s);
+/* The stored entries of column `col` (0-based) back on the host -- row ids ascending in ir_out, values in x_out, *count of
+ * them -- whichever layout holds them now (CSC arrays, or the records after spkm_shard_release_csc).  cap = room in
+ * ir_out / x_out; *count > cap: SPKM_ERR_BAD_VALUE and *count says how much is needed.  Blocks on the stream. */
+int spkm_shard_get_column_host(spkm_ctx *ctx, const spkm_shard *s, uint64_t col, uint64_t cap, uint64_t *ir_out,
+                               double *x_out, uint64_t *count);
 void spkm_shard_destroy(spkm_shard *s);
 int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
 
@@ -249,6 +254,18 @@ int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[8]);
  * info[0] = running total (this context) of the points the exact pass actually streamed, info[1] = in the last call.
  * Blocks on the stream. */
 int spkm_exact_pass_points(spkm_ctx *ctx, int64_t info[2]);
+
+/* k-means++ seeding on the device (private/Arthur_initialization.m:38-69).  A round evaluates the distances to the NEWEST
+ * centre only (spkm_assign_dev with K = 1 -> d_dist_new) and
+ *   spkm_kpp_update_dev: d_run = min(d_run, d_dist_new) (first_round != 0: d_run = d_dist_new) -- the reference's
+ *     [~,dist] = findClusterAssignments(X, all chosen centres) bit for bit, at 1/k of the work -- and d_cum = inclusive
+ *     prefix sums of d_run.^2 in a fixed order; *total (host, may be NULL) = their sum (blocks on the stream);
+ *   spkm_kpp_draw_dev: *index (host) = the first i with d_cum[i] > target: randsample(n,1,true,dist.^2) (:50) for
+ *     target = u * total with the HOST's uniform random number u (blocks on the stream).
+ * All buffers are n doubles on the device. */
+int spkm_kpp_update_dev(spkm_ctx *ctx, uint64_t n, const double *d_dist_new, double *d_run, int first_round,
+                        double *d_cum, double *total);
+int spkm_kpp_draw_dev(spkm_ctx *ctx, uint64_t n, const double *d_cum, double target, int64_t *index);
 
 /* centers(:,k) = gamma*S(:,k) ./ (Cnt(:,k) + 1e-16) for clusters with nk > 0
  * (kmeans_sparsified.m:448); empty clusters keep their column.  d_centers is updated in place;

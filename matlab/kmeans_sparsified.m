@@ -6,11 +6,19 @@ function [IDX, C, SUMD, D, OUTPUT, C2, IDX2, D2, SUMD2] = kmeans_sparsified(X, K
 %
 % MATLAB host for libspkm.so (include/spkm.h).  Same entry point, option names, defaults, outputs and error
 % conditions as kmeans_sparsified.m of stephenbeckr/SparsifiedKMeans v2.1 (cited below as REF:line), written from
-% scratch around the GPU engine: the data is sparsified once, uploaded once (spkm_lloyd('upload', X)) and every
-% dense-centre iteration is ONE mex call (spkm_lloyd('iterate', ...): assignment, per-cluster sums, ML-corrected
-% centre update, dff and obj on the device).  Iterations with sparse centres (the first one or two after a
-% 'sample' / k-means++ start) and 'MLcorrection',false go through findClusterAssignments, whose mex
-% (SparseMatrixMinusCluster) is this repository's GPU gateway as well.
+% scratch around the GPU engine.  With 'Sparsify',true and the Hadamard sketch the whole pipeline runs on the device:
+%   * spkm_lloyd('sparsify', X, p2, d, s, seed): X*(1+2eps), zero-pad, D, FWHT / sqrt(p2) and the s sampled rows per
+%     column in ONE fused pass (REF:292-334) -- the dense data crosses PCIe once, the sparse p2 x n matrix never exists on
+%     the host;
+%   * seeding: spkm_lloyd('kpp', K, gam) (k-means++ with a running minimum on the device, MATLAB's rand as the random
+%     source) or spkm_lloyd('columns', randsample(n, K)) ('sample');
+%   * every iteration is ONE mex call that returns centers, dff, obj and the cluster sizes -- nothing of size n;
+%   * IDX and D are fetched ONCE per replicate after the loop (spkm_lloyd('assignments'), spkm_lloyd('distances', ...)),
+%     together with the objective of the last iteration (REF:471 evaluates obj every iteration but uses it only for
+%     Display = 'iter' and after the loop: unless it is displayed per iteration the library may leave it out).
+% Other sketches ('DCT', function handles), 'DataFile' and 'MLcorrection',false keep the reference's host-side route and
+% upload the sparse result (spkm_lloyd('upload', X)); iterations with sparse centres go through findClusterAssignments,
+% whose mex (SparseMatrixMinusCluster) is this repository's GPU gateway as well.
 %
 % STATUS: NOT RUN IN THIS REPOSITORY -- neither MATLAB nor Octave exists in its build / test environment, so this
 % file and the gateways in matlab/*.c are written against the documented mex / MATLAB API and have never been
@@ -73,7 +81,7 @@ end
 if n < K, error('kmeans_sparsified:badDimensions', 'X must have more samples than the number of clusters.'); end
 
 % ---- preconditioner and sparsifier (REF:224-358) ----
-gam = o.SparsityLevel;  p2 = p;  XFull = [];
+gam = o.SparsityLevel;  p2 = p;  XFull = [];  onDevice = false;
 mixf = @(Z) Z;  unmixf = @(Z) Z;
 if o.Sparsify
     sk = o.SketchType;
@@ -119,23 +127,42 @@ if o.Sparsify
     else
         if nargout > 5, XFull = X; end
         if ~isreal(X), error('Code and distance computations require real data'); end
-        X = X * (1 + 2 * eps);                                                  % REF:292
-        t1 = tic;  X = mixf(X);  OUTPUT.TimeToSketch = toc(t1);
         small_p = max(1, round(gam * p2));
         gam = small_p / p;                                                      % REF:329 (divides by p, not p2)
-        t1 = tic;  X = randsample_fixedNumberEntries(X, small_p);  OUTPUT.TimeToSample = toc(t1);
+        onDevice = haveEngine && o.MLcorrection && ischar(sk) && strcmpi(sk, 'Hadamard') && ~issparse(X) && p2 <= 65536;
+        if onDevice
+            % REF:292 (X*(1+2*eps)), :295 (mix), :334 (randsample_fixedNumberEntries) as one fused device pass; the
+            % sampled rows come from a counter-based generator keyed by (seed, column) -- any exact without-replacement
+            % sampler has the reference's distribution (randsample_block.m:44-84)
+            t1 = tic;
+            spkm_lloyd('sparsify', full(X), p2, d, small_p, randi(2^31 - 1));
+            OUTPUT.TimeToSketch = toc(t1);  OUTPUT.TimeToSample = 0;
+            X = [];                                                             % the sparse data lives on the GPU only
+        else
+            X = X * (1 + 2 * eps);                                              % REF:292
+            t1 = tic;  X = mixf(X);  OUTPUT.TimeToSketch = toc(t1);
+            t1 = tic;  X = randsample_fixedNumberEntries(X, small_p);  OUTPUT.TimeToSample = toc(t1);
+        end
     end
     if show('iter') || show('final')
-        fprintf('Randomly taking %.1f%% of the data; actual dataset is %.1f%% sparse\n', 100 * gam, 100 * nnz(X) / numel(X));
+        if onDevice, fprintf('Randomly taking %.1f%% of the data\n', 100 * gam);
+        else, fprintf('Randomly taking %.1f%% of the data; actual dataset is %.1f%% sparse\n', 100 * gam, 100 * nnz(X) / numel(X)); end
     end
-    if o.MLcorrection, Nmask = spones(X); end                                   % REF:352-355
+    if o.MLcorrection && ~onDevice, Nmask = spones(X); end                      % REF:352-355
 elseif fromDisk
     error('kmeans_sparsified:needSparsify', '''DataFile'' is only read on the ''Sparsify'',true path');
 end
-useEngine = haveEngine && issparse(X) && o.MLcorrection;
-if useEngine, spkm_lloyd('upload', X); cleanupObj = onCleanup(@() spkm_lloyd('release')); end %#ok<NASGU>
+useEngine = onDevice || (haveEngine && issparse(X) && o.MLcorrection);
+if useEngine
+    if ~onDevice, spkm_lloyd('upload', X); end
+    cleanupObj = onCleanup(@() spkm_lloyd('release')); %#ok<NASGU>
+end
+lazyObj = ~show('iter');       % obj is displayed per iteration only under Display = 'iter' (REF:472-475)
 
-if ischar(o.Start) && strcmpi(o.Start, 'uniform'), mn = full(min(X(:)));  mx = full(max(X(:))); end
+if ischar(o.Start) && strcmpi(o.Start, 'uniform')
+    if onDevice, error('kmeans_sparsified:uniformOnDevice', 'Start = uniform needs the sparse data on the host (min / max of X)'); end
+    mn = full(min(X(:)));  mx = full(max(X(:)));
+end
 if o.Sparsify && o.unbiasedDistance
     findClusters = @(Z, ctr) findClusterAssignments(Z, ctr, o.tryBuiltinMex, gam);
 else
@@ -151,10 +178,13 @@ for trial = 1:R
     % ---- start (REF:381-415) ----
     if ischar(o.Start)
         switch lower(o.Start)
-            case 'sample',  centers = X(:, randsample(n, K));
+            case 'sample'
+                if onDevice, centers = spkm_lloyd('columns', randsample(n, K)); else, centers = X(:, randsample(n, K)); end
             case 'uniform', centers = (mx - mn) * rand(p2, K) - mn;             % (the reference subtracts mn)
             case {'arthur', '++', 'kmeans++', 'k-means++', 'k-means-++'}
-                if o.Sparsify && o.unbiasedInitialization
+                if onDevice
+                    if o.unbiasedInitialization, centers = spkm_lloyd('kpp', K, gam); else, centers = spkm_lloyd('kpp', K, []); end
+                elseif o.Sparsify && o.unbiasedInitialization
                     centers = Arthur_initialization(X, K, gam);
                 else
                     centers = Arthur_initialization(X, K);
@@ -173,17 +203,20 @@ for trial = 1:R
     if useEngine, spkm_lloyd('reset'); end                                      % nothing learned carries over
 
     % ---- Lloyd iterations (REF:417-486) ----
+    fetched = false;               % IDX / D of the latest iteration are on the host
     for its = 1:o.MaxIter
         old = centers;  dropList = [];
-        if useEngine && ~issparse(centers)
-            % one call: assignment + accumulation + centre update + dff + obj on the GPU
-            [assignments, distances, centers, ~, obj, nk] = spkm_lloyd('iterate', centers, gam, o.unbiasedDistance);
-            emptyK = find(nk == 0);
+        if useEngine && (onDevice || ~issparse(centers))
+            % one call: assignment + accumulation + centre update + dff + obj on the GPU; four small outputs.  Sparse
+            % centres (the iteration after a 'sample' / k-means++ start) take the sparse-centres branch on the device too;
+            % the updated centres come back full (ML-corrected columns are > 99 % filled: REF:460-464)
+            [centers, ~, obj, nk] = spkm_lloyd('iterate', centers, gam, o.unbiasedDistance, lazyObj);
+            emptyK = find(nk == 0);  fetched = false;
         else
             [assignments, distances] = findClusters(X, centers);
             if ~isreal(distances), error('Distance estimates are complex, something went wrong'); end
             if any(distances < 0), error('Found negative distance estimates, something went wrong'); end
-            obj = sqrt(sum(distances .^ 2));
+            obj = sqrt(sum(distances .^ 2));  fetched = true;
             emptyK = [];
             for k = 1:K
                 members = find(assignments == k);
@@ -199,12 +232,21 @@ for trial = 1:R
         for k = emptyK(:).'                                                     % REF:432-445
             warning('kmeans_sparsified:dropCluster', 'cluster has lost all its members');
             switch lower(o.EmptyAction)
-                case 'singleton', [~, far] = max(distances);  centers(:, k) = X(:, far);
+                case 'singleton'
+                    if ~fetched                                                 % this iteration's distances, now (REF:436)
+                        [distances, obj] = spkm_lloyd('distances', old, gam, o.unbiasedDistance);
+                        assignments = spkm_lloyd('assignments');  fetched = true;
+                    end
+                    [~, far] = max(distances);
+                    if onDevice, centers(:, k) = full(spkm_lloyd('columns', far)); else, centers(:, k) = X(:, far); end
                 case 'error',     error('One cluster lost all its members');
                 case 'drop',      dropList(end + 1) = k; %#ok<AGROW>
             end
         end
         if ~isempty(dropList)                                                   % REF:454-459
+            if ~fetched && useEngine                                            % `distances` / obj of THIS iteration stay (REF:471)
+                [distances, obj] = spkm_lloyd('distances', old, gam, o.unbiasedDistance);  fetched = true;
+            end
             keep = setdiff(1:K, dropList);
             centers = centers(:, keep);  old = old(:, keep);  assignments = [];  K = numel(keep);
         end
@@ -216,6 +258,12 @@ for trial = 1:R
         end
         if dff < o.Tol, break; end
         if any(isnan(centers(:))), error('Found NaN in centers'); end
+    end
+    if useEngine && ~fetched
+        % IDX, D and the objective of the iteration that turned out to be the last (REF:420,471): fetched once per replicate.
+        % `old` holds the centres that iteration's assignment was computed with.
+        [distances, obj] = spkm_lloyd('distances', old, gam, o.unbiasedDistance);
+        assignments = spkm_lloyd('assignments');
     end
     OUTPUT.replicateTimes(trial) = toc(t1);
     OUTPUT.stoppingDiff(trial) = dff;  OUTPUT.objectives(trial) = obj;  OUTPUT.iterations(trial) = its;

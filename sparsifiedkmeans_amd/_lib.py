@@ -136,6 +136,9 @@ def lib():
     L.spkm_distances_stats_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp, _vp]
     L.spkm_shard_set_lazy_stats.argtypes = [_vp, C.c_int]
     L.spkm_shard_release_csc.argtypes = [_vp, _vp]
+    L.spkm_shard_get_column_host.argtypes = [_vp, _vp, _u64, _u64, _vp, _vp, C.POINTER(C.c_uint64)]
+    L.spkm_kpp_update_dev.argtypes = [_vp, _u64, _vp, _vp, C.c_int, _vp, C.POINTER(C.c_double)]
+    L.spkm_kpp_draw_dev.argtypes = [_vp, _u64, _vp, C.c_double, C.POINTER(C.c_int64)]
     L.spkm_ctx_reload_switches.argtypes = [_vp]
     L.spkm_widen_f64_dev.argtypes = [_vp, C.c_int, _u64, _vp, _vp]
     L.spkm_comm_unique_id.argtypes = [_vp]

@@ -547,6 +547,44 @@ extern "C" int spkm_shard_info(const spkm_shard* s, uint64_t* p, uint64_t* n, ui
     return SPKM_OK;
 }
 
+// One column of a resident shard back on the host: its stored entries (row ids ascending, values), whichever layout
+// holds them now (CSC arrays, or the record layout after spkm_shard_release_csc).  'sample' starts, k-means++ centres and
+// X(:,iMax) of EmptyAction='singleton' (kmeans_sparsified.m:387,437; Arthur_initialization.m:36,68) need a handful per run.
+extern "C" int spkm_shard_get_column_host(spkm_ctx* ctx, const spkm_shard* s, uint64_t col, uint64_t cap, uint64_t* ir_out,
+                                          double* x_out, uint64_t* count)
+{
+    if (!ctx || !s || !count || (cap && (!ir_out || !x_out))) return SPKM_ERR_NULL_ARG;
+    if (col >= s->n) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    long long j0, j1;
+    if (s->fixed_s > 0) { j0 = (long long)col * s->fixed_s; j1 = j0 + s->fixed_s; }
+    else {
+        long long jj[2];
+        HIP_TRY(hipMemcpy(jj, s->jc + col, 16, hipMemcpyDeviceToHost));
+        j0 = jj[0]; j1 = jj[1];
+    }
+    const uint64_t cnt = (uint64_t)(j1 - j0);
+    *count = cnt;
+    if (cnt > cap) return SPKM_ERR_BAD_VALUE; // (count tells the caller how much room the column needs)
+    if (cnt == 0) return SPKM_OK;
+    const size_t irb = (size_t)s->ir_bits / 8;
+    std::vector<unsigned char> raw(cnt * irb);
+    if (s->x != nullptr) {
+        HIP_TRY(hipMemcpy(x_out, s->x + j0, cnt * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(raw.data(), (const char*)s->ir + (size_t)j0 * irb, cnt * irb, hipMemcpyDeviceToHost));
+    } else {
+        if (!s->rec) return SPKM_ERR_BAD_VALUE;
+        const char* b = s->rec + (size_t)col * (size_t)s->rec_R;
+        HIP_TRY(hipMemcpy(x_out, b, cnt * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(raw.data(), b + (size_t)s->fixed_s * 8, cnt * irb, hipMemcpyDeviceToHost));
+    }
+    for (uint64_t j = 0; j < cnt; j++)
+        ir_out[j] = irb == 2 ? (uint64_t)reinterpret_cast<const unsigned short*>(raw.data())[j]
+                             : (uint64_t)reinterpret_cast<const unsigned int*>(raw.data())[j];
+    return SPKM_OK;
+}
+
 extern "C" uint64_t spkm_reduce_len(uint64_t p, uint64_t K) { return 2 * p * K + K + 1; }
 
 

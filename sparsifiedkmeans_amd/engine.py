@@ -66,6 +66,22 @@ class Shard:
         delivers them for the iteration that needs them."""
         _lib.check(_lib.lib().spkm_shard_set_lazy_stats(self.handle, 1 if on else 0), "spkm_shard_set_lazy_stats")
 
+    def column(self, i: int) -> tuple[np.ndarray, np.ndarray]:
+        """(row ids int64 ascending, values float64) of column ``i`` -- from the CSC arrays or, once they are released,
+        from the record layout (spkm_shard_get_column_host)."""
+        cap = 64
+        while True:
+            ir = np.zeros(cap, np.uint64)
+            x = np.zeros(cap, np.float64)
+            cnt = C.c_uint64()
+            st = _lib.lib().spkm_shard_get_column_host(self.ctx.handle, self.handle, int(i), cap, C.c_void_p(ir.ctypes.data),
+                                                       C.c_void_p(x.ctypes.data), C.byref(cnt))
+            if st == _lib.ERR_BAD_VALUE and cnt.value > cap:
+                cap = int(cnt.value)
+                continue
+            _lib.check(st, "spkm_shard_get_column_host")
+            return ir[: cnt.value].astype(np.int64), x[: cnt.value].copy()
+
     def release_csc(self) -> bool:
         """Let go of the CSC value / row-id arrays once the record layout and the screen copy exist
         (spkm_shard_release_csc): the tensors an adopted shard was built from are dropped here, so that their memory

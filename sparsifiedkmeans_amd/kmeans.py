@@ -25,6 +25,7 @@ SUMD are global.
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
 import warnings
 
@@ -32,6 +33,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
+from . import _lib
 from . import distributed as D_
 from . import synth
 from .engine import (LloydEngine, Shard, StreamingSparsifier, dense_accumulate_device, dense_assign_device, mix_device,
@@ -756,9 +758,16 @@ def _arthur(ctx, shard, column, n, K, gamma, rng, first=0, n_glob=None, dist_on=
             # gamma empty: findClusterAssignments(X, ref) with the SPARSE column (:29) -> sparse-centres branch,
             # distance over supp(x) n supp(c), no scaling (findClusterAssignments.m:71-75)
             eng.assign_sparse_step(c_new, (c_new != 0).to(torch.uint8).contiguous())
-        dist = eng.mind.clone() if dist is None else torch.minimum(dist, eng.mind)
-        cum = torch.cumsum(dist * dist, 0)
-        local_total = float(cum[-1].item()) if n > 0 else 0.0
+        # running minimum + prefix sums of dist.^2 in the library (spkm_kpp_update_dev)
+        first_round = dist is None
+        if first_round:
+            dist = torch.empty_like(eng.mind)
+            cum = torch.empty_like(eng.mind)
+        tot = C.c_double(0.0)
+        _lib.check(_lib.lib().spkm_kpp_update_dev(ctx.handle, n, C.c_void_p(eng.mind.data_ptr()), C.c_void_p(dist.data_ptr()),
+                                                  1 if first_round else 0, C.c_void_p(cum.data_ptr()), C.byref(tot)),
+                   "spkm_kpp_update_dev")
+        local_total = float(tot.value) if n > 0 else 0.0
         if dist_on:
             world = torch.distributed.get_world_size()
             tt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
@@ -773,13 +782,17 @@ def _arthur(ctx, shard, column, n, K, gamma, rng, first=0, n_glob=None, dist_on=
             if total > 0:                                                        # norm(dist) > 0 (:49)
                 u = rng.random() * total                                         # same number on every rank
                 r = int(min(np.searchsorted(edges, u, side="right") - 1, len(totals) - 1))
+                def local_draw(target):
+                    idx = C.c_int64(0)
+                    _lib.check(_lib.lib().spkm_kpp_draw_dev(ctx.handle, n, C.c_void_p(cum.data_ptr()), float(target),
+                                                            C.byref(idx)), "spkm_kpp_draw_dev")
+                    return int(idx.value)
+
                 if not dist_on:
-                    t = torch.tensor([u], dtype=torch.float64, device=dev)
-                    return int(min(torch.searchsorted(cum, t, right=True).item(), n - 1))
+                    return local_draw(u)
                 gi = torch.zeros(1, dtype=torch.float64, device=dev)
                 if torch.distributed.get_rank() == r:
-                    t = torch.tensor([u - edges[r]], dtype=torch.float64, device=dev)
-                    gi[0] = float(first + int(min(torch.searchsorted(cum, t, right=True).item(), n - 1)))
+                    gi[0] = float(first + local_draw(u - edges[r]))
                 torch.distributed.broadcast(gi, src=r)
                 return int(gi.item())
             return int(rng.integers(n_glob))

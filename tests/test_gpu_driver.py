@@ -254,3 +254,33 @@ def test_datafile_with_host_sampler_equals_in_memory(gpu_ctx, tmp_path, sketch):
     b = kmeans_sparsified(fn, 3, Sparsify=True, SparsityLevel=0.2, SketchType=sketch, Start=S, rng=9, MB_limit=0.2)
     assert np.array_equal(a[0], b[0]) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-12)
     assert np.allclose(a[3], b[3], rtol=1e-9, atol=1e-12)
+
+
+def test_kmeanspp_device_helpers_match_numpy(gpu_ctx):
+    """spkm_kpp_update_dev / spkm_kpp_draw_dev: running minimum, prefix sums of dist.^2 and the search for
+    randsample(n,1,true,dist.^2) (Arthur_initialization.m:50) -- against numpy's minimum / cumsum / searchsorted."""
+    import ctypes as C
+    from sparsifiedkmeans_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for n in (1, 5, 1023, 1024, 1025, 70_001, 3_000_000):
+        run_ref = None
+        run = torch.empty(n, dtype=torch.float64, device="cuda")
+        cum = torch.empty(n, dtype=torch.float64, device="cuda")
+        for rnd in range(3):
+            dnew_h = rng.random(n) * 10.0
+            dnew_h[rng.integers(0, n)] = 0.0                         # a chosen point: distance 0 to itself
+            dnew = torch.tensor(dnew_h, device="cuda")
+            tot = C.c_double()
+            _lib.check(L.spkm_kpp_update_dev(gpu_ctx.handle, n, C.c_void_p(dnew.data_ptr()), C.c_void_p(run.data_ptr()),
+                                             1 if rnd == 0 else 0, C.c_void_p(cum.data_ptr()), C.byref(tot)))
+            run_ref = dnew_h if run_ref is None else np.minimum(run_ref, dnew_h)
+            assert np.array_equal(run.cpu().numpy(), run_ref)
+            want = np.cumsum(run_ref * run_ref)
+            got = cum.cpu().numpy()
+            assert np.allclose(got, want, rtol=1e-12, atol=0) and np.all(np.diff(got) >= 0)
+            assert abs(tot.value - want[-1]) <= 1e-12 * want[-1] and tot.value == got[-1]
+            for u in (0.0, 0.3, 0.999999, 1.0):
+                idx = C.c_int64()
+                _lib.check(L.spkm_kpp_draw_dev(gpu_ctx.handle, n, C.c_void_p(cum.data_ptr()), u * tot.value, C.byref(idx)))
+                assert idx.value == min(int(np.searchsorted(got, u * tot.value, side="right")), n - 1)

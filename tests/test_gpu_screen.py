@@ -700,8 +700,14 @@ def test_releasing_the_csc_arrays_changes_nothing_but_the_footprint(gpu_ctx, ora
     c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
     eng.assign_accumulate_step(c)
     _check(eng, oracle, X, Cm, gam)
+    def col_ok(i):
+        r, v = shard.column(i)
+        return np.array_equal(r, X.indices[X.indptr[i]:X.indptr[i + 1]]) and np.array_equal(v, X.data[X.indptr[i]:X.indptr[i + 1]])
+
+    assert col_ok(0) and col_ok(n - 1) and col_ok(777)             # spkm_shard_get_column_host from the CSC arrays
     assert shard.release_csc()
     assert shard.release_csc()                                     # idempotent
+    assert col_ok(0) and col_ok(n - 1) and col_ok(4242)            # ... and from the records
     torch.cuda.empty_cache()
     for it in range(3):                                            # fused calls on the records alone
         Cm = Cm + 0.01 * rng.standard_normal((p, K))
