@@ -151,19 +151,10 @@ struct spkm_shard {
     unsigned* h_nlist = nullptr; // pinned: uncertified count of the previous screen call, copied back asynchronously
     hipEvent_t ev_nlist = nullptr;
     bool nlist_pending = false;
-    int exact_cooldown = 0;      // calls left on the all-exact kernels after a poorly certifying screen
-    // two-phase screen (screen.hip, phase B): rounds evaluated for ALL centroids in the call whose counters are
-    // pending / in the next call (0 = all rounds, the plain screen), and calls left before pruning is retried
-    int prune_pending_a = 0, prune_next_a = 0, prune_cooldown = 0;
-    // hinted two-phase screen: the hints (written by k_bounds_steps from the carried bounds), whether the call whose
-    // counters are pending used them, calls to wait before the next hinted call
+    spkm_policy pol;             // which form the next fused call takes (policy.h), fed by the counters read back one call late
+    // hinted two-phase screen: the hints (written by k_bounds_steps from the carried bounds)
     float* hintu = nullptr;   // per-point hints of the two-phase screen (k_bounds_steps), npad floats
     long long hintu_len = 0;
-    bool hint_pending = false;
-    bool hint_late = true, hint_late_pending = false; // which compiled split the next hinted call uses / the pending one used
-    int hint_late_left = 3;                           // hinted calls left on the late split
-    int hint_cooldown = 0;
-    int hint_fail_streak = 0; // consecutive hinted calls that did not pay: the pause doubles (2, 4, 8, 16 calls)
     // bounds carried between screen calls (screen.hip, k_center_drift): ub | lb | assignment | drift table, the
     // centroids of the call that produced them, and whether they describe this shard's previous call
     float* hb = nullptr;
@@ -173,7 +164,6 @@ struct spkm_shard {
     int hb_K = 0;
     double hb_gamma = 0.0;
     bool hb_valid = false;
-    bool skip_pending = false; // the call whose counters are pending ran the bounds test
     // unchanged-cluster shortcut of the exact pass (screen.hip, k_cluster_need): per-cluster cache of the LOCAL sums and
     // counts (2 p K doubles), obj2 / max distance / its index (3 K), flags need | touched | same | ibeg | icnt (5 K ints)
     double* hb_cum = nullptr;  // [2]: drift accumulated since the lower bounds were stored (screen.hip, k_bounds_steps), by call parity
@@ -183,7 +173,6 @@ struct spkm_shard {
     size_t cl_pk = 0;
     int cl_K = 0;
     bool cl_valid = false;     // the cache describes this shard's previous screen call completely
-    bool pt_next = false;      // the next bounds test lists POINTS, not 16-point steps (the last one passed >= 90 % of the points)
     // lazy statistics + incremental sums (spkm_shard_set_lazy_stats): the caller does not need obj2 / the largest distance
     // from every fused call, so a call may leave the exact pass out and move the per-cluster sums by the points that
     // changed cluster only (events: run_screen, k_accumulate_events)
@@ -193,8 +182,6 @@ struct spkm_shard {
     int* ev_pt = nullptr;        // events of the current call: point | key (K + old cluster, or new cluster); 2 n each
     int* ev_k = nullptr;
     size_t ev_cap = 0;
-    bool movers_known = false, mov_pending_valid = false; // last_movers = points that changed cluster in the last counted call
-    unsigned long long last_movers = 0;
 };
 
 #define HIP_TRY(expr)                                                                                   \
@@ -477,21 +464,9 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
 extern "C" int spkm_shard_reset_policy(spkm_shard* s)
 {
     if (!s) return SPKM_ERR_NULL_ARG;
-    s->exact_cooldown = 0;
-    s->prune_next_a = 0;
-    s->prune_cooldown = 0;
-    s->prune_pending_a = 0;
-    s->hint_cooldown = 0;
-    s->hint_fail_streak = 0;
-    s->hint_pending = false;
-    s->hint_late = true; // a run starts with loose hints
-    s->hint_late_left = 3;
-    s->skip_pending = false;
-    s->pt_next = false;
+    s->pol.reset();
     s->cl_valid = false;
     s->cl_stats_valid = false;
-    s->movers_known = false;
-    s->mov_pending_valid = false;
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
     return SPKM_OK;
@@ -1335,11 +1310,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // hinted two-phase form: needs the carried bounds (the hints are ub + drift) and a split that saves rounds
         hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds;
         if (hinted) {
-            const bool late = sm->hint_late && quad_split_late(q_rounds) > quad_split(q_rounds) && !ctx->sw.no_late_split;
+            const bool late = sm->pol.take_hinted_split(q_rounds, ctx->sw.no_late_split);
             prune_a = late ? quad_split_late(q_rounds) : quad_split(q_rounds);
             ctx->last_hint_late = late;
-            if (sm->hint_late_left > 0) sm->hint_late_left--;
-            if (sm->hint_late_left == 0) sm->hint_late = false;
             if (sm->hintu_len < npad) {
                 if (sm->hintu) (void)hipFree(sm->hintu);
                 sm->hintu = nullptr;
@@ -1350,7 +1323,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const bool skip_enabled = bounds_ok && !ctx->sw.no_bounds;
         // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 90 % of the points
         // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
-        pt_mode = skip_enabled && sm->pt_next && !ctx->sw.no_point_list;
+        pt_mode = skip_enabled && sm->pol.pt_next && !ctx->sw.no_point_list;
         // per-cluster cache / flags of the unchanged-cluster shortcut
         if (!sm->cl_cache || sm->cl_pk != pk || sm->cl_K != K) {
             if (sm->cl_cache) (void)hipFree(sm->cl_cache);
@@ -1372,7 +1345,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // 10.4 ms for a full pass over 1e8 points); no count yet (a run's second call): taken as few -- at worst every
         // point moves and the events cost what the full pass would have.  Whatever is chosen, the sums are the members' sums.
         ev_path = sm->lazy && d_mind == nullptr && kept && sm->cl_valid && !ctx->sw.no_incremental &&
-                  !ctx->sw.no_sort_reuse && (!sm->movers_known || sm->last_movers * 3 <= (unsigned long long)n) &&
+                  !ctx->sw.no_sort_reuse && sm->pol.few_movers((double)n) &&
                   (size_t)p * 12 <= 64 * 1024;
         if (ev_path && sm->ev_cap < (size_t)2 * n) {
             if (sm->ev_pt) (void)hipFree(sm->ev_pt);
@@ -1552,7 +1525,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         if ((rc = ensure(ctx, ctx->cursor, (size_t)K2 * 8))) return rc;
         if ((rc = ensure(ctx, ctx->items, (size_t)max_items_ev * 16))) return rc;
         // (sized by what usually moves, not by the worst case: every kernel strides over the device-side count)
-        const long long ev_est = std::max<long long>(4096, (long long)std::min<unsigned long long>(sm->movers_known ? 4 * sm->last_movers + 4096 : (unsigned long long)n, (unsigned long long)2 * n));
+        const long long ev_est = std::max<long long>(4096, (long long)std::min<unsigned long long>(sm->pol.movers_known ? 4 * sm->pol.last_movers + 4096 : (unsigned long long)n, (unsigned long long)2 * n));
         const int hb_ = (int)std::min<long long>(1024, (ev_est + 1023) / 1024);
         hipLaunchKernelGGL(k_hist, dim3(hb_), dim3(256), (size_t)K2 * 4, ctx->stream, (const int*)sm->ev_k, (long long)0, K2,
                            (unsigned long long*)ctx->nk_ev.p, (const unsigned*)nullptr, ev_n);
@@ -1731,60 +1704,20 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     if (sm->nlist_pending && hipEventQuery(sm->ev_nlist) == hipSuccess) {
         sm->nlist_pending = false;
         ctx->last_listed = sm->h_nlist[0];
-        if (sm->mov_pending_valid) { sm->last_movers = sm->h_nlist[14]; sm->movers_known = true; }
-        const double listed = (double)sm->h_nlist[0], ambig = (double)sm->h_nlist[1], nn = (double)s->n;
-        if (listed > 0.05 * nn) sm->exact_cooldown = 8;
-        // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed
-        // (in cluster-contiguous order the failing points sit together and whole steps are as good)
-        // (entered at 4x, left below 2.5x: the two forms leave slightly different bounds behind, and a choice that flips
-        //  every call pays for both)
-        sm->pt_next = sm->skip_pending && (double)sm->h_nlist[12] >= 0.9 * nn &&
-                      (std::ceil(nn / 16.0) - (double)sm->h_nlist[3]) * 16.0 > (sm->pt_next ? 2.5 : 4.0) * (nn - (double)sm->h_nlist[12]);
-        const int nr = (s->fixed_s + 3) / 4;
-        const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
-        if (sm->hint_pending) {
-            // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only
-            // while the hints do not mislead (stale buffer: many listed points)
-            // (steps skipped on the carried bounds never got as far as their hints)
-            const double steps = std::max(0.0, nn / 16.0 - (double)sm->h_nlist[3]) * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
-            // early or late split (screen.hip, quad_split_late): a run's first three hinted calls use the late one (its
-            // hints are loose: the centroids have just moved a long way), then the early one; an early call that finishes
-            // fewer than 15 % of its (step, tile) pairs early sends the next two back to the late split.  (The late split's
-            // own early-finish share says little about when to leave it -- it moves from 0.37 to 0.44 over the iterations
-            // in which the early split's goes from 0.1 to 0.4 -- so the way back is a fixed count, not a threshold.)
-            const double share = steps > 0.0 ? (double)sm->h_nlist[2] / steps : 1.0;
-            const bool was_late = sm->hint_late_pending;
-            // (only while a good part of the data is on the screen: with most steps settled by the carried bounds the
-            //  few that are left are the hard ones, and the late split just costs more rounds on them)
-            const double all_pairs = nn / 16.0 * std::max(1, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT));
-            if (!was_late && share < 0.15 && steps > 0.25 * all_pairs && sm->hint_late_left == 0) sm->hint_late_left = 2;
-            sm->hint_late = sm->hint_late_left > 0;
-            const bool fallback_to_late = !was_late && sm->hint_late && quad_split_late(nr) > quad_split(nr);
-            if (listed > 0.005 * nn || ((double)sm->h_nlist[2] < 0.05 * steps && steps > 0.01 * nn / 16.0 && !fallback_to_late)) {
-                sm->hint_fail_streak = std::min(sm->hint_fail_streak + 1, 4);
-                sm->hint_cooldown = 1 << sm->hint_fail_streak; // early iterations mislead briefly, not for 16 calls
-            } else {
-                sm->hint_fail_streak = 0;
-                // runner-up bounds of early-finished steps are partial sums, so `ambig` over-counts: still small
-                // means the unconditional form (no hint loads, no second evaluation) is safe to try
-                if (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) sm->prune_next_a = a_prune;
-            }
-        } else if (sm->prune_pending_a == 0)
-            sm->prune_next_a = (ambig <= 0.002 * nn && sm->prune_cooldown == 0 && a_prune < nr) ? a_prune : 0;
-        else if (listed > 0.005 * nn) { sm->prune_next_a = 0; sm->prune_cooldown = 16; }
+        spkm_policy_counters c;
+        c.listed = sm->h_nlist[0]; c.ambig = sm->h_nlist[1]; c.early = sm->h_nlist[2]; c.skipped = sm->h_nlist[3];
+        c.kept = sm->h_nlist[12]; c.movers = sm->h_nlist[14];
+        sm->pol.observe(c, (double)s->n, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT), (s->fixed_s + 3) / 4);
     }
-    if (sm->prune_cooldown > 0) sm->prune_cooldown--;
-    if (sm->hint_cooldown > 0) sm->hint_cooldown--;
-    const bool cooling = sm->exact_cooldown > 0;
-    if (cooling) sm->exact_cooldown--;
+    const spkm_policy::choice ch = sm->pol.next(ctx->sw.no_prune, ctx->sw.no_hint, screen_use_quad(ctx, s));
+    const bool cooling = ch.exact;
     if (s->n > 0 && !cooling && screen_eligible(ctx, s, (int)K64)) {
         ctx->ev_valid = false;
-        int prune_a = ctx->sw.no_prune ? 0 : sm->prune_next_a;
         // Hinted two-phase screen: when the unconditional two-phase form is not chosen and hints are not paused, the
         // screen compares the competition's partial sums with per-point upper bounds taken from the carried bounds
         // (run_screen / k_bounds_steps); needs this shard's previous call to have been a screen call.
-        const bool want_hint = prune_a == 0 && !ctx->sw.no_prune && !ctx->sw.no_hint &&
-                               sm->hint_cooldown == 0 && screen_use_quad(ctx, s);
+        const int prune_a = ch.prune_a;
+        const bool want_hint = ch.want_hint;
         rc = (s->ir_bits == 16) ? run_screen<unsigned short>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint, d_stats, d_nk_u64)
                                 : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint, d_stats, d_nk_u64);
         if (rc) return rc;
@@ -1797,11 +1730,8 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 64, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
             sm->nlist_pending = true;
-            sm->prune_pending_a = (ctx->last_rounds_all < ctx->last_rounds) ? ctx->last_rounds_all : 0;
-            sm->hint_pending = ctx->last_hinted;
-            sm->hint_late_pending = ctx->last_hinted && ctx->last_hint_late;
-            sm->skip_pending = ctx->last_skipping;
-            sm->mov_pending_valid = ctx->last_lib_valid;
+            sm->pol.launched(ctx->last_rounds_all, ctx->last_rounds, ctx->last_hinted, ctx->last_hint_late, ctx->last_skipping,
+                             ctx->last_lib_valid);
         }
         return SPKM_OK; // (statistics and cluster sizes were handed over by run_screen's last kernel)
     }
@@ -2188,7 +2118,8 @@ extern "C" int spkm_kpp_update_dev(spkm_ctx* ctx, uint64_t n64, const double* d_
     hipLaunchKernelGGL(k_kpp_block_scan, dim3(nb), dim3(256), 0, ctx->stream, (const double*)d_run, n, (const double*)part, d_cum);
     HIP_TRY(hipGetLastError());
     if (total) {
-        HIP_TRY(hipMemcpyAsync(total, part + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+        // (the LAST prefix sum, not the sum of the block partials: the two differ in the last bit, and the draw searches d_cum)
+        HIP_TRY(hipMemcpyAsync(total, d_cum + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return SPKM_OK;

@@ -1,0 +1,148 @@
+// Which form the next fused call takes -- the host-side policy of the screen path, on its own so that it can be read,
+// and tested (tests/test_policy.py drives it through tables on the CPU), apart from the launch code in api.hip.
+//
+// Nothing here can change an output: every form computes the reference's assignment; the policy only chooses how much
+// work the next call does.  It sees the counters of a screen call ONE CALL LATE (copied back asynchronously: no host
+// sync on the hot path) and keeps its state per shard.
+//
+//   counters of a screen call (k_combine_screen, k_screen_quad, k_bounds_steps, k_call_tail):
+//     listed   points the certificate could not settle (exact evaluation over all K)
+//     ambig    points whose runner-up is within 2.25x of the winner
+//     early    (16-point step, centroid tile) pairs the hinted form finished after its first rounds
+//     skipped  16-point steps settled by the carried bounds (never screened)
+//     kept     points that passed the carried-bounds test
+//     movers   points that changed cluster (counted when the library holds the previous assignment)
+#pragma once
+#include <algorithm>
+#include <cmath>
+
+#ifdef __HIPCC__
+#define SPKM_HD __host__ __device__
+#else
+#define SPKM_HD
+#endif
+
+// Two-phase forms of the 4-lanes-per-point screen (screen_quad.hip, TWO): the first A = quad_split(NR) rounds for all
+// centroids, the rest only for each tile's leader (or, hinted, for all again when a step's points do not clear their
+// hints).  The split is a compile-time constant: with a run-time split every round sits behind its own branch and the
+// finish's LDS reads are waited for one by one.
+// Late split of the HINTED form (columns of >= 37 entries): half of the rounds.  In the first iterations of a run the
+// hints are loose (the own centroid has just moved a long way) and the competition's partial sums clear them only after
+// about half of the rounds; measured on the headline run (s = 51, 13 rounds) a split at 7 is best in iterations 2-4
+// (28.4 / 27.9 / 26.9 ms against 33.9 / 32.6 / 29.7 at 3), the early one from the fifth on.
+SPKM_HD constexpr int quad_split_late(int nr) { return nr >= 10 ? (nr + 1) / 2 : 0; } // 0: none
+SPKM_HD constexpr int quad_split(int nr) { return nr >= 3 ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : nr; }
+
+struct spkm_policy_counters {
+    double listed = 0, ambig = 0, early = 0, skipped = 0, kept = 0, movers = 0;
+};
+
+struct spkm_policy {
+    // --- what the call whose counters are pending did ---
+    int prune_pending_a = 0;        // rounds it evaluated for all centroids (0: all of them, the plain form)
+    bool hint_pending = false;      // it used the hinted two-phase form ...
+    bool hint_late_pending = false; // ... with the late split
+    bool skip_pending = false;      // it ran the carried-bounds test
+    bool mov_pending_valid = false; // it counted the movers
+    // --- what the next call should do ---
+    int exact_cooldown = 0;         // calls left on the all-exact kernels after a poorly certifying screen
+    int prune_next_a = 0;           // unconditional two-phase form with this many rounds for all centroids (0: no)
+    int prune_cooldown = 0;         // calls to wait before the unconditional form is tried again
+    bool hint_late = true;          // the next hinted call uses the late split
+    int hint_late_left = 3;         // hinted calls left on the late split
+    int hint_cooldown = 0;          // calls to wait before the next hinted call
+    int hint_fail_streak = 0;       // consecutive hinted calls that did not pay: the pause doubles (2, 4, 8, 16 calls)
+    bool pt_next = false;           // the next bounds test lists POINTS, not 16-point steps
+    bool movers_known = false;      // last_movers is a count (not before a run's second screen call has been read back)
+    unsigned long long last_movers = 0;
+
+    // a new start / new replicate (spkm_shard_reset_policy): nothing learned carries over
+    void reset()
+    {
+        *this = spkm_policy();
+    }
+
+    // The counters of the pending call have arrived.  n points, tiles = centroid tiles of the screen, nr = rounds per
+    // column (ceil(s / 4)).
+    void observe(const spkm_policy_counters& c, double n, int tiles, int nr)
+    {
+        if (mov_pending_valid) { last_movers = (unsigned long long)c.movers; movers_known = true; }
+        // more than 5 % of the points on the exact list: the screen pays K-fold exact work for each; 8 calls all-exact
+        if (c.listed > 0.05 * n) exact_cooldown = 8;
+        // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed (in
+        // cluster-contiguous order the failing points sit together and whole steps are as good).  Entered at 4x, left
+        // below 2.5x: the two forms leave slightly different bounds behind, and a choice that flips every call pays for both
+        pt_next = skip_pending && c.kept >= 0.9 * n &&
+                  (std::ceil(n / 16.0) - c.skipped) * 16.0 > (pt_next ? 2.5 : 4.0) * (n - c.kept);
+        const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
+        const int t = std::max(1, tiles);
+        if (hint_pending) {
+            // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only while the
+            // hints do not mislead (many listed points).  Steps skipped on the carried bounds never got as far as their hints.
+            const double steps = std::max(0.0, n / 16.0 - c.skipped) * t;
+            // early or late split: a run's first three hinted calls use the late one, then the early one; an early call
+            // that finishes fewer than 15 % of its pairs early sends the next two back to the late split.  (The late
+            // split's own early-finish share says little about when to leave it -- it moves from 0.37 to 0.44 over the
+            // iterations in which the early split's goes from 0.1 to 0.4 -- so the way back is a fixed count.)
+            const double share = steps > 0.0 ? c.early / steps : 1.0;
+            const bool was_late = hint_late_pending;
+            // (only while a good part of the data is on the screen: with most steps settled by the carried bounds the few
+            //  that are left are the hard ones, and the late split just costs more rounds on them)
+            const double all_pairs = n / 16.0 * t;
+            if (!was_late && share < 0.15 && steps > 0.25 * all_pairs && hint_late_left == 0) hint_late_left = 2;
+            hint_late = hint_late_left > 0;
+            const bool fallback_to_late = !was_late && hint_late && quad_split_late(nr) > quad_split(nr);
+            if (c.listed > 0.005 * n || (c.early < 0.05 * steps && steps > 0.01 * n / 16.0 && !fallback_to_late)) {
+                hint_fail_streak = std::min(hint_fail_streak + 1, 4);
+                hint_cooldown = 1 << hint_fail_streak; // early iterations mislead briefly, not for 16 calls
+            } else {
+                hint_fail_streak = 0;
+                // runner-up bounds of early-finished steps are partial sums, so `ambig` over-counts: still small means
+                // the unconditional form (no hint loads, no second evaluation) is safe to try
+                if (c.ambig <= 0.002 * n && prune_cooldown == 0 && a_prune < nr) prune_next_a = a_prune;
+            }
+        } else if (prune_pending_a == 0)
+            prune_next_a = (c.ambig <= 0.002 * n && prune_cooldown == 0 && a_prune < nr) ? a_prune : 0;
+        else if (c.listed > 0.005 * n) { prune_next_a = 0; prune_cooldown = 16; }
+    }
+
+    struct choice {
+        bool exact;     // this call runs the all-exact kernels
+        int prune_a;    // unconditional two-phase form: rounds for all centroids (0: not that form)
+        bool want_hint; // the hinted form, if the carried bounds allow it
+    };
+    // One call is about to be issued: tick the pauses, say which form it takes.
+    choice next(bool no_prune, bool no_hint, bool quad)
+    {
+        if (prune_cooldown > 0) prune_cooldown--;
+        if (hint_cooldown > 0) hint_cooldown--;
+        const bool cooling = exact_cooldown > 0;
+        if (cooling) exact_cooldown--;
+        choice ch;
+        ch.exact = cooling;
+        ch.prune_a = no_prune ? 0 : prune_next_a;
+        ch.want_hint = ch.prune_a == 0 && !no_prune && !no_hint && hint_cooldown == 0 && quad;
+        return ch;
+    }
+    // The late-split bookkeeping of a hinted call that is actually issued (run_screen); returns whether it is a late one.
+    bool take_hinted_split(int nr, bool no_late_split)
+    {
+        const bool late = hint_late && quad_split_late(nr) > quad_split(nr) && !no_late_split;
+        if (hint_late_left > 0) hint_late_left--;
+        if (hint_late_left == 0) hint_late = false;
+        return late;
+    }
+    // A screen call has been queued and its counters' read-back started: remember what it was.
+    void launched(int rounds_all, int rounds, bool hinted, bool hinted_late, bool skipping, bool movers_counted)
+    {
+        prune_pending_a = rounds_all < rounds ? rounds_all : 0;
+        hint_pending = hinted;
+        hint_late_pending = hinted && hinted_late;
+        skip_pending = skipping;
+        mov_pending_valid = movers_counted;
+    }
+    // Incremental sums (events) instead of a full accumulation pass: while not too many points move -- at most a third
+    // in the previous counted call (an event pair reads the point twice, through a gather: 0.2 ms per million movers at
+    // s = 51 against 10.4 ms for a full pass over 1e8 points); no count yet (a run's second call): taken as few.
+    bool few_movers(double n) const { return !movers_known || (double)last_movers * 3.0 <= n; }
+};

@@ -1,0 +1,158 @@
+"""CPU: the screen-form policy (sparsifiedkmeans_amd/csrc/policy.h) walked through tables of counters.
+
+The policy decides how much work the next fused call does -- all-exact kernels, plain screen, unconditional or hinted
+two-phase form, early or late split, point or step lists, incremental or full sums -- from the counters of the previous
+screen call; it never decides a result.  Compiled here with g++ behind a small C harness (tests/native)."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+N, TILES, NR = 1_000_000.0, 3, 13          # a shard of 1e6 points, K = 100 (three tiles after the remainder is carried), s = 51
+
+
+@pytest.fixture(scope="module")
+def pol(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("policy") / "libpolicy.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", os.path.join(HERE, "native", "policy_harness.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.pol_new.restype = C.c_void_p
+    for f in (L.pol_free, L.pol_reset):
+        f.argtypes = [C.c_void_p]
+    L.pol_observe.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_int]
+    L.pol_next.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.pol_take_hinted_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.pol_launched.argtypes = [C.c_void_p] + [C.c_int] * 6
+    L.pol_pt_next.argtypes = [C.c_void_p]
+    L.pol_few_movers.argtypes = [C.c_void_p, C.c_double]
+    return L
+
+
+class Walk:
+    """one shard's policy: call() = 'a fused call is issued' (returns its form), seen() = 'its counters arrived'"""
+
+    def __init__(self, L, no_prune=0, no_hint=0, no_late=0):
+        self.L, self.p = L, C.c_void_p(L.pol_new())
+        self.sw = (no_prune, no_hint, no_late)
+        self.bounds = False                  # the library holds bounds from a previous screen call
+
+    def call(self):
+        out = (C.c_int * 3)()
+        self.L.pol_next(self.p, self.sw[0], self.sw[1], 1, out)
+        exact, prune_a, want_hint = out[0], out[1], out[2]
+        if exact:
+            self.bounds = False
+            return "exact"
+        hinted = bool(want_hint and self.bounds and prune_a == 0)
+        late = bool(self.L.pol_take_hinted_split(self.p, NR, self.sw[2])) if hinted else False
+        rounds_all = (self.L.pol_quad_split_late(NR) if late else self.L.pol_quad_split(NR)) if hinted else (prune_a or NR)
+        self.L.pol_launched(self.p, rounds_all, NR, int(hinted), int(late), int(self.bounds), int(self.bounds))
+        self.bounds = True
+        if hinted:
+            return "hinted-late" if late else "hinted-early"
+        return "two-phase" if prune_a else "plain"
+
+    def seen(self, listed=0, ambig=0, early=0, skipped=0, kept=0, movers=0):
+        self.L.pol_observe(self.p, listed, ambig, early, skipped, kept, movers, N, TILES, NR)
+
+
+def test_compiled_splits(pol):
+    assert [pol.pol_quad_split(nr) for nr in (1, 2, 3, 8, 13, 16)] == [1, 2, 2, 2, 3, 4]
+    assert [pol.pol_quad_split_late(nr) for nr in (9, 10, 13, 16)] == [0, 5, 7, 8]
+
+
+def test_first_call_is_plain_and_well_separated_data_goes_two_phase(pol):
+    w = Walk(pol, no_hint=1)
+    assert w.call() == "plain"
+    w.seen(listed=10, ambig=0.001 * N)                       # < 0.2 % ambiguous: the unconditional two-phase form is safe
+    assert w.call() == "two-phase"
+    w.seen(listed=0.001 * N)                                 # it certifies well: stays
+    assert w.call() == "two-phase"
+    w.seen(listed=0.006 * N)                                 # > 0.5 % listed: plain again, and no retry for 16 calls
+    forms = []
+    for _ in range(17):
+        forms.append(w.call())
+        w.seen(ambig=0.0)                                    # (a plain call with nothing ambiguous asks for two-phase again ...)
+    assert forms[:15] == ["plain"] * 15 and forms[-1] == "two-phase"   # ... but the pause holds for its 16 calls
+
+
+def test_many_listed_points_send_the_next_calls_to_the_exact_kernels(pol):
+    w = Walk(pol)
+    assert w.call() == "plain"
+    w.seen(listed=0.06 * N, ambig=0.5 * N)
+    assert [w.call() for _ in range(8)] == ["exact"] * 8
+    assert w.call() == "plain"                               # the bounds are gone with the exact calls: no hints yet
+
+
+def test_hinted_form_late_split_first_then_early_and_back(pol):
+    w = Walk(pol)
+    assert w.call() == "plain"
+    w.seen(ambig=0.3 * N)                                    # a cold run: lots of close runners-up, no two-phase
+    forms = []
+    for it in range(3):
+        forms.append(w.call())
+        w.seen(ambig=0.3 * N, early=0.4 * N / 16 * TILES)    # 40 % of the pairs finished early: it pays
+    assert forms == ["hinted-late"] * 3                      # a run's first three hinted calls ask after half of the rounds
+    assert w.call() == "hinted-early"
+    w.seen(ambig=0.3 * N, early=0.10 * N / 16 * TILES)       # the early split finishes < 15 % early on a full screen ...
+    assert [w.call(), ] == ["hinted-late"]                   # ... two calls back on the late split
+    w.seen(ambig=0.3 * N, early=0.4 * N / 16 * TILES)
+    assert w.call() == "hinted-late"
+    w.seen(ambig=0.3 * N, early=0.4 * N / 16 * TILES)
+    assert w.call() == "hinted-early"
+    # with most steps settled by the carried bounds a poor early share does NOT go back to the late split
+    w.seen(ambig=0.1 * N, early=0.10 * 0.1 * N / 16 * TILES, skipped=0.9 * N / 16)
+    assert w.call() == "hinted-early"
+    # SPKM_NO_LATE_SPLIT: always the early one
+    w2 = Walk(pol, no_late=1)
+    w2.call(); w2.seen(ambig=0.3 * N)
+    assert w2.call() == "hinted-early"
+
+
+def test_hints_that_do_not_pay_are_paused_with_doubling(pol):
+    w = Walk(pol)
+    w.call(); w.seen(ambig=0.3 * N)
+    forms = []
+    for _ in range(60):
+        forms.append(w.call())
+        w.seen(ambig=0.3 * N, early=0.0)                     # no step ever finishes early: the hints mislead
+    at = [i for i, f in enumerate(forms) if f.startswith("hinted")]
+    gaps = [b - a - 1 for a, b in zip(at, at[1:])]           # plain calls between two hinted ones
+    # the three late-split calls of a run: pauses of 2, 4, 8 calls (the hinted call included); the first early-split call
+    # that fails on a full screen is not a pause but the way back to the late split (next call, streak forgotten)
+    assert gaps[:4] == [1, 3, 7, 0], (gaps, forms[:20])
+    assert forms[at[3]] == "hinted-early" and forms[at[4]] == "hinted-late"
+
+
+def test_point_lists_enter_at_four_leave_below_two_and_a_half(pol):
+    w = Walk(pol)
+    w.call(); w.seen(ambig=0.3 * N)
+    w.call()                                                 # a call that ran the bounds test
+    steps = N / 16
+
+    def after(kept_share, skipped_share):
+        w.seen(ambig=0.3 * N, early=0.5 * N, kept=kept_share * N, skipped=skipped_share * steps)
+        r = pol.pol_pt_next(w.p)
+        w.call()
+        return r
+
+    assert after(0.85, 0.1) == 0                             # < 90 % of the points passed
+    assert after(0.98, 0.95) == 0                            # steps left hold 5 % of the points vs 2 % failing: 2.5x < 4x
+    assert after(0.98, 0.90) == 1                            # 10 % vs 2 %: 5x -> point lists
+    assert after(0.98, 0.94) == 1                            # 3x: stays (left only below 2.5x)
+    assert after(0.98, 0.96) == 0                            # 2x: back to steps
+
+
+def test_incremental_sums_while_at_most_a_third_of_the_points_move(pol):
+    w = Walk(pol)
+    assert pol.pol_few_movers(w.p, N) == 1                   # no count yet (a run's second call): taken as few
+    w.call(); w.seen()                                       # the first call cannot count movers (no previous assignment)
+    assert pol.pol_few_movers(w.p, N) == 1
+    w.call(); w.seen(movers=0.4 * N)
+    assert pol.pol_few_movers(w.p, N) == 0
+    w.call(); w.seen(movers=0.3 * N)
+    assert pol.pol_few_movers(w.p, N) == 1
+    pol.pol_reset(w.p)
+    assert pol.pol_few_movers(w.p, N) == 1
