@@ -2114,7 +2114,7 @@ extern "C" int spkm_kpp_update_dev(spkm_ctx* ctx, uint64_t n64, const double* d_
     if ((rc = ensure(ctx, ctx->tmp_mind, (size_t)(nb + 1) * 8))) return rc;
     double* part = (double*)ctx->tmp_mind.p;
     hipLaunchKernelGGL(k_kpp_min_partial, dim3(nb), dim3(256), 0, ctx->stream, d_dist_new, d_run, n, first_round ? 1 : 0, part);
-    hipLaunchKernelGGL(k_kpp_scan_partials, dim3(1), dim3(256), 0, ctx->stream, part, nb);
+    hipLaunchKernelGGL(k_kpp_scan_partials, dim3(1), dim3(1), 0, ctx->stream, part, nb);
     hipLaunchKernelGGL(k_kpp_block_scan, dim3(nb), dim3(256), 0, ctx->stream, (const double*)d_run, n, (const double*)part, d_cum);
     HIP_TRY(hipGetLastError());
     if (total) {

@@ -107,53 +107,56 @@ __global__ __launch_bounds__(256) void k_combine(const double* __restrict__ part
 // one-block scan of the partials, per-block scan) and a search for the first index whose cumulative weight exceeds
 // u x total, u the HOST's uniform random number (the random stream stays the host's).
 #define KPP_BLOCK 1024
-// run[i] = min(run[i], dnew[i]) (first round: run = dnew); part[b] = sum over block b of run[i]^2
-__global__ __launch_bounds__(256) void k_kpp_min_partial(const double* __restrict__ dnew, double* __restrict__ run,
-                                                         long long n, int first_round, double* __restrict__ part)
+// The prefix sums must be MONOTONE (the draw is a binary search), so every partial result is built by the same chain of
+// additions wherever it is needed: a thread owns 4 consecutive elements (a0 <= a1 <= a2 <= a3 their running sums), thread
+// 0 walks the 256 thread totals serially (e[t+1] = fl(e[t] + a3[t])), a block's total is fl(e[255] + a3[255]), and the
+// block offsets are one serial chain part[b+1] = fl(part[b] + total[b]).  Then cum = fl(part[b] + fl(e[t] + a_j)) never
+// decreases: floating-point addition is monotone in each argument.
+__device__ __forceinline__ void kpp_block_prefix(const double* sh /* KPP_BLOCK squares */, double* seg /* 256 */,
+                                                 double& a0, double& a1, double& a2, double& a3, double& e)
 {
-    __shared__ double sh[4];
+    const int e0 = threadIdx.x * 4;
+    a0 = sh[e0]; a1 = a0 + sh[e0 + 1]; a2 = a1 + sh[e0 + 2]; a3 = a2 + sh[e0 + 3];
+    seg[threadIdx.x] = a3;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int t = 0; t < 256; t++) { const double v = seg[t]; seg[t] = run; run = run + v; }
+    }
+    __syncthreads();
+    e = seg[threadIdx.x];
+}
+// run[i] = min(run[i], dnew[i]) (first round: run = dnew); total[b] = sum over block b of run[i]^2
+__global__ __launch_bounds__(256) void k_kpp_min_partial(const double* __restrict__ dnew, double* __restrict__ run,
+                                                         long long n, int first_round, double* __restrict__ total)
+{
+    __shared__ double sh[KPP_BLOCK];
+    __shared__ double seg[256];
     const long long base = (long long)blockIdx.x * KPP_BLOCK;
-    double acc = 0.0;
     for (int t = threadIdx.x; t < KPP_BLOCK; t += 256) {
         const long long i = base + t;
+        double v = 0.0;
         if (i < n) {
-            double v = dnew[i];
+            v = dnew[i];
             if (!first_round) { const double r = run[i]; v = r < v ? r : v; }
             run[i] = v;
-            acc += v * v;
         }
+        sh[t] = v * v;
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    double a0, a1, a2, a3, e;
+    kpp_block_prefix(sh, seg, a0, a1, a2, a3, e);
+    if (threadIdx.x == 255) total[blockIdx.x] = e + a3;
 }
-// exclusive scan of the block partials in place (one workgroup, sequential over tiles of 256); part[nb] = total
-__global__ __launch_bounds__(256) void k_kpp_scan_partials(double* __restrict__ part, int nb)
+// part[b] = exclusive serial prefix of the block totals, in place; part[nb] = grand total (one thread: nb <= 1e5 additions)
+__global__ void k_kpp_scan_partials(double* __restrict__ part, int nb)
 {
-    __shared__ double sh[256];
-    __shared__ double carry;
-    if (threadIdx.x == 0) carry = 0.0;
-    __syncthreads();
-    for (int t0 = 0; t0 < nb; t0 += 256) {
-        const int t = t0 + threadIdx.x;
-        const double v = t < nb ? part[t] : 0.0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan
-            const double add = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
-            __syncthreads();
-            sh[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (t < nb) part[t] = carry + sh[threadIdx.x] - v; // exclusive
-        __syncthreads();
-        if (threadIdx.x == 255) carry += sh[255];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) part[nb] = carry;
+    if (blockIdx.x || threadIdx.x) return;
+    double run = 0.0;
+    for (int b = 0; b < nb; b++) { const double v = part[b]; part[b] = run; run = run + v; }
+    part[nb] = run;
 }
-// cum[i] = part[block] + inclusive sum of run^2 inside the block (thread 0 of each block walks it: fixed order)
+// cum[i] = part[block] + (e[thread] + a_j)
 __global__ __launch_bounds__(256) void k_kpp_block_scan(const double* __restrict__ run, long long n,
                                                         const double* __restrict__ part, double* __restrict__ cum)
 {
@@ -162,23 +165,14 @@ __global__ __launch_bounds__(256) void k_kpp_block_scan(const double* __restrict
     const long long base = (long long)blockIdx.x * KPP_BLOCK;
     for (int t = threadIdx.x; t < KPP_BLOCK; t += 256) { const long long i = base + t; const double v = i < n ? run[i] : 0.0; sh[t] = v * v; }
     __syncthreads();
-    // each thread owns 4 consecutive elements; scan of the 256 thread totals, then the per-thread prefixes
-    const int e0 = threadIdx.x * 4;
-    const double a0 = sh[e0], a1 = a0 + sh[e0 + 1], a2 = a1 + sh[e0 + 2], a3 = a2 + sh[e0 + 3];
-    seg[threadIdx.x] = a3;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const double add = (int)threadIdx.x >= off ? seg[threadIdx.x - off] : 0.0;
-        __syncthreads();
-        seg[threadIdx.x] += add;
-        __syncthreads();
-    }
-    const double before = part[blockIdx.x] + (threadIdx.x ? seg[threadIdx.x - 1] : 0.0);
-    const long long i = base + e0;
-    if (i < n) cum[i] = before + a0;
-    if (i + 1 < n) cum[i + 1] = before + a1;
-    if (i + 2 < n) cum[i + 2] = before + a2;
-    if (i + 3 < n) cum[i + 3] = before + a3;
+    double a0, a1, a2, a3, e;
+    kpp_block_prefix(sh, seg, a0, a1, a2, a3, e);
+    const double off = part[blockIdx.x];
+    const long long i = base + threadIdx.x * 4;
+    if (i < n) cum[i] = off + (e + a0);
+    if (i + 1 < n) cum[i + 1] = off + (e + a1);
+    if (i + 2 < n) cum[i + 2] = off + (e + a2);
+    if (i + 3 < n) cum[i + 3] = off + (e + a3);
 }
 // out[0] = first index i with cum[i] > target (clamped to n - 1): searchsorted(cum, target, right)
 __global__ void k_kpp_search(const double* __restrict__ cum, long long n, double target, long long* __restrict__ out)
