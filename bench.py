@@ -507,7 +507,10 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
     scr = kms[0::2][:its] if kms.size >= 2 * its else np.array([])
     acc = kms[1::2][:its] if kms.size >= 2 * its else np.array([])
     total = float(ms.sum()) * 1e-3
-    tail = ms[-min(3, its):]
+    # (a run's LAST step also fetches that iteration's distances and objective -- once per run, as kmeans_sparsified()
+    #  does: the settled figure is taken over the three iterations before it, the fetch reported by itself)
+    tail = ms[-min(4, its):-1] if its >= 2 else ms[-1:]
+    fetch_ms = float(ms[-1] - tail.mean()) if its >= 2 else None
     r = {"iterations": its, "converged": bool(dff < TOL), "ended_by": "tol" if dff < TOL else "maxiter",
          "final_dff": dff, "final_obj": objs[-1], "seconds": total,
          # one whole run from the cold start: to dff < Tol if `converged`, else capped at MaxIter (then it is a
@@ -519,6 +522,7 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
          "whole_iter_cold": {"bytes": b_iter, "ms": float(ms[0]), "GBs": b_iter / (float(ms[0]) * 1e-3) / 1e9,
                              "frac": b_iter / (float(ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
          "converged_ms": float(tail.mean()), "converged_iters_per_s": 1e3 / float(tail.mean()),
+         "distances_and_objective_once_per_run_ms": fetch_ms,
          # for comparison across rounds only: round 1 timed iterations W+1 .. W+K of ONE run (its --warmup 5 --steps 20 window)
          "r01_window_iters_6_to_25_per_s": (20.0 / (float(ms[5:25].sum()) * 1e-3)) if its >= 25 else None,
          "per_iter_ms": [round(float(v), 2) for v in ms],
@@ -532,7 +536,7 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
         last_pts = loop.eng.exact_pass_points()[1]
         share = last_pts / max(loop.shard.n, 1)
         r["exact_pass_points_share_last_iter"] = share
-        r["roofline_converged"] = roofline_obj("k_exact_accumulate", float(acc[-min(3, its):].mean()), int(b_acc * share),
+        r["roofline_converged"] = roofline_obj("k_exact_accumulate", float(acc[-min(4, its):-1].mean()) if its >= 2 else float(acc[-1]), int(b_acc * share),
                                                f"exact confirmation + accumulation pass over the {share:.3f} of the points in clusters "
                                                "that changed; (nnz*(8+2) + n*8 + 16*p*K) bytes scaled by that share")
     loop.restart()

@@ -60,6 +60,7 @@ struct spkm_switches {
     bool no_dist1 = false;        // SPKM_NO_DIST1: K = 1 calls go through the tiled exact kernel
     bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
+    bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
 static spkm_switches read_switches()
 {
@@ -80,6 +81,7 @@ static spkm_switches read_switches()
     w.no_dist1 = on("SPKM_NO_DIST1");
     w.no_incremental = on("SPKM_NO_INCREMENTAL");
     w.no_support_drift = on("SPKM_NO_SUPPORT_DRIFT");
+    w.no_teams = on("SPKM_NO_TEAMS");
     return w;
 }
 
@@ -92,7 +94,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev, fin_ticket;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
@@ -291,7 +293,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->mscr, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->bstat, &ctx->nk_ev};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->bstat, &ctx->nk_ev, &ctx->fin_ticket};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -703,7 +705,7 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
     int& slot_key = ctx->bmapq_key;
     int& slot_blocks = ctx->bmapq_blocks;
     const int NB = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    const int key = G * 64 + pl_last * 8 + 1000003 * rounds;
+    const int key = G * 64 + pl_last * 8 + 1000003 * rounds + (ctx->sw.no_teams ? 7 : 0);
     if (slot_key == key && slot_blocks == NB) return SPKM_OK;
     const int NX = (NB % 8 == 0) ? 8 : 1;
     const int per = NB / NX;
@@ -717,7 +719,7 @@ static int build_blockmap_quad(spkm_ctx* ctx, int G, int pl_last, int rounds)
         return (double)rounds * (32.0 + 32.0 * pl + (pl == 4 ? 12.0 : 0.0)) + 560.0;
     };
     std::vector<spkm_blockmap> bm(NB, spkm_blockmap{-1, 0, 1, 0});
-    if (pl_last >= 4) {
+    if (pl_last >= 4 && !ctx->sw.no_teams) {
         // TEAMS: every tile costs the same per chunk (full tiles; with pl_last = 5 the remainder of <= 4 centroids is
         // carried by the G tiles in turn, chunk by chunk -- screen_quad.hip, `rot`).  A team is one workgroup per tile on
         // ONE XCD; team t takes chunks t, t + nteams, ...; its members sweep them in the same order at the same pace, so
@@ -1395,11 +1397,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     } else
         sm->hb_valid = false;
     zero_flush();
+    // (one launch: the f32 tiles, the row-major f64 centres of the exact list, the library's copy for the next call's drift)
     hipLaunchKernelGGL(k_prep_tiles_f32, dim3((unsigned)std::min<size_t>((tile_floats + 255) / 256, 2048)), dim3(256),
                        0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
-                       (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0);
-    hipLaunchKernelGGL(k_prep_rowmajor, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0,
-                       ctx->stream, d_centers, p, K, gamma, (double*)ctx->ct.p);
+                       (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0, (double*)ctx->ct.p,
+                       quad ? sm->hb_centers : (double*)nullptr);
     // 1. screen
     const int sweep = 16 * 16;
     long long chunk = n / ((long long)(quad ? ctx->bmapq_blocks / 4 : ctx->bmap_streams) * 8);
@@ -1492,7 +1494,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // the cluster sizes (a separate pass comparing the two arrays used to do that: 0.16 ms per call at N = 1e8)
     int* a_lib = quad ? (int*)(sm->hb + 2 * npad) : (int*)nullptr;
     const int cb = (int)std::min<long long>(4096, (n + 255) / 256); // (8192+: the cold pass gains 6 %, the short lists of a converged run lose 70 %)
-    hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), nk_incr ? (size_t)K * 4 : 0, ctx->stream, (const float*)ctx->scr_m1.p,
+    hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), ((nk_incr ? (size_t)K : 0) + (ev_path ? (size_t)2 * K : 0)) * 4, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
                        (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
@@ -1500,7 +1502,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        quad ? (const double*)(sm->hb_cum + sm->cum_par) : (const double*)nullptr,
                        bounds_ok ? 1 : 0, cl_skip ? cl_touched : (int*)nullptr, K,
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
-                       ev_path ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr);
+                       ev_path ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr,
+                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1508,7 +1511,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
                        ev_path ? sm->hb : (float*)nullptr, ev_path ? sm->ev_pt : (int*)nullptr,
                        ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p,
-                       s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R);
+                       s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
+                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     ctx->last_lib_valid = bounds_ok;
     ctx->last_incremental = ev_path;
@@ -1518,7 +1522,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // histogram / plan / placement kernels as the points of a full pass, their number read on the device
         const unsigned* ev_n = (const unsigned*)ctx->nlist.p + 16;
         const int K2 = 2 * K;
-        const int seg_ev = SEG_POINTS;
+        // (few events -- a settled run moves a few thousand points per call --: short segments, so that they spread over
+        //  more than a handful of workgroups)
+        const int seg_ev = (sm->pol.movers_known && sm->pol.last_movers < 100000) ? 256 : SEG_POINTS;
         const int max_items_ev = (int)((2 * n) / seg_ev) + K2 + 1;
         if ((rc = ensure(ctx, ctx->perm, (size_t)2 * n * 4))) return rc;
         if ((rc = ensure(ctx, ctx->offs, (size_t)(K2 + 1) * 8))) return rc;
@@ -1527,8 +1533,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // (sized by what usually moves, not by the worst case: every kernel strides over the device-side count)
         const long long ev_est = std::max<long long>(4096, (long long)std::min<unsigned long long>(sm->pol.movers_known ? 4 * sm->pol.last_movers + 4096 : (unsigned long long)n, (unsigned long long)2 * n));
         const int hb_ = (int)std::min<long long>(1024, (ev_est + 1023) / 1024);
-        hipLaunchKernelGGL(k_hist, dim3(hb_), dim3(256), (size_t)K2 * 4, ctx->stream, (const int*)sm->ev_k, (long long)0, K2,
-                           (unsigned long long*)ctx->nk_ev.p, (const unsigned*)nullptr, ev_n);
+        // (the histogram over the 2 K keys was collected by k_combine_screen / k_assign_list as they appended the events)
         hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk_ev.p, K2,
                            seg_ev, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
                            (int*)ctx->nitems.p, (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
@@ -1547,13 +1552,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         if (ctx->tlog_both) HIP_TRY(timing_end(ctx));
         HIP_TRY(hipGetLastError());
         // the call's sums and counts ARE the cache (rows that no member stores any more: exactly 0)
-        hipLaunchKernelGGL(k_sums_from_cache, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 1024)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_call_tail, dim3((unsigned)std::max<size_t>((K + 255) / 256, std::min<size_t>((pk + 255) / 256, 1024))), dim3(256),
+                           0, ctx->stream, (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
+                           (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p, 1,
                            cache_s, (const double*)cache_c, pk, sums, counts);
-        hipLaunchKernelGGL(k_call_tail, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
-                           (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
-                           (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p, 1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(sm->hb_centers, d_centers, pk * 8, hipMemcpyDeviceToDevice, ctx->stream));
         sm->hb_K = K;
         sm->hb_gamma = gamma;
         sm->hb_valid = true;
@@ -1677,7 +1680,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p);
     HIP_TRY(hipGetLastError());
     if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
-        HIP_TRY(hipMemcpyAsync(sm->hb_centers, d_centers, pk * 8, hipMemcpyDeviceToDevice, ctx->stream));
         sm->hb_K = K;
         sm->hb_gamma = gamma;
         sm->hb_valid = true;
@@ -1948,11 +1950,14 @@ extern "C" int spkm_finalize_dev(spkm_ctx* ctx, uint64_t p, uint64_t K, const do
     const size_t pk = (size_t)p * K;
     int rc;
     if ((rc = ensure(ctx, ctx->blk_dff, FIN_BLOCKS * 8))) return rc;
+    if (!ctx->fin_ticket.p) {
+        if ((rc = ensure(ctx, ctx->fin_ticket, 64))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->fin_ticket.p, 0, 64, ctx->stream)); // (the kernel's last workgroup resets it after every call)
+    }
     const int fb = (int)std::min<size_t>(FIN_BLOCKS, (pk + 255) / 256);
     hipLaunchKernelGGL(k_finalize_centers, dim3(fb), dim3(256), 0, ctx->stream, d_reduce, d_reduce + pk,
-                       d_reduce + 2 * pk, (int)p, (int)K, gamma, d_centers, (double*)ctx->blk_dff.p);
-    hipLaunchKernelGGL(k_reduce_dff, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->blk_dff.p, fb, d_out,
-                       d_reduce + 2 * pk + K);
+                       d_reduce + 2 * pk, (int)p, (int)K, gamma, d_centers, (double*)ctx->blk_dff.p,
+                       (unsigned*)ctx->fin_ticket.p, d_out, (const double*)(d_reduce + 2 * pk + K));
     HIP_TRY(hipGetLastError());
     return SPKM_OK;
 }

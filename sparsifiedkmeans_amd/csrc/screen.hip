@@ -51,8 +51,25 @@
 //    q ^ ((r >> 1) & 3) (the kernel's stored row ids carry the same two bits, k_screen_reorder).
 __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int G, double gamma,
                                  float* __restrict__ T32, unsigned long long* __restrict__ cmax_bits, int pl_last,
-                                 int swz)
+                                 int swz, double* __restrict__ Cs, double* __restrict__ keep)
 {
+    // Two more views of the same centres ride along (they were launches of their own: a small shard's settled iteration is
+    // a chain of ~5-us kernels): Cs[r*K + k] = C[k*p + r] / gamma, row-major for the exact list kernel (k_assign_list),
+    // and keep = C itself, the library's copy that the NEXT call's drift is measured from (k_center_drift has already
+    // read the previous copy: it is launched before this kernel).
+    if (Cs != nullptr || keep != nullptr) {
+        const size_t pkk = (size_t)p * K;
+        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pkk; t += (size_t)gridDim.x * blockDim.x) {
+            if (keep != nullptr) keep[t] = C[t];
+            if (Cs != nullptr) {
+                const int k = (int)(t % K);
+                const size_t r = t / K;
+                double v = C[(size_t)k * p + r];
+                if (gamma > 0.0) v = v / gamma;
+                Cs[t] = v;
+            }
+        }
+    }
     const size_t total = (size_t)G * (p + 1) * SCREEN_KT;
     double mx = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -812,8 +829,11 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         const double* __restrict__ cum, int lib_valid,
                                                         int* __restrict__ touched, int K,
                                                         unsigned long long* __restrict__ nk,
-                                                        int lazy, int* __restrict__ ev_pt, int* __restrict__ ev_k)
+                                                        int lazy, int* __restrict__ ev_pt, int* __restrict__ ev_k,
+                                                        unsigned long long* __restrict__ nk_ev)
 {
+    // nk_ev (with ev_pt): the histogram of the events over their 2 K keys, collected per workgroup next to the cluster-size
+    // deltas -- the counting sort of the events then needs no histogram pass of its own
     // lazy != 0 (the exact pass will not run in this call, api.hip): a certified point's upper bound is written here,
     // (r1 + eps1) rounded up -- rigorous, if a few 1e-6 looser than the exact distance the pass would have stored -- and
     // every point that changes cluster is recorded as two EVENTS, (point, K + old cluster) and (point, new cluster), for
@@ -834,6 +854,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     //   half the points move in the first iterations of a run, and global atomics on K addresses would take 100 ms).
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     int* delta = reinterpret_cast<int*>(smem_c);
+    unsigned* evc = reinterpret_cast<unsigned*>(smem_c) + (nk ? K : 0); // 2 K event counters (ev_pt != nullptr)
     int* alib = bnd ? reinterpret_cast<int*>(bnd + 2 * npad) : nullptr;
     bool changed = false;
     // bnd != nullptr: write each point's new lower bound (k_center_drift's comment)
@@ -850,6 +871,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     if ((long long)blockIdx.x * blockDim.x >= total) return; // (whole workgroup)
     if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; }
     if (nk) for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
+    if (ev_pt) for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) evc[k] = 0u;
     __syncthreads();
     unsigned nmov = 0;
     auto flush_events = [&]() { // (whole workgroup)
@@ -931,8 +953,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         }
         if (mover) {
             unsigned at = wbase + (unsigned)(incl - cnt);
-            if (mv_old >= 0) { s_evp[at] = (int)i; s_evk[at] = K + mv_old; at++; }
+            if (mv_old >= 0) { s_evp[at] = (int)i; s_evk[at] = K + mv_old; at++; atomicAdd(&evc[K + mv_old], 1u); }
             s_evp[at] = (int)i; s_evk[at] = mv_new;
+            atomicAdd(&evc[mv_new], 1u);
         }
         __syncthreads();
         if (s_evn + 2u * 256u > (unsigned)EVCAP) flush_events();
@@ -955,6 +978,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     if (nk)
         for (int k = threadIdx.x; k < K; k += blockDim.x)
             if (delta[k]) atomicAdd(&nk[k], (unsigned long long)(long long)delta[k]);
+    if (ev_pt)
+        for (int k = threadIdx.x; k < 2 * K; k += blockDim.x)
+            if (evc[k]) atomicAdd(&nk_ev[k], (unsigned long long)evc[k]);
 }
 
 // Listed points: exact reference arithmetic over all K centroids (row-major scaled centres Cs in
@@ -969,7 +995,8 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      unsigned long long* __restrict__ nk,
                                                      float* __restrict__ ubv, int* __restrict__ ev_pt,
                                                      int* __restrict__ ev_k, unsigned* __restrict__ counters,
-                                                     const char* __restrict__ rec, int rec_R)
+                                                     const char* __restrict__ rec, int rec_R,
+                                                     unsigned long long* __restrict__ nk_ev)
 {
     // alib / lib_valid / touched / nk: the library's copy of the assignment and what follows from a change, as in
     // k_combine_screen (these points kept their previous value there); few points: global atomics
@@ -1048,8 +1075,9 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                         if (nk) { if (vo) atomicAdd(&nk[old], ~0ull); atomicAdd(&nk[bk], 1ull); }
                         if (ev_pt) {
                             const unsigned at = atomicAdd(counters + 16, vo ? 2u : 1u);
-                            if (vo) { ev_pt[at] = (int)i; ev_k[at] = K + old; }
+                            if (vo) { ev_pt[at] = (int)i; ev_k[at] = K + old; atomicAdd(&nk_ev[K + old], 1ull); }
                             ev_pt[at + (vo ? 1u : 0u)] = (int)i; ev_k[at + (vo ? 1u : 0u)] = bk;
+                            atomicAdd(&nk_ev[bk], 1ull);
                         }
                     }
                 }
@@ -1540,10 +1568,10 @@ template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const 
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*);
 
 // ============================================================================================
 // K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through

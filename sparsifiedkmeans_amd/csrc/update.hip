@@ -609,21 +609,6 @@ __global__ __launch_bounds__(256) void k_accumulate_events(const char* __restric
     }
 }
 
-// After the events: the call's sums and counts ARE the cache.  One repair on the way: a row of a cluster that no member
-// stores any more (count 0) must have the sum EXACTLY 0 -- a fresh summation gives that, an add-and-subtract history
-// leaves a residual of rounding noise, and kmeans_sparsified.m:448 divides it by 1e-16.
-__global__ __launch_bounds__(256) void k_sums_from_cache(double* __restrict__ cache_s, const double* __restrict__ cache_c,
-                                                         size_t pk, double* __restrict__ sums, double* __restrict__ counts)
-{
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pk; t += (size_t)gridDim.x * blockDim.x) {
-        const double c = cache_c[t];
-        double v = cache_s[t];
-        if (c == 0.0 && v != 0.0) { v = 0.0; cache_s[t] = 0.0; }
-        sums[t] = v;
-        counts[t] = c;
-    }
-}
-
 // centers(:,k) = (gamma*S(:,k)) ./ (Cnt(:,k) + 1e-16) for non-empty clusters (kmeans_sparsified.m:448);
 // empty clusters keep their old column (the host applies EmptyAction, :432-445).
 // blk_dff2[b] = partial sum of (old - new)^2, reduced in fixed order by k_reduce_dff.
@@ -631,9 +616,14 @@ __global__ __launch_bounds__(256) void k_finalize_centers(const double* __restri
                                                           const double* __restrict__ counts,
                                                           const double* __restrict__ nk_f64, int p, int K,
                                                           double gamma, double* __restrict__ centers,
-                                                          double* __restrict__ blk_dff2)
+                                                          double* __restrict__ blk_dff2, unsigned* __restrict__ ticket,
+                                                          double* __restrict__ out, const double* __restrict__ obj2)
 {
+    // blk_dff2[b] = this workgroup's partial sum of (old - new)^2.  The workgroup that finishes LAST (a ticket counter, reset
+    // for the next call) adds the partials up in a fixed order -- lane l takes blocks l, l + 64, ...; then a shuffle tree --
+    // and writes out = [dff^2, obj^2] (kmeans_sparsified.m:470-471 before sqrt): what used to be a launch of its own.
     __shared__ double s_part[4];
+    __shared__ unsigned s_last;
     const size_t total = (size_t)p * K;
     double acc = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -652,20 +642,20 @@ __global__ __launch_bounds__(256) void k_finalize_centers(const double* __restri
         double o = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); w++) o += s_part[w];
         blk_dff2[blockIdx.x] = o;
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     }
-}
-
-__global__ void k_reduce_dff(const double* __restrict__ blk_dff2, int nblk, double* __restrict__ out_dff2,
-                             const double* __restrict__ obj2)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0 && obj2) out_dff2[1] = *obj2; // d_out = [dff^2, obj^2]
-    // one wave, a fixed order (lane l adds blocks l, l + 64, ...; then a shuffle tree): one thread walking all the
-    // blocks took 17 us of serial load latency per iteration
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    __threadfence();
     double o = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 64) o += blk_dff2[b];
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) o += __builtin_nontemporal_load(blk_dff2 + b);
     for (int off = 32; off > 0; off >>= 1) o += __shfl_down(o, off);
-    if (threadIdx.x == 0) *out_dff2 = o;
+    if (threadIdx.x == 0) {
+        out[0] = o;
+        if (obj2) out[1] = *obj2;
+        *ticket = 0u;
+    }
 }
 
 // nk (u64 counters) -> f64 slots of the reduce buffer, so that one SUM all-reduce covers everything.
@@ -680,8 +670,22 @@ __global__ void k_nk_to_f64(const unsigned long long* __restrict__ nk, int K, do
 __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, double* __restrict__ nk_f,
                             const double* __restrict__ stats, double* __restrict__ obj2, double* __restrict__ d_stats,
                             unsigned long long* __restrict__ d_nk, const unsigned* __restrict__ bstat, int bstat_n,
-                            unsigned* __restrict__ counters, int lazy = 0)
+                            unsigned* __restrict__ counters, int lazy = 0, double* __restrict__ cache_s = nullptr,
+                            const double* __restrict__ cache_c = nullptr, size_t pk = 0, double* __restrict__ sums = nullptr,
+                            double* __restrict__ counts = nullptr)
 {
+    // cache_s != nullptr (incremental calls): the call's sums and counts ARE the cache.  One repair on the way: a row of a
+    // cluster that no member stores any more (count 0) must have the sum EXACTLY 0 -- a fresh summation gives that, an
+    // add-and-subtract history leaves a residual of rounding noise, and kmeans_sparsified.m:448 divides it by 1e-16.
+    if (cache_s != nullptr) {
+        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pk; t += (size_t)gridDim.x * blockDim.x) {
+            const double c = cache_c[t];
+            double v = cache_s[t];
+            if (c == 0.0 && v != 0.0) { v = 0.0; cache_s[t] = 0.0; }
+            sums[t] = v;
+            counts[t] = c;
+        }
+    }
     // lazy != 0: this call did not evaluate the objective, the largest distance and its index (spkm_shard_set_lazy_stats):
     // NaN in their places, so that a caller that reads them anyway cannot mistake them for values
     // bstat: (points kept, steps skipped) per workgroup of k_bounds_steps -> counters[12], counters[3] and the running
