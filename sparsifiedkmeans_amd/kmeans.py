@@ -271,7 +271,7 @@ def kmeans_sparsified(X, K, **options):
             x2_[:nnz] = vals_[nzm_]
             ir2_[:nnz] = sp_.ir[: n * small_p][nzm_]
             shard = Shard.from_device(ctx, p2, jc_, ir2_, x2_, nnz=nnz)
-        del nzm_
+        del nzm_, vals_
         torch.cuda.synchronize()
         OUTPUT["TimeToSketch"] = OUTPUT["TimeToSample"] = time.time() - t1       # fused: one number for both
     else:
@@ -317,10 +317,9 @@ def kmeans_sparsified(X, K, **options):
         """dense copy of local sparse column i"""
         if Y is not None:
             return Y[:, i].toarray().ravel()
-        o_ = i * small_p
-        rows = sp_.ir[o_:o_ + small_p].cpu().numpy().view(np.uint16 if sp_.ir.element_size() == 2 else np.uint32)
+        rows, vals = shard.column(i)         # from the CSC arrays or, once they are released, from the record layout
         col = np.zeros(p2)
-        col[rows.astype(np.int64)] = sp_.x[o_:o_ + small_p].cpu().numpy()
+        col[rows] = vals
         return col
 
     def column(gi):
@@ -394,6 +393,7 @@ def kmeans_sparsified(X, K, **options):
         its = 0
         dff = obj = np.nan
         assignments = None
+        csc_released = False
         dist_t = eng.mind                     # min-distances of the latest iteration (survives a 'drop' re-build of eng)
         mind_pending, eng_used, centers_used = False, eng, centers
         fused_iters = 0
@@ -415,6 +415,15 @@ def kmeans_sparsified(X, K, **options):
                 else:
                     eng.assign_accumulate_step(centers, want_mind=False)
                 fused_iters += 1
+                if Y is None and not csc_released and fused_iters == 1:
+                    # the first fused call has built the library's record layout and screen copy: the CSC value / row
+                    # arrays of the device-built shard can go (spkm_shard_release_csc; an entry point that needs them
+                    # -- the k-means++ rounds of the next replicate -- brings them back from the records)
+                    torch.cuda.synchronize()
+                    if shard.release_csc():
+                        sp_.x = sp_.ir = None
+                        torch.cuda.empty_cache()
+                    csc_released = True
             if mask_t is not None:
                 old = centers.clone()
             mind_pending = mask_t is None          # the distances of THIS iteration still have to be materialised
