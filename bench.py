@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md chip table: 8.0 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz (non-fused ops; 78.6 TFLOP/s counts FMA as 2)
 TOL, MAXITER = 1e-6, 100       # kmeans_sparsified.m:133,135 defaults
+DUMP = bool(os.environ.get("SPKM_BENCH_DUMP"))   # per-call kernel times and forms of the timed region on stderr (diagnostics)
 
 
 def main():
@@ -195,6 +196,7 @@ def main():
             self.prev = centers0_.clone()           # the centres the latest assignment was computed with
             self.restart()
             self.runs_completed, self.run_lengths = 0, []
+            self.forms = []
 
         def restart(self):
             self.centers.copy_(self.c0)
@@ -206,6 +208,9 @@ def main():
             self.prev.copy_(self.centers)
             out = self.eng.iterate(self.centers, want_mind=False).cpu().numpy()   # host sync: the driver needs dff to decide
             self.it += 1
+            if DUMP:   # diagnostics: the form each call took (rounds for all centroids, early-finished pairs, skipped steps)
+                md = self.eng.last_screen_mode()
+                self.forms.append((self.it, md[0], self.eng.last_screen_rounds()[0], md[3], md[4]))
             dff = float(np.sqrt(out[0]))
             done = dff < TOL or self.it >= MAXITER
             obj = float(np.sqrt(out[1]))            # NaN when the library left the objective out of this call
@@ -286,8 +291,9 @@ def main():
     mode = eng.last_screen_mode()
     kms = read_tlog(2 * max(args.steps, 1))
     _lib.check(L.spkm_timing_log(ctx.handle, 0))
-    if os.environ.get("SPKM_BENCH_DUMP") and rank == 0:   # per-call kernel times of the timed region (diagnostics)
+    if DUMP and rank == 0:
         print("per-call ms:", [round(float(v), 3) for v in kms], "last screen mode:", mode, file=sys.stderr)
+        print("forms (iteration, form, rounds for all, early pairs, skipped steps):", loop.forms[-args.steps:], file=sys.stderr)
     if path == 1 and kms.size == 2 * args.steps:
         screen_ms, acc_ms = float(kms[0::2].mean()), float(kms[1::2].mean())
     else:                                       # all-exact path (or a mix after a back-off): the tile kernel only
