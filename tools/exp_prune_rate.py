@@ -62,15 +62,18 @@ for it in range(1, 11):
         Pm = prev_c if Kdim == 0 else prev_c.t()
         d = (Cm - Pm) / gamma
         top = d.pow(2).topk(s, dim=1).values.sum(1).sqrt()              # drift on the support (per centroid)
-        hint_cons = (prev_ub + top[prev_a].float())                     # what the library carries
+        hint_cons = (prev_ub + top[prev_a].float())                     # carried bound + rigorous drift
+        full_d2 = d.pow(2).sum(1)
+        hint_lib = (prev_ub ** 2 + (2.0 * s / p2) * full_d2[prev_a].float()).sqrt()   # what k_bounds_steps writes
         hint_best = full[torch.arange(m), prev_a].sqrt()                # the tightest a hint could be
         moved = float((a != prev_a).float().mean())
         line = [f"it {it}: moved {moved:.3f}"]
         for A in (3, 5, 7):
             part = dist2(cur, 4 * A)
             part[torch.arange(m), prev_a] = float("inf")                # the hinted centroid itself is always evaluated
-            for name, h in (("cons", hint_cons), ("best", hint_best)):
-                alive = part <= (h * h)[:, None] * (1 + 1e-5)           # pairs that survive phase A
+            for name, h, fac in (("cons x1.0", hint_cons, 1.0), ("lib x1.5", hint_lib, 1.5), ("best x1.5", hint_best, 1.5),
+                                 ("best x1.0", hint_best, 1.0)):
+                alive = part <= (h * h)[:, None] * fac                  # pairs that survive phase A (kernel: m2 >= 1.5 h^2)
                 t32 = torch.stack([alive[:, 0:32].any(1), alive[:, 32:64].any(1), alive[:, 64:100].any(1)], 1)
                 own_tile = torch.clamp(prev_a // 32, max=2)
                 other = torch.ones_like(t32)
