@@ -218,7 +218,9 @@ static hipError_t allow_lds(spkm_ctx* ctx, const void* kern, size_t bytes)
 static int ensure(spkm_ctx* ctx, devbuf& b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return SPKM_OK;
-    ctx->sort_owner = nullptr; // (any reallocation: the kept counting sort may have lived there)
+    // (a buffer that is replaced may have held the kept counting sort; one that is allocated for the first time cannot --
+    //  a context's first call allocates several after its sort is queued, and used to lose the sort for the second call)
+    if (b.p) ctx->sort_owner = nullptr;
     if (b.p) HIP_TRY(hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -1287,7 +1289,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const long long npad = (n + 63) / 64 * 64;
     int bstat_n = 0; // workgroups of k_bounds_steps whose statistics wait in ctx->bstat
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
-    bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
+    bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false, ev_possible = false; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
             if (sm->hb) (void)hipFree(sm->hb);
@@ -1346,10 +1348,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // change (an event pair reads the point twice, through a gather: 0.2 ms per million movers at s = 51 against
         // 10.4 ms for a full pass over 1e8 points); no count yet (a run's second call): taken as few -- at worst every
         // point moves and the events cost what the full pass would have.  Whatever is chosen, the sums are the members' sums.
-        ev_path = sm->lazy && d_mind == nullptr && kept && sm->cl_valid && !ctx->sw.no_incremental &&
-                  !ctx->sw.no_sort_reuse && sm->pol.few_movers((double)n) &&
-                  (size_t)p * 12 <= 64 * 1024;
-        if (ev_path && sm->ev_cap < (size_t)2 * n) {
+        // (what an incremental call needs is allocated by the first lazy call, whatever path that one takes: a run's
+        //  first call is the one that builds things; 3 x 8 B per point here, and the sort buffers at their event sizes below)
+        ev_possible = sm->lazy && !ctx->sw.no_incremental && !ctx->sw.no_sort_reuse && (size_t)p * 12 <= 64 * 1024;
+        ev_path = ev_possible && d_mind == nullptr && kept && sm->cl_valid && sm->pol.few_movers((double)n);
+        if (ev_possible && sm->ev_cap < (size_t)2 * n) {
             if (sm->ev_pt) (void)hipFree(sm->ev_pt);
             if (sm->ev_k) (void)hipFree(sm->ev_k);
             sm->ev_pt = sm->ev_k = nullptr;
@@ -1359,7 +1362,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                 (void)hipGetLastError();
                 if (sm->ev_pt) (void)hipFree(sm->ev_pt);
                 sm->ev_pt = sm->ev_k = nullptr;
-                ev_path = false; // (no room: the full pass)
+                ev_path = ev_possible = false; // (no room: the full pass)
             } else
                 sm->ev_cap = (size_t)2 * n;
         }
@@ -1451,10 +1454,13 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // SPKM_NO_SORT_REUSE=1: A/B switch.
     const int seg = seg_points(n, ctx->num_cus);
     const int max_items = (int)(n / seg) + K + 1;
-    if ((rc = ensure(ctx, ctx->perm, (size_t)n * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->offs, (size_t)(K + 1) * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->cursor, (size_t)K * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->items, (size_t)max_items * 16))) return rc;
+    // (ev_possible: at the sizes the sort of the EVENTS needs -- 2 per point, 2 K keys, 256-event segments -- from the
+    //  start, so that no incremental call has to replace them)
+    const int max_items_ev_all = ev_possible ? (int)((2 * n) / 256) + 2 * K + 1 : 0;
+    if ((rc = ensure(ctx, ctx->perm, (size_t)(ev_possible ? 2 : 1) * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->offs, (size_t)((ev_possible ? 2 : 1) * K + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->cursor, (size_t)(ev_possible ? 2 : 1) * K * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->items, (size_t)std::max(max_items, max_items_ev_all) * 16))) return rc;
     if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
     // (the exact pass's geometry is needed here already: the plan below depends on which kernel runs)
     const int threads = 1024;
@@ -1483,7 +1489,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     int* cl_same = cl_on ? sm->cl_flags + 2 * K : nullptr;
     int* cl_ibeg = cl_on ? sm->cl_flags + 3 * K : nullptr;
     int* cl_icnt = cl_on ? sm->cl_flags + 4 * K : nullptr;
-    const bool reuse = kept && ctx->sort_perm_valid && ctx->sort_seg == seg && !ctx->sort_partial && !ctx->sw.no_sort_reuse;
+    // (ctx->sort_owner still set: none of the sort buffers was replaced by the ensure() calls above)
+    const bool reuse = kept && ctx->sort_owner == (const void*)sm && ctx->sort_perm_valid && ctx->sort_seg == seg &&
+                       !ctx->sort_partial && !ctx->sw.no_sort_reuse;
     const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
     // cluster sizes: updated by the points that moved (k_combine_screen / k_assign_list see every change against the
     // library's copy of the previous assignment) instead of a histogram over all points; SPKM_NO_SORT_REUSE=1 recounts

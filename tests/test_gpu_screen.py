@@ -671,6 +671,37 @@ def test_lazy_statistics_incremental_sums_stay_the_members_sums(gpu_ctx, oracle,
         assert np.count_nonzero(a1 != a0) <= max(2, n // 10000)
 
 
+def test_a_fresh_contexts_second_lazy_call_is_already_incremental(oracle):
+    """A context's first fused call allocates most of its buffers AFTER queueing its counting sort; those first-time
+    allocations must not make the library forget the sort (and with it the previous assignment and cluster sizes): the
+    second call of a run is then an incremental one, on buffers the first call sized for it.  Outputs are the oracle's."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard, torch_context
+
+    ctx = torch_context(0)                                          # its own context: no buffer exists yet
+    p, n, K, s = 256, 30000, 24, 26
+    X = random_csc(p, n, s, seed=123)
+    gam = s / p
+    shard = Shard.from_scipy(ctx, X)
+    shard.set_lazy_stats(True)
+    eng = LloydEngine(shard, K, gam)
+    rng = np.random.default_rng(9)
+    c = torch.tensor(np.ascontiguousarray((rng.standard_normal((p, K)) * 0.3).T), device="cuda")
+    nan_obj = []
+    for it in range(3):
+        used = c.cpu().numpy().T.copy()
+        out = eng.iterate(c, want_mind=False).cpu().numpy()
+        ra, _ = oracle.assign(p, n, *parts(X), used, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra), f"iteration {it}"
+        S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), ra)
+        red = eng.reduce.cpu().numpy()
+        assert np.array_equal(red[p * K:2 * p * K].reshape(K, p).T, Cnt)
+        assert np.abs(red[:p * K].reshape(K, p).T - S).max() <= 1e-10 * np.abs(S).max()
+        nan_obj.append(bool(np.isnan(out[1])))
+    # (the third call's path depends on how many points the second saw move: random centres on random data move most)
+    assert nan_obj[:2] == [False, True], nan_obj
+    shard.set_lazy_stats(False)
+
+
 @pytest.mark.parametrize("adopted", [False, True])
 def test_releasing_the_csc_arrays_changes_nothing_but_the_footprint(gpu_ctx, oracle, adopted):
     """spkm_shard_release_csc: the record layout becomes the only copy of the exact entries.  Fused calls, distances on

@@ -2,7 +2,8 @@
 # Timeline of single Lloyd iterations (GPU box): rocprofv3 kernel trace of a bench run, cut at k_finalize_centers; prints
 # for chosen iterations every kernel with its start offset, duration and the idle gap in front of it, and per iteration
 # the busy / idle split -- what the launches and the host's per-iteration read cost when the shard is small.
-#   tools/timeline.sh TAG [bench.py arguments]        (TIMELINE_SCRIPT=tools/driver_bench.py: another entry point)
+#   tools/timeline.sh TAG [bench.py arguments]        (TIMELINE_SCRIPT=tools/driver_bench.py: another entry point;
+#                                                      TIMELINE_SHOW=3,4,7: which iterations of the trace to list)
 export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
@@ -49,7 +50,9 @@ def show(j):
         last = max(last, e)
 if its:
     # the bench's timed region follows the warm-up: show a cold-ish and a converged iteration from the last run in the trace
-    for j in sorted(set([max(0, len(its) - 20), max(0, len(its) - 18), len(its) - 3])):
+    import os
+    pick = [int(v) for v in os.environ.get('TIMELINE_SHOW', '').split(',') if v] or [max(0, len(its) - 20), max(0, len(its) - 18), len(its) - 3]
+    for j in sorted(set(j for j in pick if 0 <= j < len(its))):
         show(j)
 PY
 head -150 $root/gpurun_out/timeline_$tag/timeline.txt
