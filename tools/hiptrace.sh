@@ -1,9 +1,14 @@
+#!/bin/bash
+# Host-side view of a short bench run (GPU box): rocprofv3 --hip-trace, then every HIP API call over 20 ms and every
+# allocation / free / synchronisation from the first k_finalize_centers on, with arguments -- what the host pays between
+# kernels (a 51-GB hipMalloc is ~1 s on a cold box; a hipFree of 400 MB waits for the device).
+#   tools/hiptrace.sh [bench.py arguments; default --steps 4 --warmup 2 --cpu-sample 0 --no-regimes]
 export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 for run in 1; do
 rm -rf /tmp/ht1
-rocprofv3 --hip-trace --kernel-trace --output-format json -d /tmp/ht1 -o t -- python $root/bench.py --steps 4 --warmup 2 --cpu-sample 0 --no-regimes > /tmp/ht1.log 2>&1
+rocprofv3 --hip-trace --kernel-trace --output-format json -d /tmp/ht1 -o t -- python $root/bench.py ${@:---steps 4 --warmup 2 --cpu-sample 0 --no-regimes} > /tmp/ht1.log 2>&1
 tail -1 /tmp/ht1.log | cut -c1-200
 f=$(find /tmp/ht1 -name "*.json" | head -1)
 ls -la $f
