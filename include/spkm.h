@@ -234,7 +234,7 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context;
  * info[6] = 0 (reserved); info[7] = 2 if the
  * bounds were applied point by point (the list then names points; info[4] still counts the steps whose 16 points all
- * passed): the library switches to that form when the previous call's test passed >= 90 % of the points and whole
+ * passed): the library switches to that form when the previous call's test passed >= 60 % of the points and whole
  * steps would leave several times as many points on the screen as failed, so that data in arbitrary order -- where a 16-point
  * step is rarely settled as a whole -- skips as much as cluster-contiguous data does.  (The listed points' entries are
  * then read from the record layout of the exact pass, 512 contiguous bytes per point at s = 51, when the shard has

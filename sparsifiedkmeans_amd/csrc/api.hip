@@ -1325,7 +1325,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             }
         }
         const bool skip_enabled = bounds_ok && !ctx->sw.no_bounds;
-        // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 90 % of the points
+        // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 60 % of the points
         // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
         pt_mode = skip_enabled && sm->pol.pt_next && !ctx->sw.no_point_list;
         // per-cluster cache / flags of the unchanged-cluster shortcut

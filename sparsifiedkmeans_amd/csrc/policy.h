@@ -71,8 +71,13 @@ struct spkm_policy {
         if (c.listed > 0.05 * n) exact_cooldown = 8;
         // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed (in
         // cluster-contiguous order the failing points sit together and whole steps are as good).  Entered at 4x, left
-        // below 2.5x: the two forms leave slightly different bounds behind, and a choice that flips every call pays for both
-        pt_next = skip_pending && c.kept >= 0.9 * n &&
+        // below 2.5x: the two forms leave slightly different bounds behind, and a choice that flips every call pays for both.
+        // At least 60 % of the points must have passed: a listed point's entries are gathered once per centroid tile
+        // (512 B each at s = 51), which stops paying against whole steps somewhere below half.  (The bar was 90 %; on
+        // overlapping clusters -- slack between the bounds small everywhere, eroded by a steady drift -- 10-40 % of the
+        // points fail for many iterations in a row, scattered over all steps: whole steps meant the full screen, 27 ms
+        // at N = 1e8 where the list takes 5-19; a run to convergence there went from 57 to 63 it/s.)
+        pt_next = skip_pending && c.kept >= 0.6 * n &&
                   (std::ceil(n / 16.0) - c.skipped) * 16.0 > (pt_next ? 2.5 : 4.0) * (n - c.kept);
         const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
         const int t = std::max(1, tiles);

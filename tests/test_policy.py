@@ -138,7 +138,9 @@ def test_point_lists_enter_at_four_leave_below_two_and_a_half(pol):
         w.call()
         return r
 
-    assert after(0.85, 0.1) == 0                             # < 90 % of the points passed
+    assert after(0.55, 0.0) == 0                             # < 60 % of the points passed
+    assert after(0.85, 0.1) == 1                             # 15 % failing, scattered (90 % of the steps left): 6x -> lists
+    assert after(0.55, 0.0) == 0                             # ... and off again when too many fail
     assert after(0.98, 0.95) == 0                            # steps left hold 5 % of the points vs 2 % failing: 2.5x < 4x
     assert after(0.98, 0.90) == 1                            # 10 % vs 2 %: 5x -> point lists
     assert after(0.98, 0.94) == 1                            # 3x: stays (left only below 2.5x)
