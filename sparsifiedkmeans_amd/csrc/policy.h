@@ -97,9 +97,14 @@ struct spkm_policy {
             if (!was_late && share < 0.15 && steps > 0.25 * all_pairs && hint_late_left == 0) hint_late_left = 2;
             hint_late = hint_late_left > 0;
             const bool fallback_to_late = !was_late && hint_late && quad_split_late(nr) > quad_split(nr);
-            if (c.listed > 0.005 * n || (c.early < 0.05 * steps && steps > 0.01 * n / 16.0 && !fallback_to_late)) {
+            const bool poor = c.early < 0.05 * steps && steps > 0.01 * n / 16.0;
+            if (c.listed > 0.005 * n || (poor && !fallback_to_late)) {
                 hint_fail_streak = std::min(hint_fail_streak + 1, 4);
                 hint_cooldown = 1 << hint_fail_streak; // early iterations mislead briefly, not for 16 calls
+            } else if (poor) {
+                // a poor early-split call whose way back to the late split is open: the next call tries that, without a
+                // pause -- and without forgetting the failures so far (clusters that overlap never finish a step early
+                // on either split: forgetting meant two wasted hinted calls in every seven)
             } else {
                 hint_fail_streak = 0;
                 // runner-up bounds of early-finished steps are partial sums, so `ambig` over-counts: still small means
