@@ -61,7 +61,7 @@ struct spkm_switches {
     bool no_dist1 = false;        // SPKM_NO_DIST1: K = 1 calls go through the tiled exact kernel
     bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
-    bool no_onepass = false;      // SPKM_NO_ONEPASS: few centroids still take screen + accumulation pass instead of the fused one (onepass.hip)
+    bool onepass = false;         // SPKM_ONEPASS: few centroids (K <= 16) take the fused one-pass form (onepass.hip) -- off by default: measured slower
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
 static spkm_switches read_switches()
@@ -84,7 +84,7 @@ static spkm_switches read_switches()
     w.no_incremental = on("SPKM_NO_INCREMENTAL");
     w.no_support_drift = on("SPKM_NO_SUPPORT_DRIFT");
     w.no_teams = on("SPKM_NO_TEAMS");
-    w.no_onepass = on("SPKM_NO_ONEPASS");
+    w.onepass = on("SPKM_ONEPASS");
     return w;
 }
 
@@ -1359,10 +1359,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             if ((rc = ensure(ctx, ctx->nk_ev, (size_t)2 * K * 8))) return rc;
             zero_later(ctx->nk_ev.p, (size_t)2 * K * 8);
         }
-        // One pass for few centroids (onepass.hip): a lazy call that would run the full accumulation pass -- a run's first
-        // call, or too many movers for the events -- reads each point's record once: screen, certificate and accumulation
-        // fused.  Needs the sums of all K clusters (f64) + 16-bit counts + the f32 tile in LDS.  SPKM_NO_ONEPASS=1: A/B switch.
-        if (sm->lazy && d_mind == nullptr && !ev_path && !ctx->sw.no_onepass && K >= 2 && K <= 16 && s->fixed_s <= 64 &&
+        // One pass for few centroids (onepass.hip; SPKM_ONEPASS=1, OFF by default): a lazy call that would run the full
+        // accumulation pass -- a run's first call, or too many movers for the events -- reads each point's record once:
+        // screen, certificate and accumulation fused.  Needs the sums of all K clusters (f64) + 16-bit counts + the f32 tile
+        // in LDS.  Measured on config 5 (1.25e8 points, K = 10): 28.4 ms against 9.2 + 14.8 for the two kernels.
+        if (sm->lazy && d_mind == nullptr && !ev_path && ctx->sw.onepass && K >= 2 && K <= 16 && s->fixed_s <= 64 &&
             sm->cl_cache != nullptr) {
             const int nq = (K + 3) / 4;
             const size_t lds = (size_t)(p + 1) * nq * 16 + (size_t)K * p * 8 + (size_t)((K * p + 1) / 2) * 4 + (size_t)K * 4 + 64;

@@ -7,7 +7,8 @@
 // Taken by run_screen (api.hip) for a LAZY call (spkm_shard_set_lazy_stats: no distances, no objective asked for) that
 // would otherwise run the full accumulation pass -- a run's first call, or one in which more than a third of the points
 // moved -- when K <= 16 and (p + 1) x KP x 4 + K x p x 10 bytes fit the CU's LDS (KP = K rounded up to 4; p = 1024: K <= 10,
-// which is config 5 and the MNIST config).  SPKM_NO_ONEPASS=1: A/B switch.
+// which is config 5 and the MNIST config) AND SPKM_ONEPASS=1: the form is OFF by default, because it measured slower than the two
+// kernels it replaces (config 5: 28.4 ms against 9.2 + 14.8; DESIGN.md 4.2g says where the time goes).
 //
 // Arithmetic: the screen's (screen.hip header) -- x~ = fl32(x), c~ = fl32(c / gamma), a~_k = sum fl32((x~ - c~)^2) in f32,
 // certified iff (r1 + eps1)(1 + 2^-45) < (r2 - eps2)(1 - 2^-45) with the same eps -- so a certified point's cluster is

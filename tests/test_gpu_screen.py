@@ -631,7 +631,6 @@ def test_lazy_statistics_incremental_sums_stay_the_members_sums(gpu_ctx, oracle,
     runs = {}
     for incremental in (True, False):
         set_switch(monkeypatch, gpu_ctx, "SPKM_NO_INCREMENTAL", not incremental)
-        set_switch(monkeypatch, gpu_ctx, "SPKM_NO_ONEPASS", not incremental)   # (K <= 16: the other form without an exact pass)
         shard.reset_policy()
         shard.set_lazy_stats(True)
         eng = LloydEngine(shard, K, gam)
@@ -679,7 +678,8 @@ def test_one_pass_for_few_centroids(gpu_ctx, oracle, monkeypatch, p, s, n, K):
     fitting LDS, reads the records once -- screen, certificate, accumulation fused.  Every call: assignment and cluster
     sizes the oracle's bit for bit (an exact tie between two centroids sends points through the exact list), counts
     exact, sums the members' sums to rounding; the bounds it leaves behind carry the later calls to the oracle's answers
-    too.  SPKM_NO_ONEPASS=1 gives the same outputs on the two-kernel form."""
+    too.  The form is opt-in (SPKM_ONEPASS=1: it measured slower than the two kernels it replaces); without the switch the
+    same outputs come from the two-kernel form."""
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
 
     X = random_csc(p, n, s, seed=1000 + K)
@@ -691,7 +691,7 @@ def test_one_pass_for_few_centroids(gpu_ctx, oracle, monkeypatch, p, s, n, K):
     shard = Shard.from_scipy(gpu_ctx, X)
     seen = {}
     for onepass in (True, False):
-        set_switch(monkeypatch, gpu_ctx, "SPKM_NO_ONEPASS", not onepass)
+        set_switch(monkeypatch, gpu_ctx, "SPKM_ONEPASS", onepass)
         shard.reset_policy()
         shard.set_lazy_stats(True)
         eng = LloydEngine(shard, K, gam)
@@ -718,8 +718,8 @@ def test_one_pass_for_few_centroids(gpu_ctx, oracle, monkeypatch, p, s, n, K):
         eng.distances(torch.tensor(np.ascontiguousarray(used.T), device="cuda"))
         assert np.array_equal(eng.mind.cpu().numpy(), rd)
     shard.set_lazy_stats(False)
-    assert seen[True][0] == 1, seen                                # a run's first call takes the fused form ...
-    assert not any(seen[False]), seen                              # ... unless switched off
+    assert seen[True][0] == 1, seen                                # switched on, a run's first call takes the fused form ...
+    assert not any(seen[False]), seen                              # ... and by default no call does
 
 
 def test_a_fresh_contexts_second_lazy_call_is_already_incremental(oracle):
