@@ -232,9 +232,12 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * (a bound: over-counts in the two-phase forms), (16-point step, centroid tile) pairs finished early by the
  * hinted form, 16-point steps skipped altogether on the bounds carried from the previous call (see
  * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context;
- * info[6] = 1 if the call was a ONE-PASS call (few centroids, lazy statistics: the f32 screen, its certificate and the
- * per-cluster accumulation fused over one read of the points' records -- csrc/onepass.hip; opt-in, SPKM_ONEPASS=1: it
- * measured slower than the two kernels it replaces); info[7] = 2 if the
+ * info[6] = how the call got its per-cluster sums: 0 = the full accumulation pass with every point's distance, 3 = the
+ * full pass WITHOUT distances (lazy statistics, spkm_shard_set_lazy_stats: a run's first call, or too many movers for
+ * events; SPKM_NO_SUMS_ONLY=1: A/B switch), 2 = incrementally, by the points that changed cluster (events), 1 = the
+ * ONE-PASS form (few centroids: the f32 screen, its certificate and the accumulation fused over one read of the points'
+ * records -- csrc/onepass.hip; opt-in, SPKM_ONEPASS=1: it measured slower than the two kernels it replaces);
+ * info[7] = 2 if the
  * bounds were applied point by point (the list then names points; info[4] still counts the steps whose 16 points all
  * passed): the library switches to that form when the previous call's test passed >= 60 % of the points and whole
  * steps would leave several times as many points on the screen as failed, so that data in arbitrary order -- where a 16-point

@@ -61,6 +61,7 @@ struct spkm_switches {
     bool no_dist1 = false;        // SPKM_NO_DIST1: K = 1 calls go through the tiled exact kernel
     bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
+    bool no_sums_only = false;    // SPKM_NO_SUMS_ONLY: a lazy call's full pass still evaluates every point's distance
     bool onepass = false;         // SPKM_ONEPASS: few centroids (K <= 16) take the fused one-pass form (onepass.hip) -- off by default: measured slower
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
@@ -85,6 +86,7 @@ static spkm_switches read_switches()
     w.no_support_drift = on("SPKM_NO_SUPPORT_DRIFT");
     w.no_teams = on("SPKM_NO_TEAMS");
     w.onepass = on("SPKM_ONEPASS");
+    w.no_sums_only = on("SPKM_NO_SUMS_ONLY");
     return w;
 }
 
@@ -123,6 +125,7 @@ struct spkm_ctx {
     bool last_lib_valid = false;     // the last screen call could compare with the library's previous assignment (movers counted)
     bool last_incremental = false;   // the last screen call updated the sums by events (no exact pass)
     bool last_onepass = false;       // the last screen call was a one-pass call (onepass.hip)
+    bool last_sums_only = false;     // the last screen call's full pass left the distances out (lazy statistics)
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
     bool last_pt_mode = false;       // ... and listed points instead of 16-point steps
@@ -1502,10 +1505,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         ctx->last_lib_valid = bounds_ok;
         ctx->last_incremental = false;
         ctx->last_onepass = true;
+        ctx->last_sums_only = false;
         ctx->last_path = 1;
         return SPKM_OK;
     }
     ctx->last_onepass = false;
+    ctx->last_sums_only = false;
     // 1. screen
     const int sweep = 16 * 16;
     long long chunk = n / ((long long)(quad ? ctx->bmapq_blocks / 4 : ctx->bmap_streams) * 8);
@@ -1585,6 +1590,13 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // SPKM_NO_CLUSTER_SKIP=1: A/B switch.
     const bool cl_on = quad && pipe && sm->cl_cache != nullptr;
     const bool cl_skip = cl_on && bounds_ok && drift_ran && sm->cl_valid && sm->cl_stats_valid && d_mind == nullptr && !ctx->sw.no_cluster_skip && !ev_path;
+    // Sums-only full pass (SPKM_NO_SUMS_ONLY=1: A/B switch): a LAZY call that cannot take the event path -- a run's first
+    // call, or too many movers -- still has to add up every member, but nobody asked for a distance: the pass leaves the
+    // centroid reads, the squared terms and the per-point sums out (k_exact_accumulate_rec<..., DIST = false>); upper bounds
+    // come from the screen's certificate as in an incremental call, objective and largest distance are NaN.
+    const bool sums_only = cl_on && sm->lazy && d_mind == nullptr && !ev_path && !cl_skip && !ctx->sw.no_sums_only;
+    const bool lazy_ub = ev_path || sums_only; // the certificate writes the upper bounds (k_combine_screen, k_assign_list)
+    ctx->last_sums_only = sums_only;
     int* cl_need = cl_on ? sm->cl_flags : nullptr;
     int* cl_touched = cl_on ? sm->cl_flags + K : nullptr;
     int* cl_same = cl_on ? sm->cl_flags + 2 * K : nullptr;
@@ -1611,14 +1623,14 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        quad ? (const double*)(sm->hb_cum + sm->cum_par) : (const double*)nullptr,
                        bounds_ok ? 1 : 0, cl_skip ? cl_touched : (int*)nullptr, K,
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
-                       ev_path ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr,
+                       lazy_ub ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr,
                        ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
                        a_lib, bounds_ok ? 1 : 0, (unsigned*)ctx->nlist.p + 5, cl_skip ? cl_touched : (int*)nullptr,
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
-                       ev_path ? sm->hb : (float*)nullptr, ev_path ? sm->ev_pt : (int*)nullptr,
+                       lazy_ub ? sm->hb : (float*)nullptr, ev_path ? sm->ev_pt : (int*)nullptr,
                        ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p,
                        s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
                        ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr);
@@ -1721,7 +1733,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->blk_imax, (size_t)std::max(ab, max_items) * 8))) return rc;
     if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
     if (pipe) {
-        const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4>;
+        const void* k3 = sums_only ? (const void*)k_exact_accumulate_rec<IR, 4, true, false> : (const void*)k_exact_accumulate_rec<IR, 4>;
         const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
         HIP_TRY(allow_lds(ctx, k3, lds3));
         const char* a_rec = sm->rec;
@@ -1767,11 +1779,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         long long* cl_imax = reinterpret_cast<long long*>(cl_max + K);
         hipLaunchKernelGGL(k_cluster_restore, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
                            (const int*)cl_touched /* = fresh, after k_cluster_need */, K, p, sums, counts, cache_s, cache_c);
-        hipLaunchKernelGGL(k_cluster_stats, dim3(1), dim3(256), 0, ctx->stream, (const int*)cl_need, K, (const int*)cl_ibeg,
-                           (const int*)cl_icnt, (const double*)ctx->blk_obj.p, (const double*)ctx->blk_max.p,
-                           (const long long*)ctx->blk_imax.p, cl_obj, cl_max, cl_imax, (double*)ctx->stats.p);
+        if (!sums_only)
+            hipLaunchKernelGGL(k_cluster_stats, dim3(1), dim3(256), 0, ctx->stream, (const int*)cl_need, K, (const int*)cl_ibeg,
+                               (const int*)cl_icnt, (const double*)ctx->blk_obj.p, (const double*)ctx->blk_max.p,
+                               (const long long*)ctx->blk_imax.p, cl_obj, cl_max, cl_imax, (double*)ctx->stats.p);
         sm->cl_valid = true;
-        sm->cl_stats_valid = true;
+        sm->cl_stats_valid = !sums_only;
     } else {
         sm->cl_valid = false;
         sm->cl_stats_valid = false;
@@ -1786,7 +1799,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     }
     hipLaunchKernelGGL(k_call_tail, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
-                       (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p);
+                       (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p,
+                       sums_only ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
         sm->hb_K = K;
@@ -2026,7 +2040,9 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         info[0] = ctx->last_mode;
         for (int j = 0; j < 4; j++) info[1 + j] = v[j];
         info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
-        info[6] = ctx->last_onepass ? 1 : 0; // 1: one-pass call (screen + accumulation fused, onepass.hip)
+        // how the call got its sums: 0 full pass with every distance, 1 one-pass form (onepass.hip), 2 incremental (events),
+        // 3 full pass without distances (sums only)
+        info[6] = ctx->last_onepass ? 1 : (ctx->last_incremental ? 2 : (ctx->last_sums_only ? 3 : 0));
         info[7] = ctx->last_pt_mode ? 2 : 0; // 2: point-granular list
     }
     return SPKM_OK;

@@ -1399,7 +1399,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 // k_exact_accumulate (same arithmetic, same order).
 // ACCUM = false: the distance-only variant of spkm_distances_dev -- no sum / count atomics, no flush; `sums` and `counts`
 // may be null.
-template <typename IR, int WPE, bool ACCUM = true>
+// DIST = false: the sums-only variant of a LAZY call's full pass (spkm_shard_set_lazy_stats: no distance, objective or
+// largest distance is wanted, the upper bounds come from the screen's certificate): no centroid reads, no staging of the
+// squared terms, no per-point sums; mind / ubv / it_* are not touched.
+template <typename IR, int WPE, bool ACCUM = true, bool DIST = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_exact_accumulate_rec(
     const char* __restrict__ rec, int R, const int* __restrict__ perm, const long long* __restrict__ offs,
     const int4* __restrict__ items, const int* __restrict__ nitems, const double* __restrict__ C, double gamma, int p,
@@ -1434,9 +1437,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         const long long start = offs[k] + it.y;
         const int len = it.z;
         for (int r = tid; r < p; r += blockDim.x) {
-            double c = C[(size_t)k * p + r];
-            if (gamma > 0.0) c = c / gamma;
-            negc[r] = -c;
+            if constexpr (DIST) {
+                double c = C[(size_t)k * p + r];
+                if (gamma > 0.0) c = c / gamma;
+                negc[r] = -c;
+            }
             ssum[r] = 0.0;
             scnt[r] = 0u;
         }
@@ -1468,21 +1473,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             // order, so a read issued behind a group's staging writes and atomics would wait for all of them; issued in
             // front of them it is only ever waited for together with older reads.
             double cg[2][4];
+            if constexpr (DIST) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) cg[0][t] = negc[rv[t]];
+                for (int t = 0; t < 4; t++) cg[0][t] = negc[rv[t]];
+            }
 #pragma unroll
             for (int g = 0; g < P; g += 4) {
-                if (g + 4 < P) {
+                if constexpr (DIST) {
+                    if (g + 4 < P) {
 #pragma unroll
-                    for (int t = 0; t < 4; t++) cg[((g >> 2) + 1) & 1][t] = negc[rv[g + 4 + t]];
+                        for (int t = 0; t < 4; t++) cg[((g >> 2) + 1) & 1][t] = negc[rv[g + 4 + t]];
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     const int v = g + t;
                     if (v < have && lane_ok) {
                         const int r = rv[v];
-                        const double d = xv[v] + cg[(g >> 2) & 1][t]; // RN(x - c): the reference's subtraction
-                        ms[(size_t)v * S1 + lane] = d * d;
+                        if constexpr (DIST) {
+                            const double d = xv[v] + cg[(g >> 2) & 1][t]; // RN(x - c): the reference's subtraction
+                            ms[(size_t)v * S1 + lane] = d * d;
+                        }
                         if constexpr (ACCUM) {
                             unsafeAtomicAdd(&ssum[r], xv[v]);
                             atomicAdd(&scnt[r], 1u);
@@ -1509,7 +1520,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             // (b) one lane per point, squared terms added in storage order
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < have) {
+            if (DIST && lane < have) {
                 double acc = 0.0;
                 const double* mq = ms + (size_t)lane * S1;
                 int j = 0;
@@ -1538,7 +1549,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         if (lane == 0) { s_obj[wave] = obj2; s_max[wave] = dmax; s_imax[wave] = imax; }
         obj2 = 0.0; dmax = -1.0; imax = 0x7fffffffffffffffLL;
         __syncthreads();
-        if (tid == 0) {
+        if (DIST && tid == 0) {
             double o = 0.0, m = -1.0;
             long long im = 0x7fffffffffffffffLL;
             for (int w = 0; w < nwaves; w++) {
