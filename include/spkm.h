@@ -124,8 +124,10 @@ int spkm_shard_reset_policy(spkm_shard *s);
  * sums, to rounding (an add and a subtract per move instead of a fresh summation; bar 1e-6 relative).  In such a call
  *     d_reduce[2pK + K] (obj2) and d_stats[0..2] are NaN -- not evaluated --
  * and the host obtains them for the iteration it needs from spkm_distances_stats_dev.  The library decides per call
- * (few points moved in the previous call, its caches describe the previous call, ...); a call that runs the full pass
- * returns the statistics as always.  SPKM_NO_INCREMENTAL=1 switches the incremental calls off. */
+ * (few points moved in the previous call, its caches describe the previous call, ...).  A lazy call that has to run the
+ * full pass -- a run's first call, one in which too many points move -- runs it WITHOUT the distances (sums and counts
+ * only; the statistics are NaN there too); with d_mind != NULL a call evaluates everything, as always.
+ * SPKM_NO_INCREMENTAL=1 switches the incremental calls off, SPKM_NO_SUMS_ONLY=1 the distance-free full pass. */
 int spkm_shard_set_lazy_stats(spkm_shard *s, int on);
 /* Halve the resident footprint of a fixed-stride shard (every column has the same number of entries, at most 64): build
  * now what the fused call would build on its first use -- the record layout (a point's values and row ids side by side)

@@ -46,7 +46,8 @@ rec('void k_screen_quad<13, unsigned short, 0, false>', 'k_screen_quad', b_iter,
     "plain form, every 16-point step (a run's first call): SURVEY 8(d) bytes of an iteration; the screen streams its own f32 / u16 copy once per centroid tile, the three tiles of a team meet in their XCD's L2")
 rec('void k_screen_quad<13, unsigned short, 2, false>', None, b_iter, "hinted form, late split (7 of 13 rounds for all centroids); all steps on the screen")
 rec('void k_screen_quad<13, unsigned short, 1, false>', None, None, "hinted / two-phase form with the early split (3 of 13 rounds); most launches run over a short list of steps")
-rec('void k_exact_accumulate_rec<unsigned short, 4, true>', 'k_exact_accumulate', b_acc, "full accumulation pass over the record layout (a run's first call(s)): values + 16-bit row ids once, permutation in, upper bound out")
+rec('void k_exact_accumulate_rec<unsigned short, 4, true, false>', 'k_exact_accumulate', b_acc, "full accumulation pass over the record layout, sums only (a lazy run's first call): values + 16-bit row ids once, permutation in; bytes as SURVEY 8(d)'s separate accumulation pass (the upper-bound store it no longer does included)")
+rec('void k_exact_accumulate_rec<unsigned short, 4, false, true>', None, b_acc, "distances + statistics on demand (once per run): the same records, no sums")
 rec('void k_accumulate_events<unsigned short>', None, None, "incremental calls: the points that changed cluster, each read twice (out of its old cluster's sums, into its new one's); bytes = 2 x movers x 512 B")
 json.dump(recs, open('profiles/pmc_latest.json', 'w'), indent=1)
 PY
