@@ -30,6 +30,7 @@ def dist(C):
     return out.sqrt()
 tiles = [(0, 32), (32, 64), (64, 100)]
 prev_c = prev_d = prev_a = None
+prev_dr = None
 ar = torch.arange(m, device="cuda")
 for it in range(1, 11):
     cur = centers.clone()
@@ -47,7 +48,17 @@ for it in range(1, 11):
         sk = torch.stack(skip, 1)
         # steps of 16 consecutive sample points stand in for steps (block order: neighbours share a cluster)
         st = sk.view(-1, 16, 3).all(1).float().mean().item()
+        # the same test with the centroids REGROUPED by the drift of the previous iteration (32 largest movers in one group)
+        if prev_dr is not None:
+            order = torch.argsort(prev_dr, descending=True)
+            grp = [order[0:32], order[32:64], order[64:100]]
+            sk2 = torch.stack([(pd[:, gi].min(1).values - dr[gi].max()) > ub for gi in grp], 1)
+            st2 = sk2.view(-1, 16, 3).all(1).float().mean().item()
+            regrouped = f"regrouped by last drift: per (point, group) {sk2.float().mean().item():.3f} per (16-sample, group) {st2:.3f} max drift per group {[round(dr[gi].max().item(), 2) for gi in grp]}"
+        else:
+            regrouped = ""
         # Hamerly (one group): everything
         lball = pd.min(1).values - dr.max()
-        print(f"it {it}: moved {(a != prev_a).float().mean().item():.3f}  per (point, tile) skippable {sk.float().mean().item():.3f}  per (16-sample, tile) {st:.3f}  Hamerly point skip {(lball > ub).float().mean().item():.3f}  max drift per tile {[round(dr[lo:hi].max().item(), 2) for lo, hi in tiles]} median drift {dr.median().item():.3f}", flush=True)
+        print(f"it {it}: moved {(a != prev_a).float().mean().item():.3f}  per (point, tile) skippable {sk.float().mean().item():.3f}  per (16-sample, tile) {st:.3f}  Hamerly point skip {(lball > ub).float().mean().item():.3f}  max drift per tile {[round(dr[lo:hi].max().item(), 2) for lo, hi in tiles]} median drift {dr.median().item():.3f}  {regrouped}", flush=True)
+        prev_dr = dr
     prev_c, prev_d, prev_a = cur, d, a
