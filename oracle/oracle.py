@@ -2,8 +2,10 @@
 
 TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke()
 and bench.py's cpu_baseline leg -- never by sparsifiedkmeans_amd/.
-PARITY UNPINNED (see oracle/orc_sparse.c header): restatement of the reference
-source, not checked against outputs of the reference itself.
+PARITY: rows a1-a3, a11-a14 of SURVEY section 8 are PINNED -- the restatement is checked bit for bit against the
+reference's own loops compiled from where they lie (oracle/_ref: ref_sparse_shim.c, ref_hadamard*_shim.c, the
+ref_* functions at the bottom of this file) and against tests/golden/ref_*.npz written by them.  Rows a4-a10, a16 are
+MATLAB code (no MATLAB / Octave in this image): restated from the cited lines, structurally unpinnable.
 """
 from __future__ import annotations
 
@@ -233,29 +235,36 @@ def mix(x, d, p2):
 
 
 # ------------------------------------------------------------------------------------------------
-# oracle/_ref: the part of the REFERENCE's own C that builds here (oracle/Makefile, ref_hadamard*_shim.c):
-# private/hadamard.c:57-92 and private/hadamard_pthreads.c:57-119, compiled from where the files lie under
-# /root/reference.  Present only where `make -C oracle` ran with the reference on disk (and, as prebuilt binaries,
-# wherever the snapshot travelled).  Used to PIN orc_fwht / orc_fwht_threads (rows a13, a14), nothing else.
+# oracle/_ref: the part of the REFERENCE's own C that builds here (oracle/Makefile, ref_hadamard*_shim.c,
+# ref_sparse_shim.c): private/hadamard.c:57-92, private/hadamard_pthreads.c:57-119, SparseMatrixMinusCluster.c:121-129
+# and :131-183, SparseMatrixInnerProduct.c:86-100, SparseMatrixColumnNormSq.c:70-77, compiled from where the files lie
+# under /root/reference.  Present only where `make -C oracle` ran with the reference on disk (and, as prebuilt
+# binaries, wherever the snapshot travelled).  Used to PIN orc_fwht / orc_fwht_threads (rows a13, a14) and
+# orc_dist_csc / orc_dist_csc_beta / orc_innerprod_csc / orc_colnormsq_csc (rows a1-a3, a11, a12), to write
+# tests/golden/ref_*.npz, and as the "reference" legs of bench.py's cpu_baseline.
 # ------------------------------------------------------------------------------------------------
 _REF_DIR = os.path.join(_HERE, "_ref")
 _ref_libs: dict = {}
+_REF_NAMES = {"native": "libref_hadamard.so", "portable": "libref_hadamard_portable.so",
+              "pthreads": "libref_hadamard_pthreads.so", "sparse": "libref_sparse.so", "sparse_O2": "libref_sparse_O2.so"}
 
 
 def ref_available(flavor: str = "portable") -> bool:
     """flavor: 'native' (setup_kmeans.m:53's -march=native build: only meaningful on the machine that built it),
-    'portable' (the same excerpt, -O3 without -march), 'pthreads' (hadamard_pthreads.c's worker + kernels)."""
-    name = {"native": "libref_hadamard.so", "portable": "libref_hadamard_portable.so",
-            "pthreads": "libref_hadamard_pthreads.so"}[flavor]
-    return os.path.exists(os.path.join(_REF_DIR, name))
+    'portable' (the same excerpt, -O3 without -march), 'pthreads' (hadamard_pthreads.c's worker + kernels),
+    'sparse' (the three Sparse*.c loops, `-O` as setup_kmeans.m:19,26,33), 'sparse_O2' (the same, -O2 -fwrapv)."""
+    return os.path.exists(os.path.join(_REF_DIR, _REF_NAMES[flavor]))
 
 
 def _ref(flavor: str):
     if flavor not in _ref_libs:
-        name = {"native": "libref_hadamard.so", "portable": "libref_hadamard_portable.so",
-                "pthreads": "libref_hadamard_pthreads.so"}[flavor]
-        L = C.CDLL(os.path.join(_REF_DIR, name))
-        if flavor == "pthreads":
+        L = C.CDLL(os.path.join(_REF_DIR, _REF_NAMES[flavor]))
+        if flavor.startswith("sparse"):
+            L.ref_dist_csc.argtypes = [_sz, _sz, _sz, _u64p, _u64p, _f64p, _f64p, _f64p]
+            L.ref_dist_csc_beta.argtypes = [_sz, _u64p, _u64p, _f64p, _f64p, C.c_double, _f64p]
+            L.ref_innerprod_csc.argtypes = [_sz, _u64p, _u64p, _f64p, _f64p, _f64p, _f64p]
+            L.ref_colnormsq_csc.argtypes = [_sz, _u64p, _f64p, _f64p]
+        elif flavor == "pthreads":
             L.ref_hadamard_pthreads.argtypes = [C.c_uint, C.c_uint, _f64p, _f64p, C.c_uint]
         else:
             L.ref_hadamard.argtypes = [C.c_uint, C.c_uint, _f64p, _f64p]
@@ -278,3 +287,41 @@ def ref_fwht(x, flavor: str = "portable", threads: int = 4):
     else:
         _ref(flavor).ref_hadamard(m, n, xin, out)
     return out.reshape(n, m).T.copy()
+
+
+def ref_dist_csc(p, n, jc, ir, x, Cmat, flavor: str = "sparse"):
+    """The reference's own `switch (K)` (SparseMatrixMinusCluster.c:131-183): K x n distances (numpy [K, n])."""
+    jc, ir, x = _csc(jc, ir, x)
+    Cmat = np.asarray(Cmat, np.float64).reshape(p, -1)
+    K = Cmat.shape[1]
+    out = np.zeros(n * K)
+    _ref(flavor).ref_dist_csc(p, n, K, jc, ir, x, _colmajor(Cmat), out)
+    return out.reshape(n, K).T.copy()
+
+
+def ref_dist_csc_flat(p, n, K, jc, ir, x, c_colmajor, out, flavor: str = "sparse"):
+    """Same, on prepared buffers (bench.py's cpu_baseline: nothing but the reference's loop inside the timed call)."""
+    _ref(flavor).ref_dist_csc(p, n, K, jc, ir, x, c_colmajor, out)
+
+
+def ref_dist_csc_beta(n, jc, ir, x, c, beta, flavor: str = "sparse"):
+    """The reference's own beta loop (SparseMatrixMinusCluster.c:121-129)."""
+    jc, ir, x = _csc(jc, ir, x)
+    out = np.zeros(n)
+    _ref(flavor).ref_dist_csc_beta(n, jc, ir, x, np.ascontiguousarray(c, np.float64).ravel(), float(beta), out)
+    return out
+
+
+def ref_innerprod_csc(n, jc, ir, x, c, flavor: str = "sparse"):
+    """The reference's own loop of SparseMatrixInnerProduct.c:86-100: (innerProd, normX2)."""
+    jc, ir, x = _csc(jc, ir, x)
+    ip, nx2 = np.zeros(n), np.zeros(n)
+    _ref(flavor).ref_innerprod_csc(n, jc, ir, x, np.ascontiguousarray(c, np.float64).ravel(), ip, nx2)
+    return ip, nx2
+
+
+def ref_colnormsq_csc(n, jc, x, flavor: str = "sparse"):
+    """The reference's own loop of SparseMatrixColumnNormSq.c:70-77."""
+    out = np.zeros(n)
+    _ref(flavor).ref_colnormsq_csc(n, np.ascontiguousarray(jc, np.uint64), np.ascontiguousarray(x, np.float64), out)
+    return out

@@ -49,6 +49,35 @@ def test_assign_bit_exact(gpu_ctx, oracle, p, n, K, s, ragged, gamma):
     assert abs(stats[0] - np.sum(rd * rd)) <= 1e-12 * max(1.0, np.sum(rd * rd))
 
 
+def test_fused_paths_equal_min_of_the_reference_s_own_distances(gpu_ctx, oracle):
+    """Every assignment path of the engine against tests/golden/ref_dist_*.npz -- distances produced by the REFERENCE's
+    own `switch (K)` (SparseMatrixMinusCluster.c:131-183, compiled from /root/reference by oracle/Makefile) -- followed by
+    MATLAB's `min` (findClusterAssignments.m:169: first index on ties; the fixtures hold duplicate centroids).  The exact
+    kernel (`assign_step`) and the fused certified-screen call (`assign_accumulate_step`; the p = 1024 fixtures have
+    fixed-stride columns of 51 entries, the benchmark's point shape) must both give those indices and those minima."""
+    import os
+
+    import scipy.sparse as sp
+
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    files = sorted(f for f in os.listdir(gold) if f.startswith("ref_dist_"))
+    assert len(files) == 8
+    for f in files:
+        z = np.load(os.path.join(gold, f))
+        p, n, K = int(z["p"]), int(z["n"]), int(z["K"])
+        X = sp.csc_matrix((z["x"], z["ir"].astype(np.int64), z["jc"].astype(np.int64)), shape=(p, n))
+        want_d, want_a = oracle.min_cols(z["dist"])
+        a, d, _, nk = run_assign(gpu_ctx, X, z["C"], 0.0)
+        assert np.array_equal(a, want_a) and np.array_equal(d, want_d), f
+        eng = LloydEngine(Shard.from_scipy(gpu_ctx, X), K, 1.0, unbiased=False)
+        eng.assign_accumulate_step(torch.tensor(np.ascontiguousarray(z["C"].T), device="cuda:0"))
+        assert np.array_equal(eng.assign.cpu().numpy(), want_a), f
+        assert np.array_equal(eng.mind.cpu().numpy(), want_d), f
+        assert np.array_equal(eng.nk.cpu().numpy(), np.bincount(want_a, minlength=K)), f
+
+
 def test_ties_take_first_index(gpu_ctx, oracle):
     """Duplicate centroids give exactly equal distances: MATLAB's min keeps the first
     (findClusterAssignments.m:169); empty columns give all-zero distances -> index 0."""

@@ -55,6 +55,56 @@ def test_inner_product_and_norms(gpu_ctx, oracle):
     assert np.array_equal(S.SparseMatrixColumnNormSq(X, ctx=gpu_ctx), oracle.colnormsq_csc(3000, X.indptr, X.data))
 
 
+def _golden(prefix):
+    import os
+
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    files = sorted(f for f in os.listdir(gold) if f.startswith(prefix))
+    return [(f, np.load(os.path.join(gold, f))) for f in files]
+
+
+def _fixture_csc(z):
+    return sp.csc_matrix((z["x"], z["ir"].astype(np.int64), z["jc"].astype(np.int64)), shape=(int(z["p"]), int(z["n"])))
+
+
+def test_sparse_operators_equal_the_reference_s_own_outputs(gpu_ctx, oracle):
+    """The three stand-alone HIP operators against vectors produced by the REFERENCE's own loops
+    (tests/golden/make_ref_fixtures.py: SparseMatrixMinusCluster.c:121-129,131-183, SparseMatrixInnerProduct.c:86-100,
+    SparseMatrixColumnNormSq.c:70-77 compiled from /root/reference in the build container) -- bit for bit, every branch
+    of the reference's `switch (K)`.  Where the prebuilt oracle/_ref binary travelled with the snapshot, fresh random
+    matrices go through it as well."""
+    import sparsifiedkmeans_amd as S
+
+    dist = _golden("ref_dist_")
+    assert len(dist) == 8
+    for f, z in dist:
+        got = S.SparseMatrixMinusCluster(_fixture_csc(z), z["C"], ctx=gpu_ctx)
+        assert np.array_equal(got, z["dist"]), f
+    (f, z), = _golden("ref_beta_")
+    for b in z["betas"]:
+        key = "dist_beta_" + str(float(b)).replace(".", "p").replace("-", "m")
+        got = S.SparseMatrixMinusCluster(_fixture_csc(z), z["c"], beta=float(b), ctx=gpu_ctx)
+        assert np.array_equal(got[0], z[key], equal_nan=True), key
+    (f, z), = _golden("ref_ip_")
+    ip, nx2 = S.SparseMatrixInnerProduct(_fixture_csc(z), z["c"], ctx=gpu_ctx)
+    assert np.array_equal(ip, z["ip"]) and np.array_equal(nx2, z["nx2"])
+    assert np.array_equal(S.SparseMatrixColumnNormSq(_fixture_csc(z), ctx=gpu_ctx), z["nsq"])
+    if oracle.ref_available("sparse"):
+        for p, n, K, s in [(1024, 3000, 100, 51), (784, 2000, 10, 40), (300, 5000, 3, 15), (64, 9000, 1, 6)]:
+            X = random_csc(p, n, s, seed=p + K, ragged=True, empty_cols=(0, n - 1))
+            Cm = np.random.default_rng(K).standard_normal((p, K))
+            jc, ir, x = parts(X)
+            assert np.array_equal(S.SparseMatrixMinusCluster(X, Cm, ctx=gpu_ctx), oracle.ref_dist_csc(p, n, jc, ir, x, Cm))
+            if K == 1:
+                c = Cm[:, 0]
+                assert np.array_equal(S.SparseMatrixMinusCluster(X, c, beta=0.3, ctx=gpu_ctx)[0],
+                                      oracle.ref_dist_csc_beta(n, jc, ir, x, c, 0.3), equal_nan=True)
+                ip, nx2 = S.SparseMatrixInnerProduct(X, c, ctx=gpu_ctx)
+                rip, rnx2 = oracle.ref_innerprod_csc(n, jc, ir, x, c)
+                assert np.array_equal(ip, rip) and np.array_equal(nx2, rnx2)
+                assert np.array_equal(S.SparseMatrixColumnNormSq(X, ctx=gpu_ctx), oracle.ref_colnormsq_csc(n, jc, x))
+
+
 @pytest.mark.parametrize("m", [2, 4, 8, 16, 32, 64, 256, 1024, 4096, 16384, 32768])
 @pytest.mark.parametrize("n", [1, 3, 17])
 def test_hadamard_bit_exact(gpu_ctx, oracle, m, n):

@@ -105,6 +105,90 @@ def test_reference_generated_fwht_fixtures(oracle):
             assert np.array_equal(oracle.ref_fwht(z["x"], "portable"), z["out"]), f
 
 
+def _grid_csc(p, n, K, seed):
+    """SURVEY 8(c)(i) inputs: ragged columns, an empty one where there is room, duplicate centroids (exact ties)."""
+    s = max(1, min(p, p // 20 if p >= 40 else p))
+    X = random_csc(p, n, s, seed=seed, ragged=(n > 1 and p > 2), empty_cols=(n // 2,) if n > 2 else ())
+    Cm = np.random.default_rng(seed + 1).standard_normal((p, K)) * 2.0
+    if K >= 3:
+        Cm[:, K - 1] = Cm[:, 0]
+    return X, Cm
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_ROOT, "private", "SparseMatrixMinusCluster.c")),
+                    reason="the reference tree is not on this machine (oracle/_ref is built from it in place)")
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 7, 10, 100])
+@pytest.mark.parametrize("p", [2, 64, 512, 1024])
+def test_sparse_oracle_equals_the_reference_build(oracle, K, p):
+    """PINS rows a1-a3, a11, a12: orc_dist_csc / orc_dist_csc_beta / orc_innerprod_csc / orc_colnormsq_csc (and the
+    numpy restatement) against the reference's OWN loops -- private/SparseMatrixMinusCluster.c:131-183 (`switch (K)`,
+    every branch: K = 1, 2, 3, general) and :121-129 (beta), SparseMatrixInnerProduct.c:86-100,
+    SparseMatrixColumnNormSq.c:70-77 -- cut out at build time and compiled with setup_kmeans.m:19,26,33's `-O`
+    (oracle/Makefile, oracle/ref_sparse_shim.c; no stand-in header).  SURVEY 8(c)(i)'s grid."""
+    oracle.build(force=True)
+    assert oracle.ref_available("sparse") and oracle.ref_available("sparse_O2")
+    for n in (1, 257, 4096):
+        if p * n * K > 3e7 and n == 4096:
+            n = 1024                                                     # (K = 100, p >= 512: keep the CPU suite short)
+        X, Cm = _grid_csc(p, n, K, seed=7919 * K + 31 * p + n)
+        jc, ir, x = parts(X)
+        want = oracle.ref_dist_csc(p, n, jc, ir, x, Cm)
+        assert np.array_equal(oracle.ref_dist_csc(p, n, jc, ir, x, Cm, "sparse_O2"), want)   # mex's stock -O2: same bits
+        assert np.array_equal(oracle.dist_csc(p, n, jc, ir, x, Cm), want)
+        if n <= 257:
+            assert np.array_equal(R.dist_csc(p, n, jc, ir, x, Cm), want)
+        # findClusterAssignments.m:169 on the reference's distances == orc_assign (gamma empty: no centres/gamma step)
+        mind, a = oracle.min_cols(want)
+        a2, mind2 = oracle.assign(p, n, jc, ir, x, Cm, 0.0)
+        assert np.array_equal(a, a2) and np.array_equal(mind, mind2)
+        if K >= 3 and X.nnz:
+            assert not np.any(a == K - 1)                                # the duplicate never wins: first index
+        if K == 1:
+            c = Cm[:, 0]
+            for beta in (0.37, 1.0, -0.5):
+                assert np.array_equal(oracle.dist_csc_beta(n, jc, ir, x, c, beta),
+                                      oracle.ref_dist_csc_beta(n, jc, ir, x, c, beta), equal_nan=True)
+            ip, nx2 = oracle.innerprod_csc(n, jc, ir, x, c)
+            rip, rnx2 = oracle.ref_innerprod_csc(n, jc, ir, x, c)
+            assert np.array_equal(ip, rip) and np.array_equal(nx2, rnx2)
+            assert np.array_equal(oracle.colnormsq_csc(n, jc, x), oracle.ref_colnormsq_csc(n, jc, x))
+            assert np.array_equal(rnx2, oracle.ref_colnormsq_csc(n, jc, x))
+
+
+def _load_golden(prefix):
+    files = sorted(f for f in os.listdir(GOLDEN) if f.startswith(prefix))
+    return [(f, np.load(os.path.join(GOLDEN, f))) for f in files]
+
+
+def test_reference_generated_sparse_fixtures(oracle):
+    """tests/golden/ref_dist_* / ref_beta_* / ref_ip_*.npz are outputs of the reference's own loops
+    (make_ref_fixtures.py): they pin the oracle wherever the tests run, with or without /root/reference."""
+    dist = _load_golden("ref_dist_")
+    assert sorted(int(z["K"]) for _, z in dist) == [1, 1, 2, 3, 4, 7, 10, 100], "run tests/golden/make_ref_fixtures.py"
+    for f, z in dist:
+        p, n, K = int(z["p"]), int(z["n"]), int(z["K"])
+        jc, ir, x = z["jc"].astype(np.uint64), z["ir"].astype(np.uint64), z["x"]
+        assert str(z["kind"]) == "ref_dist" and z["dist"].shape == (K, n)
+        assert np.array_equal(oracle.dist_csc(p, n, jc, ir, x, z["C"]), z["dist"]), f
+        assert np.array_equal(R.dist_csc(p, n, jc, ir, x, z["C"]), z["dist"]), f
+        mind, a = oracle.min_cols(z["dist"])
+        a2, mind2 = oracle.assign(p, n, jc, ir, x, z["C"], 0.0)
+        assert np.array_equal(a, a2) and np.array_equal(mind, mind2), f
+        if oracle.ref_available("sparse"):                        # the prebuilt binary that travelled with the snapshot
+            assert np.array_equal(oracle.ref_dist_csc(p, n, jc, ir, x, z["C"]), z["dist"]), f
+    (f, z), = _load_golden("ref_beta_")
+    jc, ir, x = z["jc"].astype(np.uint64), z["ir"].astype(np.uint64), z["x"]
+    for b in z["betas"]:
+        key = "dist_beta_" + str(float(b)).replace(".", "p").replace("-", "m")
+        assert np.array_equal(oracle.dist_csc_beta(int(z["n"]), jc, ir, x, z["c"], float(b)), z[key], equal_nan=True), key
+        assert np.array_equal(R.dist_csc_beta(int(z["n"]), jc, ir, x, z["c"], float(b)), z[key], equal_nan=True), key
+    (f, z), = _load_golden("ref_ip_")
+    jc, ir, x = z["jc"].astype(np.uint64), z["ir"].astype(np.uint64), z["x"]
+    ip, nx2 = oracle.innerprod_csc(int(z["n"]), jc, ir, x, z["c"])
+    assert np.array_equal(ip, z["ip"]) and np.array_equal(nx2, z["nx2"])
+    assert np.array_equal(oracle.colnormsq_csc(int(z["n"]), jc, x), z["nsq"]) and np.array_equal(z["nsq"], z["nx2"])
+
+
 def test_plain_mean_update_is_the_dense_mean(oracle):
     """Row a8, 'MLcorrection',false (kmeans_sparsified.m:449-451): centers(:,k) = mean(full(X(:,ind)),2) -- zeros
     included, so it differs from the ML estimate of :448 whenever a row is not stored in every member."""
