@@ -573,24 +573,68 @@ def cpu_sample_arrays(data, centers0, s, n_cpu):
     return dict(jc=jc, ir=ir, x=x, C0=centers0.cpu().numpy().T.copy(), n=n_cpu)
 
 
+def _reference_lloyd_iteration(O, p2, K, gamma, s, jc, ir, x, C0, n, chunk=250_000):
+    """One iteration with the distance loop run by the REFERENCE's own compiled code (oracle/_ref/libref_sparse.so =
+    private/SparseMatrixMinusCluster.c:131-183) and the MATLAB-level steps around it ported: centers/gamma
+    (findClusterAssignments.m:76-82), min over the K rows (:169), per-cluster sums / counts and the ML-corrected centres
+    (kmeans_sparsified.m:430-448).  Returns seconds spent in (distance loop, everything else)."""
+    cg = np.ascontiguousarray((C0 / gamma).T).ravel()                     # p2 x K column-major, true IEEE divide
+    a, mind = np.zeros(n, np.int32), np.zeros(n)
+    D = np.zeros(min(chunk, n) * K)
+    t_dist = t_rest = 0.0
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        jcc = np.ascontiguousarray(jc[lo: lo + m + 1] - jc[lo])
+        t0 = time.perf_counter()
+        O.ref_dist_csc_flat(p2, m, K, jcc, ir[lo * s: (lo + m) * s], x[lo * s: (lo + m) * s], cg, D[: m * K])
+        t1 = time.perf_counter()
+        O.lib().orc_min_cols(K, m, D[: m * K], mind[lo: lo + m], a[lo: lo + m])
+        t_dist += t1 - t0
+        t_rest += time.perf_counter() - t1
+    t0 = time.perf_counter()
+    S, Cnt, nk = O.accumulate(p2, n, K, jc[: n + 1], ir[: n * s], x[: n * s], a)
+    O.finalize_centers(S, Cnt, nk, gamma, C0)
+    t_rest += time.perf_counter() - t0
+    return t_dist, t_rest, a
+
+
 def cpu_baseline(cd, p2, K, gamma, s, n_one, n_total):
-    """The CPU oracle (a port: the reference's own C cannot be built without MATLAB's mex.h) on the host's cores, on a
-    bounded sample of the same workload, scaled linearly to N:
-      * `value`, cores = 1: the faithful variant -- the reference's distance mex is single-threaded
-        (private/SparseMatrixMinusCluster.c:117-184) and so is its MATLAB update loop;
+    """The reference's CPU path on the host's cores, on a bounded sample of the same workload, scaled linearly to N:
+      * `value`, cores = 1, kind "reference": the distance loop is the reference's own C (`switch (K)`,
+        private/SparseMatrixMinusCluster.c:131-183, single-threaded as in the reference; built into oracle/_ref by
+        oracle/Makefile in the build container and travelled here as a binary), the MATLAB-level steps around it are
+        ported (`kind_detail`).  Without that binary: kind "port", `orc_lloyd` (oracle/orc_sparse.c) as in rounds 1-3;
+      * `port_one_thread`: orc_lloyd on the same sample (the restatement; agrees with the reference leg bit for bit);
       * `all_cores`: the same iteration with the points column-partitioned over every host core the way the reference's
-        one threaded mex partitions its columns (hadamard_pthreads.c:121-204) -- the box-level baseline."""
+        one threaded mex partitions its columns (hadamard_pthreads.c:121-204) -- the box-level baseline (SURVEY 8(d)(ii));
+      * `fwht`: the reference's own threaded FWHT (hadamard_pthreads.c:57-119 behind oracle/_ref) when it travelled."""
     from oracle import oracle as O
 
     O.lib()
     jc, ir, x, C0 = cd["jc"], cd["ir"], cd["x"], cd["C0"]
     t0 = time.perf_counter()
-    O.lloyd(p2, n_one, jc[: n_one + 1], ir[: n_one * s], x[: n_one * s], C0, gamma, maxiter=1, tol=0.0)
+    port = O.lloyd(p2, n_one, jc[: n_one + 1], ir[: n_one * s], x[: n_one * s], C0, gamma, maxiter=1, tol=0.0)
     dt = time.perf_counter() - t0
-    out = {"value": 1.0 / (dt * n_total / n_one), "unit": "Lloyd iters/sec", "cores": 1, "kind": "port",
-           "sample": f"1 Lloyd iteration of oracle/orc_sparse.c orc_lloyd (gcc -O, single thread) on the first "
-                     f"{n_one} points of the same dataset in {dt:.2f} s, scaled linearly to N={n_total}",
-           "host_cpus": os.cpu_count(), "host_cpus_usable": host_cores()}
+    port_leg = {"value": 1.0 / (dt * n_total / n_one), "unit": "Lloyd iters/sec", "cores": 1,
+                "sample": f"1 Lloyd iteration of oracle/orc_sparse.c orc_lloyd (gcc -O, single thread) on the first "
+                          f"{n_one} points of the same dataset in {dt:.2f} s, scaled linearly to N={n_total}"}
+    out = dict(port_leg, kind="port")
+    if O.ref_available("sparse"):
+        try:
+            td, tr, a_ref = _reference_lloyd_iteration(O, p2, K, gamma, s, jc, ir, x, C0, n_one)
+            out = {"value": 1.0 / ((td + tr) * n_total / n_one), "unit": "Lloyd iters/sec", "cores": 1, "kind": "reference",
+                   "kind_detail": "reference C (private/SparseMatrixMinusCluster.c:131-183 compiled with setup_kmeans.m:19's "
+                                  "-O, oracle/_ref/libref_sparse.so) for the distance loop + port of the MATLAB steps "
+                                  "(centers/gamma, min, sums / counts, ML-corrected centres: oracle/orc_sparse.c)",
+                   "sample": f"1 Lloyd iteration on the first {n_one} points of the same dataset: {td:.2f} s in the "
+                             f"reference's distance loop + {tr:.2f} s in the ported steps, single thread, scaled linearly "
+                             f"to N={n_total}",
+                   "distance_loop_share": td / (td + tr),
+                   "assignments_equal_port": bool(np.array_equal(a_ref, port["assign"])),
+                   "port_one_thread": port_leg}
+        except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+            out["reference_leg_error"] = str(e)
+    out["host_cpus"], out["host_cpus_usable"] = os.cpu_count(), host_cores()
     try:
         threads = host_cores()
         n_all = cd["n"]
@@ -604,18 +648,23 @@ def cpu_baseline(cd, p2, K, gamma, s, n_one, n_total):
     except Exception as e:  # the baseline is a report, never a reason to lose the bench line
         out["all_cores"] = {"error": str(e)}
     # the preconditioner's CPU path: the reference's one multi-threaded mex (private/hadamard_pthreads.c, static
-    # column partition over NTHREADS = maxNumCompThreads(), setup_kmeans.m:45), restated in oracle/orc_fwht.c
+    # column partition over NTHREADS = maxNumCompThreads(), setup_kmeans.m:45) -- its own worker + kernels (:57-119)
+    # from oracle/_ref when the binary travelled (our restatement of the partition around them), else orc_fwht_threads
     try:
         threads = max(1, min(host_cores(), 64))
         cols = 32768
         xin = np.random.default_rng(0).standard_normal(cols * p2)
         yout = np.zeros_like(xin)
-        O.lib().orc_fwht_threads(p2, cols, xin, yout, threads)          # warm-up (thread creation, page faults)
+        if O.ref_available("pthreads"):
+            fn, what, kind = O._ref("pthreads").ref_hadamard_pthreads, "private/hadamard_pthreads.c:57-119 (oracle/_ref)", "reference"
+        else:
+            fn, what, kind = O.lib().orc_fwht_threads, "oracle/orc_fwht.c orc_fwht_threads", "port"
+        fn(p2, cols, xin, yout, threads)          # warm-up (thread creation, page faults)
         t0 = time.perf_counter()
-        O.lib().orc_fwht_threads(p2, cols, xin, yout, threads)
+        fn(p2, cols, xin, yout, threads)
         dt = time.perf_counter() - t0
-        out["fwht"] = {"columns_per_s": cols / dt, "threads": threads, "m": p2,
-                       "sample": f"{cols} columns of length {p2}, oracle/orc_fwht.c orc_fwht_threads"}
+        out["fwht"] = {"columns_per_s": cols / dt, "threads": threads, "m": p2, "kind": kind,
+                       "sample": f"{cols} columns of length {p2}, {what}"}
     except Exception as e:
         out["fwht"] = {"error": str(e)}
     return out

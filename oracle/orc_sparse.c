@@ -6,14 +6,17 @@
  * and bench.py's cpu_baseline leg may load this; the product path
  * (sparsifiedkmeans_amd/) never does.
  *
- * PARITY UNPINNED: the reference holds no golden vectors or known-answer tests
- * for this path, and its C files cannot be built in this image (they include
- * MATLAB's "mex.h", which is absent; writing a stand-in header is not allowed),
- * so this restatement has not been checked against outputs of the reference
- * itself.  It is pinned only by (a) line-by-line correspondence with the cited
- * reference source, (b) an independent numpy restatement (oracle/numpy_ref.py)
- * that must agree bit-for-bit, and (c) the identities the reference documents
- * (dist(i) == norm(X(ind,i)-c(ind)), SparseMatrixMinusCluster.c:1-8).
+ * PARITY: the four loops at the top of this file (rows a1-a3, a11, a12 of SURVEY section 8) are PINNED: they are
+ * checked bit for bit against the reference's OWN loops -- SparseMatrixMinusCluster.c:121-129 and :131-183,
+ * SparseMatrixInnerProduct.c:86-100, SparseMatrixColumnNormSq.c:70-77, line ranges without any mx / mex call, cut
+ * out of the files where they lie under /root/reference and compiled with the reference's flags (oracle/Makefile,
+ * oracle/ref_sparse_shim.c -> oracle/_ref/libref_sparse.so; no stand-in for mex.h) -- over SURVEY 8(c)(i)'s grid
+ * (tests/test_oracle.py::test_sparse_oracle_equals_the_reference_build) and against tests/golden/ref_dist_*.npz,
+ * ref_beta_*.npz, ref_ip_*.npz, which those loops wrote.  The functions further down restate MATLAB code
+ * (findClusterAssignments.m, kmeans_sparsified.m): no MATLAB / Octave in this image, structurally unpinnable; they
+ * are held by (a) line-by-line correspondence with the cited source, (b) an independent numpy restatement
+ * (oracle/numpy_ref.py) that must agree bit-for-bit, (c) the identities the reference documents, and (d) being thin
+ * compositions of the pinned loops (orc_assign == MATLAB `min` over the reference's own distances: tested).
  *
  * Build flags matter for bit patterns: compile with
  *   gcc -O -ffp-contract=off        (reference: `mex -largeArrayDims`, i.e.
