@@ -373,6 +373,12 @@ int spkm_timing_log(spkm_ctx *ctx, int enable);
  * kernel.  enable=1 arms it; enable=0 copies up to cap pairs into out and reports the grid size. */
 int spkm_debug_block_times(spkm_ctx *ctx, int enable, int64_t *out, int cap, int *nblocks);
 int spkm_timing_read(spkm_ctx *ctx, double *ms, int cap, int *count);
+/* Developer / test aid: the bounds a shard carries from its last screen call (csrc/screen.hip, k_center_drift), copied to
+ * host buffers of n entries each (any may be NULL): ub = upper bound on each point's distance to its centroid, lb = lower
+ * bound on its distance to every other centroid (the stored value minus the drift accumulated since), lib_assign = the
+ * library's copy of the assignment.  Blocks on the stream.  SPKM_ERR_UNSUPPORTED when the shard holds no valid bounds.
+ * tests/test_gpu_screen.py checks that they ARE bounds after every kind of call. */
+int spkm_debug_shard_bounds(spkm_ctx *ctx, const spkm_shard *s, float *ub, double *lb, int32_t *lib_assign);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 /*
- * mex gateway: y = hadamard(x)  -- drop-in for the reference's private/hadamard.c (and, copied to
- * hadamard_pthreads.c, for private/hadamard_pthreads.c: both names map to one HIP kernel whose output
- * is bit-identical to either).  NOT COMPILED HERE (needs MATLAB's mex.h).
+ * mex gateway: y = hadamard(x)  -- drop-in for the reference's private/hadamard.c (hadamard_pthreads.c next to this
+ * file is the gateway for private/hadamard_pthreads.c: both names map to one HIP kernel whose output is bit-identical
+ * to either).  NOT COMPILED HERE (needs MATLAB's mex.h).
  *     mex -largeArrayDims -I<repo>/include hadamard.c -L<repo>/sparsifiedkmeans_amd -lspkm -lamdhip64
  */
 #include "mex.h"

@@ -53,6 +53,7 @@ static double *g_dmind = NULL, *g_dC = NULL, *g_dred = NULL, *g_dout = NULL, *g_
 static int32_t *g_dassign = NULL;
 static size_t g_buf_n = 0, g_buf_pk = 0, g_buf_rl = 0;
 static int g_exit_registered = 0, g_csc_released = 0;
+static int g_last_sparse = 0;   /* the latest 'iterate' ran the sparse-centres assignment (its distances are in g_dmind) */
 
 static void *dmalloc(size_t bytes)
 {
@@ -69,6 +70,7 @@ static void release_all(void)
     g_shard = NULL;
     g_n = g_p = g_s = 0;
     g_csc_released = 0;
+    g_last_sparse = 0;
     dfree((void **)&g_jc); dfree(&g_ir); dfree((void **)&g_x);
     dfree((void **)&g_dmind); dfree((void **)&g_dassign); dfree((void **)&g_dC); dfree((void **)&g_dred);
     dfree((void **)&g_dout); dfree((void **)&g_dstats);
@@ -267,15 +269,25 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
          * per run -- and with them obj (:471) and [~,iMax] = max(distances) (:436) */
         if (nrhs < 3 || nrhs > 4) mexErrMsgTxt("usage: [d, obj, iMax] = spkm_lloyd('distances', centersUsed, gamma [, unbiased])");
         const mxArray *C = prhs[1];
+        if (mxIsComplex(C) || !mxIsDouble(C)) mexErrMsgTxt("centers must be a real double matrix");
         if (mxGetM(C) != p) mexErrMsgTxt(spkm_strerror(SPKM_ERR_CENTER_ROWS));
         const size_t K = mxGetN(C);
         const int unbiased = nrhs == 4 ? (mxGetScalar(prhs[3]) != 0.0) : 1;
-        centre_buffers(p, K);
-        double *d_cu = (double *)dmalloc(p * K * 8);
-        hipMemcpy(d_cu, mxGetPr(C), p * K * 8, hipMemcpyHostToDevice);
-        check(spkm_distances_stats_dev(ctx, g_shard, K, d_cu, unbiased ? mxGetScalar(prhs[2]) : 0.0, g_dassign, g_dmind, g_dstats));
-        check(spkm_ctx_sync(ctx));
-        hipFree(d_cu);
+        if (mxIsSparse(C)) {
+            /* SPARSE centres: the iteration they were used in went through spkm_assign_sparse_centers_dev
+             * (private/findClusterAssignments.m:63-75), which wrote every distance and the statistics already -- they are
+             * still in g_dmind / g_dstats.  (The dense formula below would be the wrong one for them, and mxGetPr of a
+             * sparse matrix holds nnz values, not p*K.) */
+            if (!g_last_sparse)
+                mexErrMsgTxt("spkm_lloyd('distances'): sparse centres, but the latest iteration did not use sparse centres");
+        } else {
+            centre_buffers(p, K);
+            double *d_cu = (double *)dmalloc(p * K * 8);
+            hipMemcpy(d_cu, mxGetPr(C), p * K * 8, hipMemcpyHostToDevice);
+            check(spkm_distances_stats_dev(ctx, g_shard, K, d_cu, unbiased ? mxGetScalar(prhs[2]) : 0.0, g_dassign, g_dmind, g_dstats));
+            check(spkm_ctx_sync(ctx));
+            hipFree(d_cu);
+        }
         plhs[0] = mxCreateDoubleMatrix(1, n, mxREAL);
         hipMemcpy(mxGetPr(plhs[0]), g_dmind, n * 8, hipMemcpyDeviceToHost);
         double st[3];
@@ -311,6 +323,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         hipMemcpy(d_mask, hm, pk, hipMemcpyHostToDevice);
         mxFree(hv); mxFree(hm);
         check(spkm_assign_sparse_centers_dev(ctx, g_shard, K, g_dC, d_mask, unbiased ? gamma : 0.0, g_dassign, g_dmind, g_dstats, NULL));
+        g_last_sparse = 1;   /* 'distances' with these (sparse) centres returns what this call wrote */
         check(spkm_accumulate_dev(ctx, g_shard, K, g_dassign, g_dred));
         check(spkm_allreduce_f64_dev(ctx, g_dred, spkm_reduce_len(p, K)));
         check(spkm_finalize_dev(ctx, p, K, g_dred, gamma, g_dC, g_dout));
@@ -318,6 +331,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         hipFree(d_mask);
         goto outputs;
     }
+    g_last_sparse = 0;
     if (hipMemcpy(g_dC, mxGetPr(C), pk * 8, hipMemcpyHostToDevice) != hipSuccess) mexErrMsgTxt("copy of the centres failed");
     /* assignment + accumulation (+ all-reduce when a communicator is attached) + centre update: the certified f32
      * screen with exact f64 confirmation where the data qualifies (every column the same length, as

@@ -1405,6 +1405,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                                ctx->sw.no_support_drift ? 0 : s->fixed_s, 2.0f * (float)s->fixed_s / (float)p,
                                sm->hb + 3 * npad + HB_HTERM);
             // settle the steps (points) the bounds certify, list the others for the screen; write the hints
+            // (erode: EVERY lazy call without distances -- an incremental one, and a sums-only full pass, which writes no
+            //  upper bound either: a point that passes the test gets no fresh bound from anybody in such a call, so its
+            //  bound has to take its centroid's drift here.  A call whose distance pass does run overwrites it again.)
             if ((rc = ensure(ctx, ctx->todo, pt_mode ? (size_t)(npad + 64) * 4 : (size_t)(npad / 16 + 1) * 4))) return rc;
             // (small shards: shorter spans, so that the launch still has >= 8 workgroups per CU)
             // (its statistics leave per workgroup, bstat, and are added up by the call's last kernel: same-address atomics of
@@ -1417,7 +1420,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
                                pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1),
-                               (int)span, (unsigned*)ctx->bstat.p, ev_path ? 1 : 0);
+                               (int)span, (unsigned*)ctx->bstat.p, (sm->lazy && d_mind == nullptr) ? 1 : 0);
             bstat_n = (int)std::min<long long>((npad + span - 1) / span, bgrid);
             if (skip_enabled) sm->cum_par ^= 1; // the drift has been added
         }
@@ -2050,6 +2053,25 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
 
 // [0] = path of the last spkm_assign_accumulate_dev (0 exact tiles, 1 f32 screen + exact confirmation),
 // [1] = number of points the screen could not certify (evaluated exactly over all K).  Blocks on the stream.
+extern "C" int spkm_debug_shard_bounds(spkm_ctx* ctx, const spkm_shard* s, float* ub, double* lb, int32_t* lib_assign)
+{
+    if (!ctx || !s) return SPKM_ERR_NULL_ARG;
+    if (!s->hb || !s->hb_valid || !s->hb_cum) return SPKM_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t)s->n, npad = (size_t)s->hb_npad;
+    if (ub) HIP_TRY(hipMemcpy(ub, s->hb, n * 4, hipMemcpyDeviceToHost));
+    if (lib_assign) HIP_TRY(hipMemcpy(lib_assign, s->hb + 2 * npad, n * 4, hipMemcpyDeviceToHost));
+    if (lb) {
+        std::vector<float> rel(n);
+        double cum = 0.0;
+        HIP_TRY(hipMemcpy(rel.data(), s->hb + npad, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&cum, s->hb_cum + s->cum_par, 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) lb[i] = (double)rel[i] - cum;
+    }
+    return SPKM_OK;
+}
+
 extern "C" int spkm_last_path_info(spkm_ctx* ctx, int64_t info[2])
 {
     if (!ctx || !info) return SPKM_ERR_NULL_ARG;

@@ -95,6 +95,13 @@ class Shard:
             self._keep = (self._keep[0],)      # jc stays referenced by the library; ir / x do not
         return True
 
+    def debug_bounds(self) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(ub, lb, lib_assign) the shard carries from its last screen call (spkm_debug_shard_bounds; test aid)."""
+        ub, lb, a = np.zeros(self.n, np.float32), np.zeros(self.n), np.zeros(self.n, np.int32)
+        _lib.check(_lib.lib().spkm_debug_shard_bounds(self.ctx.handle, self.handle, ub.ctypes.data, lb.ctypes.data,
+                                                      a.ctypes.data), "spkm_debug_shard_bounds")
+        return ub, lb, a
+
     def reset_policy(self):
         """New start / new replicate: drop the adaptive state of the fused call (spkm_shard_reset_policy)."""
         _lib.check(_lib.lib().spkm_shard_reset_policy(self.handle), "spkm_shard_reset_policy")

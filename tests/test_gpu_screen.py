@@ -672,6 +672,64 @@ def test_lazy_statistics_incremental_sums_stay_the_members_sums(gpu_ctx, oracle,
         assert np.count_nonzero(a1 != a0) <= max(2, n // 10000)
 
 
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_carried_bounds_stay_bounds_through_every_kind_of_lazy_call(gpu_ctx, oracle, shuffled):
+    """The bounds a shard carries between screen calls must BE bounds after every call, whatever form the call took:
+    ub[i] >= the distance to the point's centroid, lb[i] <= the distance to every other centroid (under the centres the
+    call was given).  A lazy call (no distances) writes upper bounds from the screen's certificate only for the points
+    it screened; a point that passed the carried-bounds test has to take its centroid's drift in k_bounds_steps -- in an
+    incremental call AND in a sums-only full pass (round 3 eroded only in the former: a stale bound survived a sums-only
+    call and could keep a point in a cluster the reference's argmin had left).  Teacher-forced centres: small drifts
+    (events), then a jump that moves more than a third of the points (the call after it is a sums-only pass WITH valid
+    bounds), then small drifts again.  Assignments are the oracle's in every call."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 256, 30000, 12, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=5, noise=0.2)
+    if shuffled:
+        X = X[:, np.random.default_rng(1).permutation(n)]
+    rng = np.random.default_rng(2)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    s = synth.small_p_of(gopt, p)
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    gam = s / p
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    shard.reset_policy()
+    shard.set_lazy_stats(True)
+    eng = LloydEngine(shard, K, gam)
+    jc, ir, x = parts(Y)
+    base = oracle.mix(centres, d, p) * gam                            # near the optimum: most points keep their cluster
+    scale = np.abs(base).max()
+    jump = base.copy()
+    jump[:, : K // 2] = base[:, np.roll(np.arange(K // 2), 1)]        # half of the centroids trade places: their members move
+    seq = [("drift", 0.0), ("drift", 2e-3), ("drift", 4e-3), ("jump", 0.0), ("jump", 2e-3), ("jump", 4e-3), ("jump", 5e-3),
+           ("drift", 5e-3), ("drift", 6e-3)]
+    forms = []
+    for it, (what, eps) in enumerate(seq):
+        Cm = (jump if what == "jump" else base) + eps * scale * np.random.default_rng(100 + it).standard_normal((p, K))
+        c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+        eng.assign_accumulate_step(c, want_mind=False)
+        torch.cuda.synchronize()                                       # (lets the library's asynchronous counters land)
+        forms.append(eng.last_screen_mode()[6])
+        assert eng.last_path_info()[0] == 1
+        D = oracle.dist_csc(p, n, jc, ir, x, Cm / gam)                 # K x n, the reference's distances
+        ra, rd = oracle.assign(p, n, jc, ir, x, Cm, gam)
+        a = eng.assign.cpu().numpy()
+        assert np.array_equal(a, ra), (it, what)
+        ub, lb, la = shard.debug_bounds()
+        assert np.array_equal(la, ra), (it, what)
+        own = D[ra, np.arange(n)]
+        Do = D.copy(); Do[ra, np.arange(n)] = np.inf
+        other = Do.min(axis=0)
+        bad_ub = np.flatnonzero(ub.astype(np.float64) < own)
+        bad_lb = np.flatnonzero(lb > other)
+        assert bad_ub.size == 0, (it, what, forms, bad_ub[:5], ub[bad_ub[:5]], own[bad_ub[:5]])
+        assert bad_lb.size == 0, (it, what, forms, bad_lb[:5], lb[bad_lb[:5]], other[bad_lb[:5]])
+    shard.set_lazy_stats(False)
+    assert 2 in forms and 3 in forms[1:], forms                        # events, and a sums-only pass on valid bounds, both ran
+
+
 @pytest.mark.parametrize("p,s,n,K", [(1024, 51, 20000, 10), (1024, 51, 5003, 2), (256, 26, 30011, 16), (512, 26, 70000, 7),
                                      (64, 5, 4099, 3), (1024, 49, 9000, 9)])
 def test_one_pass_for_few_centroids(gpu_ctx, oracle, monkeypatch, p, s, n, K):
