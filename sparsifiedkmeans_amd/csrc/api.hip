@@ -63,6 +63,7 @@ struct spkm_switches {
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
     bool no_sums_only = false;    // SPKM_NO_SUMS_ONLY: a lazy call's full pass still evaluates every point's distance
     bool onepass = false;         // SPKM_ONEPASS: few centroids (K <= 16) take the fused one-pass form (onepass.hip) -- off by default: measured slower
+    bool no_dual = false;         // SPKM_NO_DUAL: a run's second lazy call takes the events whatever moves (round 3) instead of deciding on the device
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
 static spkm_switches read_switches()
@@ -87,6 +88,7 @@ static spkm_switches read_switches()
     w.no_teams = on("SPKM_NO_TEAMS");
     w.onepass = on("SPKM_ONEPASS");
     w.no_sums_only = on("SPKM_NO_SUMS_ONLY");
+    w.no_dual = on("SPKM_NO_DUAL");
     return w;
 }
 
@@ -126,6 +128,7 @@ struct spkm_ctx {
     bool last_incremental = false;   // the last screen call updated the sums by events (no exact pass)
     bool last_onepass = false;       // the last screen call was a one-pass call (onepass.hip)
     bool last_sums_only = false;     // the last screen call's full pass left the distances out (lazy statistics)
+    bool last_dual = false;          // the last screen call queued both forms; the device chose (counters[19]: the full pass)
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
     bool last_pt_mode = false;       // ... and listed points instead of 16-point steps
@@ -1480,7 +1483,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                            (int*)(sm->hb + 2 * npad), bounds_ok ? 1 : 0, (unsigned*)ctx->nlist.p + 5, (int*)nullptr,
                            (unsigned long long*)nullptr, sm->hb, (int*)nullptr, (int*)nullptr, (unsigned*)ctx->nlist.p,
                            s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
-                           (unsigned long long*)nullptr);
+                           (unsigned long long*)nullptr, 0xffffffffu);
         hipLaunchKernelGGL((k_onepass_listed<IR>), dim3(std::max(1, ctx->num_cus)), dim3(256), 0, ctx->stream,
                            (const char*)sm->rec, sm->rec_R, p, n, s->fixed_s, (const int*)ctx->list.p, (unsigned*)ctx->nlist.p,
                            (const int*)d_assign, cache_s, cache_c, (unsigned long long*)ctx->nk.p);
@@ -1509,6 +1512,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         ctx->last_incremental = false;
         ctx->last_onepass = true;
         ctx->last_sums_only = false;
+        ctx->last_dual = false;
         ctx->last_path = 1;
         return SPKM_OK;
     }
@@ -1600,6 +1604,14 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const bool sums_only = cl_on && sm->lazy && d_mind == nullptr && !ev_path && !cl_skip && !ctx->sw.no_sums_only;
     const bool lazy_ub = ev_path || sums_only; // the certificate writes the upper bounds (k_combine_screen, k_assign_list)
     ctx->last_sums_only = sums_only;
+    // Form chosen on the device (SPKM_NO_DUAL=1: A/B switch): an incremental call issued WITHOUT a mover count -- a run's
+    // second call: the counters come back one call late, and from a random start nearly every point moves -- queues the
+    // full sums-only pass as well; k_pick_form, behind k_assign_list, opens one of the two from the number of events
+    // (policy.h, few_movers: events while at most a third of the points move).  Round 3 took the events blindly there:
+    // 12.1 ms of gathers where the pass takes 8.5 (N = 1e8), 25.0 against 21 ms for a config-5 iteration.
+    const bool dual = ev_path && sm->pol.form_on_device() && cl_on && !ctx->sw.no_dual && !ctx->sw.no_sums_only;
+    const unsigned ev_cap = dual ? (unsigned)std::min<unsigned long long>(spkm_policy::event_cap((unsigned long long)n), 0xfffffff0ull) : 0xffffffffu;
+    ctx->last_dual = dual;
     int* cl_need = cl_on ? sm->cl_flags : nullptr;
     int* cl_touched = cl_on ? sm->cl_flags + K : nullptr;
     int* cl_same = cl_on ? sm->cl_flags + 2 * K : nullptr;
@@ -1627,7 +1639,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        bounds_ok ? 1 : 0, cl_skip ? cl_touched : (int*)nullptr, K,
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
                        lazy_ub ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr,
-                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr);
+                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1636,7 +1648,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        lazy_ub ? sm->hb : (float*)nullptr, ev_path ? sm->ev_pt : (int*)nullptr,
                        ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p,
                        s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
-                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr);
+                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     ctx->last_lib_valid = bounds_ok;
     ctx->last_incremental = ev_path;
@@ -1657,12 +1669,19 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // (sized by what usually moves, not by the worst case: every kernel strides over the device-side count)
         const long long ev_est = std::max<long long>(4096, (long long)std::min<unsigned long long>(sm->pol.movers_known ? 4 * sm->pol.last_movers + 4096 : (unsigned long long)n, (unsigned long long)2 * n));
         const int hb_ = (int)std::min<long long>(1024, (ev_est + 1023) / 1024);
+        // dual: k_pick_form opens the events (gate_ev) or the full pass (gate_full, further down); the events' plan counts
+        // its items in nitems[1], the full pass's in nitems[0] -- whichever does not run leaves an empty work list
+        const unsigned* gate_ev = dual ? (const unsigned*)ctx->nlist.p + 18 : (const unsigned*)nullptr;
+        const unsigned* gate_full = dual ? (const unsigned*)ctx->nlist.p + 19 : (const unsigned*)nullptr;
+        int* nitems_ev = (int*)ctx->nitems.p + (dual ? 1 : 0);
+        if (dual)
+            hipLaunchKernelGGL(k_pick_form, dim3(1), dim3(1), 0, ctx->stream, (unsigned*)ctx->nlist.p, ev_cap, (int*)ctx->nitems.p);
         // (the histogram over the 2 K keys was collected by k_combine_screen / k_assign_list as they appended the events)
         hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk_ev.p, K2,
                            seg_ev, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
-                           (int*)ctx->nitems.p, (const unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+                           nitems_ev, gate_ev, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
         const size_t sc_lds_ev = (size_t)((K2 + 1) & ~1) * 4 + (size_t)K2 * 12;
-        launch_scatter(ctx, hb_, sc_lds_ev, (const int*)sm->ev_k, 0, K2, (const unsigned*)nullptr, (const int*)nullptr, ev_n,
+        launch_scatter(ctx, hb_, sc_lds_ev, (const int*)sm->ev_k, 0, K2, gate_ev, (const int*)nullptr, ev_n,
                        (const int*)sm->ev_pt);
         double* cache_s = sm->cl_cache;
         double* cache_c = cache_s + pk;
@@ -1671,8 +1690,45 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
         hipLaunchKernelGGL((k_accumulate_events<IR>), dim3(ab_ev), dim3(256), slab, ctx->stream, (const char*)sm->rec,
                            sm->rec_R, (const IR*)s->ir, (const double*)s->x, (const int*)ctx->perm.p,
-                           (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)ctx->nitems.p, p,
+                           (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)nitems_ev, p,
                            s->fixed_s, K, cache_s, cache_c);
+        if (dual) {
+            // ---- ... and the full sums-only pass, for the case that too many points moved: the same kernels, in the same
+            // order, as a call that knows it from the start (below); every one of them returns at once unless
+            // k_pick_form opened gate_full.  Its sums go to the reduce buffer (zeroed at the top of the call), from there
+            // into the cache (every cluster is `fresh`), and the tail hands the cache over as it does after the events.
+            if ((rc = ensure(ctx, ctx->blk_obj, (size_t)max_items * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->blk_max, (size_t)max_items * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->blk_imax, (size_t)max_items * 8))) return rc;
+            hipLaunchKernelGGL(k_cluster_need, dim3(1), dim3(256), 0, ctx->stream, cl_touched, (const int*)cl_same, 1, K,
+                               (const unsigned long long*)ctx->nk.p, cl_need, (unsigned*)ctx->nlist.p, gate_full);
+            hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk.p, K,
+                               seg, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                               (int*)ctx->nitems.p, gate_full, (const int*)cl_need, cl_ibeg, cl_icnt);
+            const int sb2 = (int)std::max<long long>(std::min<long long>(1024, (n + 1023) / 1024), std::min<long long>(8192, n / 4096));
+            launch_scatter(ctx, sb2, (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12, (const int*)d_assign, n, K, gate_full, (const int*)nullptr);
+            const void* k3 = (const void*)k_exact_accumulate_rec<IR, 4, true, false>;
+            const size_t lds3 = fixed_lds + (size_t)nw * 16 * per_pt;
+            HIP_TRY(allow_lds(ctx, k3, lds3));
+            const char* a_rec = sm->rec;
+            int a_R = sm->rec_R, a_p = p, a_s = s->fixed_s;
+            const int* a_perm = (const int*)ctx->perm.p;
+            const long long* a_offs = (const long long*)ctx->offs.p;
+            const int4* a_items = (const int4*)ctx->items.p;
+            const int* a_nitems = (const int*)ctx->nitems.p;
+            const double* a_C = d_centers;
+            double a_gamma = gamma;
+            double* a_mind = nullptr;
+            float* a_ub = sm->hb;
+            double *a_sums = sums, *a_counts = counts, *a_bo = (double*)ctx->blk_obj.p, *a_bm = (double*)ctx->blk_max.p;
+            long long* a_bi = (long long*)ctx->blk_imax.p;
+            void* args[] = {&a_rec, &a_R, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s,
+                            &a_mind, &a_ub, &a_sums, &a_counts, &a_bo, &a_bm, &a_bi};
+            const int ab2 = std::min(max_items, std::max(1, ctx->num_cus));
+            HIP_TRY(hipLaunchKernel(k3, dim3(ab2), dim3(threads), args, lds3, ctx->stream));
+            hipLaunchKernelGGL(k_cluster_restore, dim3((unsigned)std::min<size_t>((pk + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+                               (const int*)cl_touched, K, p, sums, counts, cache_s, cache_c, gate_full);
+        }
         if (ctx->tlog_both) HIP_TRY(timing_end(ctx));
         HIP_TRY(hipGetLastError());
         // the call's sums and counts ARE the cache (rows that no member stores any more: exactly 0)
@@ -1864,6 +1920,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         return SPKM_OK; // (statistics and cluster sizes were handed over by run_screen's last kernel)
     }
     ctx->last_path = 0;
+    ctx->last_dual = false;
     sm->hb_valid = false; // the carried bounds describe the previous SCREEN call only
     if (!d_mind) { // the exact kernels produce the distances on their way to the argmin: park them in scratch
         if ((rc = ensure(ctx, ctx->mscr, (size_t)std::max<uint64_t>(s->n, 1) * 8))) return rc;
@@ -2046,6 +2103,11 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         // how the call got its sums: 0 full pass with every distance, 1 one-pass form (onepass.hip), 2 incremental (events),
         // 3 full pass without distances (sums only)
         info[6] = ctx->last_onepass ? 1 : (ctx->last_incremental ? 2 : (ctx->last_sums_only ? 3 : 0));
+        if (ctx->last_dual) { // both forms were queued: which one the device opened (k_pick_form)
+            unsigned f[2] = {0, 0};
+            HIP_TRY(hipMemcpy(f, (const unsigned*)ctx->nlist.p + 18, 8, hipMemcpyDeviceToHost));
+            info[6] = f[1] ? 3 : 2;
+        }
         info[7] = ctx->last_pt_mode ? 2 : 0; // 2: point-granular list
     }
     return SPKM_OK;

@@ -155,4 +155,10 @@ struct spkm_policy {
     // in the previous counted call (an event pair reads the point twice, through a gather: 0.2 ms per million movers at
     // s = 51 against 10.4 ms for a full pass over 1e8 points); no count yet (a run's second call): taken as few.
     bool few_movers(double n) const { return !movers_known || (double)last_movers * 3.0 <= n; }
+    // ... and a call issued without a count (a run's second: the counters come back one call late; from a random start
+    // nearly every point moves there) does not guess: it queues BOTH forms and the device opens one of them once the
+    // events are counted (screen.hip, k_pick_form) -- the events while there are at most event_cap(n) of them, two per
+    // mover, i.e. the same third of the points as above; the full sums-only pass otherwise.
+    bool form_on_device() const { return !movers_known; }
+    static unsigned long long event_cap(unsigned long long n) { return 2ull * (n / 3ull); }
 };

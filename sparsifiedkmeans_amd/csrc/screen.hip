@@ -714,8 +714,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
 // would the centroid.  On return touched[k] = 1 marks the clusters whose freshly accumulated sums are the ones to keep.
 __global__ void k_cluster_need(int* __restrict__ touched, const int* __restrict__ same, int force, int K,
                                const unsigned long long* __restrict__ nk, int* __restrict__ need,
-                               unsigned* __restrict__ counters)
+                               unsigned* __restrict__ counters, const unsigned* __restrict__ gate = nullptr)
 {
+    if (gate != nullptr && *gate == 0u) return; // (k_pick_form: this call's sums come from the events)
     __shared__ unsigned long long s_pts;
     if (threadIdx.x == 0) s_pts = 0ull;
     __syncthreads();
@@ -739,8 +740,10 @@ __global__ void k_cluster_need(int* __restrict__ touched, const int* __restrict_
 // sums / counts (before any all-reduce), all others get theirs from it
 __global__ __launch_bounds__(256) void k_cluster_restore(const int* __restrict__ need, int K, int p,
                                                          double* __restrict__ sums, double* __restrict__ counts,
-                                                         double* __restrict__ cache_s, double* __restrict__ cache_c)
+                                                         double* __restrict__ cache_s, double* __restrict__ cache_c,
+                                                         const unsigned* __restrict__ gate = nullptr)
 {
+    if (gate != nullptr && *gate == 0u) return; // (k_pick_form: this call's sums come from the events)
     const size_t pk = (size_t)K * p;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < pk; t += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(t / p);
@@ -790,6 +793,24 @@ __global__ __launch_bounds__(256) void k_cluster_stats(const int* __restrict__ n
     }
     if (tid == 0) { stats[0] = s_o[0]; stats[1] = s_m[0]; stats[2] = (double)s_i[0]; }
 }
+// The accumulation form of a lazy call, chosen ON THE DEVICE (api.hip, `dual`): a call whose mover count the host cannot
+// know yet -- a run's second call; the counters come back one call late -- queues BOTH forms, the incremental one
+// (k_plan_segments / k_scatter_by_cluster / k_accumulate_events over the events) and the full sums-only pass
+// (k_cluster_need / plan / scatter / k_exact_accumulate_rec<DIST = false> / k_cluster_restore over all points), and this
+// kernel, queued behind k_assign_list -- when every event has been counted, counters[16] -- opens exactly one of them:
+//   counters[18] = 1: the events (at most ev_cap of them: movers <= n / 3, policy.h few_movers)
+//   counters[19] = 1: the full pass
+// The kernels of the other form return at once (their `gate`) or find an empty work list: nitems[0] (full pass) and
+// nitems[1] (events) are zeroed here, and only the plan kernel that runs fills its own.
+__global__ void k_pick_form(unsigned* __restrict__ counters, unsigned ev_cap, int* __restrict__ nitems)
+{
+    const bool full = counters[16] > ev_cap;
+    counters[18] = full ? 0u : 1u;
+    counters[19] = full ? 1u : 0u;
+    nitems[0] = 0;
+    nitems[1] = 0;
+}
+
 // several small buffers zeroed by ONE launch (the per-call counters, flags and the reduce buffer of the fused
 // iteration: six memsets were six launches in front of the first kernel that does work)
 struct spkm_zero_jobs {
@@ -830,8 +851,11 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         int* __restrict__ touched, int K,
                                                         unsigned long long* __restrict__ nk,
                                                         int lazy, int* __restrict__ ev_pt, int* __restrict__ ev_k,
-                                                        unsigned long long* __restrict__ nk_ev)
+                                                        unsigned long long* __restrict__ nk_ev, unsigned ev_cap)
 {
+    // ev_cap: events appended at a position beyond it are counted but NOT stored -- the call's accumulation form is
+    // chosen on the device from the count (k_pick_form: more than ev_cap events -> the full pass, which needs none of
+    // them), so once the running count has passed the cap the stores (16 B per mover) would be wasted
     // nk_ev (with ev_pt): the histogram of the events over their 2 K keys, collected per workgroup next to the cluster-size
     // deltas -- the counting sort of the events then needs no histogram pass of its own
     // lazy != 0 (the exact pass will not run in this call, api.hip): a certified point's upper bound is written here,
@@ -842,7 +866,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     // would take tens of milliseconds).  nlist[14] counts the movers in every mode, nlist[16] the events.
     constexpr int EVCAP = 2048;
     __shared__ int s_evp[EVCAP], s_evk[EVCAP];
-    __shared__ unsigned s_evn, s_evbase, s_mov;
+    __shared__ unsigned s_evn, s_evbase, s_mov, s_over; // s_over: the running event count has passed ev_cap -- this workgroup stops collecting events
     const double cum_now = cum ? *cum : 0.0; // lower bounds are stored relative to the accumulated drift (k_bounds_steps)
     // The library's own copy of the assignment (bnd + 2 npad) is kept up to date here and in k_assign_list -- the only
     // two places an assignment can change: a CERTIFIED point's new cluster is written at once; an uncertified one keeps
@@ -869,15 +893,16 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     const long long total = skipping ? (pt_mode ? (long long)nlist[4] : (long long)nlist[4] * 16) : n;
     __shared__ unsigned s_amb, s_chg;
     if ((long long)blockIdx.x * blockDim.x >= total) return; // (whole workgroup)
-    if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; }
+    if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; s_over = 0u; }
     if (nk) for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
     if (ev_pt) for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) evc[k] = 0u;
     __syncthreads();
     unsigned nmov = 0;
     auto flush_events = [&]() { // (whole workgroup)
-        if (threadIdx.x == 0) s_evbase = atomicAdd(nlist + 16, s_evn);
+        if (threadIdx.x == 0) { s_evbase = atomicAdd(nlist + 16, s_evn); if (s_evbase > ev_cap) s_over = 1u; }
         __syncthreads();
-        for (unsigned j = threadIdx.x; j < s_evn; j += blockDim.x) { ev_pt[s_evbase + j] = s_evp[j]; ev_k[s_evbase + j] = s_evk[j]; }
+        if (s_evbase <= ev_cap)
+            for (unsigned j = threadIdx.x; j < s_evn; j += blockDim.x) { ev_pt[s_evbase + j] = s_evp[j]; ev_k[s_evbase + j] = s_evk[j]; }
         __syncthreads();
         if (threadIdx.x == 0) s_evn = 0u;
         __syncthreads();
@@ -940,7 +965,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         // could not separate; the host decides from this count whether the next call may use the two-phase screen
         if (!(r2 >= 2.25 * r1)) nambig++;
       }
-      if (ev_pt && __syncthreads_or(mover ? 1 : 0)) { // (every thread of the workgroup gets here in every trip; no mover: nothing to stage)
+      // (s_over: the full pass will run whatever else moves, k_pick_form -- no event of this workgroup is needed any more;
+      //  the flag changes only inside flush_events, between barriers: the same for every thread of a trip)
+      if (ev_pt && !s_over && __syncthreads_or(mover ? 1 : 0)) { // (every thread of the workgroup gets here in every trip; no mover: nothing to stage)
         const int cnt = mover ? (mv_old >= 0 ? 2 : 1) : 0;
         // exclusive prefix of cnt inside the wave, one LDS atomic per wave for its total
         int incl = cnt;
@@ -996,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      float* __restrict__ ubv, int* __restrict__ ev_pt,
                                                      int* __restrict__ ev_k, unsigned* __restrict__ counters,
                                                      const char* __restrict__ rec, int rec_R,
-                                                     unsigned long long* __restrict__ nk_ev)
+                                                     unsigned long long* __restrict__ nk_ev, unsigned ev_cap)
 {
     // alib / lib_valid / touched / nk: the library's copy of the assignment and what follows from a change, as in
     // k_combine_screen (these points kept their previous value there); few points: global atomics
@@ -1075,8 +1102,11 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                         if (nk) { if (vo) atomicAdd(&nk[old], ~0ull); atomicAdd(&nk[bk], 1ull); }
                         if (ev_pt) {
                             const unsigned at = atomicAdd(counters + 16, vo ? 2u : 1u);
-                            if (vo) { ev_pt[at] = (int)i; ev_k[at] = K + old; atomicAdd(&nk_ev[K + old], 1ull); }
-                            ev_pt[at + (vo ? 1u : 0u)] = (int)i; ev_k[at + (vo ? 1u : 0u)] = bk;
+                            if (at <= ev_cap) { // (k_combine_screen: past the cap the events are only counted)
+                                if (vo) { ev_pt[at] = (int)i; ev_k[at] = K + old; }
+                                ev_pt[at + (vo ? 1u : 0u)] = (int)i; ev_k[at + (vo ? 1u : 0u)] = bk;
+                            }
+                            if (vo) atomicAdd(&nk_ev[K + old], 1ull);
                             atomicAdd(&nk_ev[bk], 1ull);
                         }
                     }
@@ -1579,10 +1609,10 @@ template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const 
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned);
 
 // ============================================================================================
 // K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through

@@ -26,6 +26,8 @@ void pol_launched(void* p, int rounds_all, int rounds, int hinted, int late, int
 }
 int pol_pt_next(void* p) { return ((spkm_policy*)p)->pt_next; }
 int pol_few_movers(void* p, double n) { return ((spkm_policy*)p)->few_movers(n); }
+int pol_form_on_device(void* p) { return ((spkm_policy*)p)->form_on_device(); }
+unsigned long long pol_event_cap(unsigned long long n) { return spkm_policy::event_cap(n); }
 int pol_quad_split(int nr) { return quad_split(nr); }
 int pol_quad_split_late(int nr) { return quad_split_late(nr); }
 }

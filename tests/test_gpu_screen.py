@@ -672,6 +672,61 @@ def test_lazy_statistics_incremental_sums_stay_the_members_sums(gpu_ctx, oracle,
         assert np.count_nonzero(a1 != a0) <= max(2, n // 10000)
 
 
+@pytest.mark.parametrize("second_call,expect", [("far", 3), ("near", 2)])
+def test_second_lazy_call_lets_the_device_choose_between_events_and_the_full_pass(gpu_ctx, oracle, monkeypatch, second_call, expect):
+    """A run's second lazy call is issued before any mover count has come back: both accumulation forms are queued and
+    k_pick_form opens one from the number of events.  "far": the second call's centres send most points elsewhere -> the
+    full sums-only pass (form 3); "near": a small drift -> the events (form 2).  Either way assignment, cluster sizes and
+    counts are the oracle's bit for bit and the sums the members' sums; SPKM_NO_DUAL=1 (round 3's behaviour: always the
+    events) gives the same outputs.  The calls after it are held to the oracle too (bounds / cache left in order)."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 256, 30011, 20, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=9, noise=0.3)
+    X = X[:, np.random.default_rng(4).permutation(n)]
+    rng = np.random.default_rng(6)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    s = synth.small_p_of(gopt, p)
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    gam = s / p
+    jc, ir, x = parts(Y)
+    base = oracle.mix(centres, d, p) * gam
+    sc = np.abs(base).max()
+    far = base[:, np.roll(np.arange(K), 3)]                            # every centroid takes another one's place
+    seq = [base,
+           far if second_call == "far" else base + 1e-3 * sc * rng.standard_normal((p, K)),
+           (far if second_call == "far" else base) + 2e-3 * sc * rng.standard_normal((p, K)),
+           (far if second_call == "far" else base) + 3e-3 * sc * rng.standard_normal((p, K))]
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    outs = {}
+    for nodual in (False, True):
+        set_switch(monkeypatch, gpu_ctx, "SPKM_NO_DUAL", nodual)
+        shard.reset_policy()
+        shard.set_lazy_stats(True)
+        eng = LloydEngine(shard, K, gam)
+        forms, reds = [], []
+        for it, Cm in enumerate(seq):
+            c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+            eng.assign_accumulate_step(c, want_mind=False)             # (no host sync in between: the count cannot be back for call 2)
+            if it >= 1:
+                torch.cuda.synchronize()
+            forms.append(eng.last_screen_mode()[6])
+            ra, rd = oracle.assign(p, n, jc, ir, x, Cm, gam)
+            assert np.array_equal(eng.assign.cpu().numpy(), ra), (nodual, it)
+            S, Cnt, nk = oracle.accumulate(p, n, K, jc, ir, x, ra)
+            red = eng.reduce.cpu().numpy()
+            pk = p * K
+            assert np.array_equal(red[pk:2 * pk].reshape(K, p).T, Cnt), (nodual, it)
+            assert np.array_equal(red[2 * pk:2 * pk + K], nk.astype(float)) and np.array_equal(eng.nk.cpu().numpy(), nk)
+            assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-10 * np.abs(S).max(), (nodual, it)
+            reds.append(red)
+        outs[nodual] = (forms, reds)
+        assert forms[0] == 3, forms                                    # a run's first call: the full pass, sums only
+        assert forms[1] == (2 if nodual else expect), (nodual, forms)
+    shard.set_lazy_stats(False)
+
+
 @pytest.mark.parametrize("shuffled", [False, True])
 def test_carried_bounds_stay_bounds_through_every_kind_of_lazy_call(gpu_ctx, oracle, monkeypatch, shuffled):
     """The bounds a shard carries between screen calls must BE bounds after every call, whatever form the call took:
@@ -784,13 +839,16 @@ def test_one_pass_for_few_centroids(gpu_ctx, oracle, monkeypatch, p, s, n, K):
     assert all(f != 1 for f in seen[False]), seen                  # ... and by default no call does
 
 
-def test_a_fresh_contexts_second_lazy_call_is_already_incremental(oracle):
+def test_a_fresh_contexts_second_lazy_call_is_already_incremental(oracle, monkeypatch):
     """A context's first fused call allocates most of its buffers AFTER queueing its counting sort; those first-time
     allocations must not make the library forget the sort (and with it the previous assignment and cluster sizes): the
     second call of a run is then an incremental one, on buffers the first call sized for it.  Outputs are the oracle's."""
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard, torch_context
 
     ctx = torch_context(0)                                          # its own context: no buffer exists yet
+    # (SPKM_NO_DUAL: the second call takes the events whatever moves -- with the form chosen on the device, random centres
+    #  on random data would open the full pass, which is also what a library that HAD forgotten the sort would run)
+    set_switch(monkeypatch, ctx, "SPKM_NO_DUAL")
     p, n, K, s = 256, 30000, 24, 26
     X = random_csc(p, n, s, seed=123)
     gam = s / p

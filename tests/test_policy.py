@@ -27,6 +27,9 @@ def pol(tmp_path_factory):
     L.pol_launched.argtypes = [C.c_void_p] + [C.c_int] * 6
     L.pol_pt_next.argtypes = [C.c_void_p]
     L.pol_few_movers.argtypes = [C.c_void_p, C.c_double]
+    L.pol_form_on_device.argtypes = [C.c_void_p]
+    L.pol_event_cap.argtypes = [C.c_uint64]
+    L.pol_event_cap.restype = C.c_uint64
     return L
 
 
@@ -159,3 +162,28 @@ def test_incremental_sums_while_at_most_a_third_of_the_points_move(pol):
     assert pol.pol_few_movers(w.p, N) == 1
     pol.pol_reset(w.p)
     assert pol.pol_few_movers(w.p, N) == 1
+
+
+def test_a_call_without_a_mover_count_lets_the_device_choose_the_form(pol):
+    """Table for the accumulation form of a lazy call (api.hip `dual`, screen.hip k_pick_form): while no mover count has
+    come back -- a run's second call, or any call whose predecessor's counters are still in flight -- both forms are
+    queued and the device opens the events iff there are at most event_cap(n) of them (two per mover: a third of the
+    points, the same bar few_movers applies to a known count); once a count is known the host decides alone."""
+    w = Walk(pol)
+    assert pol.pol_form_on_device(w.p) == 1                  # nothing known: the device decides
+    w.call(); w.seen()                                       # first call: cannot count movers
+    assert pol.pol_form_on_device(w.p) == 1                  # the run's second call is issued like this
+    w.call()                                                 # ... its counters are not back yet:
+    assert pol.pol_form_on_device(w.p) == 1                  # a third call issued now still lets the device decide
+    w.seen(movers=0.9 * N)                                   # (from a random start nearly every point moves)
+    assert pol.pol_form_on_device(w.p) == 0 and pol.pol_few_movers(w.p, N) == 0   # known and many: the full pass, host-side
+    w.call(); w.seen(movers=0.1 * N)
+    assert pol.pol_form_on_device(w.p) == 0 and pol.pol_few_movers(w.p, N) == 1   # known and few: the events, host-side
+    pol.pol_reset(w.p)
+    assert pol.pol_form_on_device(w.p) == 1                  # a new replicate starts over
+    # the device's bar: events <= 2 * floor(n / 3)  <=>  movers <= n / 3 (every mover with a valid old cluster is 2 events)
+    for n in (0, 1, 2, 3, 4, 100, 10**8, 125_000_000, 2**31):
+        cap = pol.pol_event_cap(n)
+        assert cap == 2 * (n // 3) and cap <= 2 * n
+        movers_ok, movers_too_many = n // 3, n // 3 + 1
+        assert 2 * movers_ok <= cap < 2 * movers_too_many
