@@ -375,6 +375,94 @@ __device__ __forceinline__ void quad_round<{nv}, {pl}>(int xi, int ro, int off0,
 """
 
 
+def own_round_block(nv: int, pl: int) -> str:
+    """f32 SCREEN round of the OWN-REGISTER form of the 4-lanes-per-point kernel (screen_quad.hip, k_screen_own): every
+    lane of a quad holds ALL entries of its point -- values as aligned pairs (x0, x1), (x2, x3), row offsets o_m =
+    row * 128 | swizzle * 16 -- so nothing is broadcast: per entry two plain address ops instead of a DPP xor, an add
+    and a DPP move (4 issue cycles instead of 10 next to the 32 of the packed arithmetic):
+        a_m = o_m ^ off0 ; b_m = o_m ^ off1            v_xor_b32 x2           (pl >= 4; off1 = off0 ^ 64)
+        T   = LDS[a_m], LDS[b_m]                       ds_read_b128 x2
+        T  += (x_m, x_m)                               v_pk_add_f32, x_m picked out of its pair by op_sel
+        acc_j = T_j * T_j + acc_j                      v_pk_fma_f32
+    pl = 5: the lane's extra centroid for entries m, m + 1 is handled as ONE packed pair -- (c_m, c_m+1) + (x_m, x_m+1),
+    squared into a two-sum accumulator -- so the remainder costs one packed add + fma per two entries.
+    Temporaries and read results in literal registers v[QX:QT+39] (declared as clobbers)."""
+    L = []
+    two = pl >= 4
+    for m in range(nv):
+        T = QT + 8 * m
+        A, B = QX + 2 * m, QX + 2 * m + 1
+        L.append(f"v_xor_b32 v{A}, %[o{m}], %[off0]")
+        if two:
+            L.append(f"v_xor_b32 v{B}, %[o{m}], %[off1]")
+            L.append(f"ds_read_b128 v[{T}:{T+3}], v{A}")
+            L.append(f"ds_read_b128 v[{T+4}:{T+7}], v{B}")
+        elif pl == 2:
+            L.append(f"ds_read_b128 v[{T}:{T+3}], v{A}")
+        else:
+            L.append(f"ds_read_b64 v[{T}:{T+1}], v{A}")
+    ne = 0
+    if pl == 5:
+        ne = (nv + 1) // 2 * 2  # entries of the extra centroid, in pairs (a slot past the column: x = 0 on the zero row)
+        for m in range(ne):
+            E = QT + 36 + m
+            L.append(f"v_bfe_u32 v{E}, %[o{m}], 7, 16")
+            L.append(f"v_lshl_add_u32 v{E}, v{E}, 4, %[ce]")
+            L.append(f"ds_read_b32 v{QT + 32 + m}, v{E}")
+    per = 2 if two else 1
+    nreads = per * nv + ne
+    done = 0
+    for m in range(nv):
+        xp = "%[xp01]" if m < 2 else "%[xp23]"
+        sel = "op_sel_hi:[1,0]" if m % 2 == 0 else "op_sel:[0,1] op_sel_hi:[1,1]"
+        for h in range(2 if two else 1):
+            T = QT + 8 * m + 4 * h
+            done += 1
+            L.append(f"s_waitcnt lgkmcnt({nreads - done})")
+            L.append(f"v_pk_add_f32 v[{T}:{T+1}], v[{T}:{T+1}], {xp} {sel}")
+            if pl >= 2:
+                L.append(f"v_pk_add_f32 v[{T+2}:{T+3}], v[{T+2}:{T+3}], {xp} {sel}")
+            L.append(f"v_pk_fma_f32 %[acc{2*h}], v[{T}:{T+1}], v[{T}:{T+1}], %[acc{2*h}]")
+            if pl >= 2:
+                L.append(f"v_pk_fma_f32 %[acc{2*h+1}], v[{T+2}:{T+3}], v[{T+2}:{T+3}], %[acc{2*h+1}]")
+    if pl == 5:
+        L.append("s_waitcnt lgkmcnt(0)")
+        for m in range(0, ne, 2):
+            E = QT + 32 + m
+            xp = "%[xp01]" if m < 2 else "%[xp23]"
+            L.append(f"v_pk_add_f32 v[{E}:{E+1}], v[{E}:{E+1}], {xp}")
+            L.append(f"v_pk_fma_f32 %[acc4], v[{E}:{E+1}], v[{E}:{E+1}], %[acc4]")
+    return "\\n\\t".join(L)
+
+
+def own_round_func(nv: int, pl: int) -> str:
+    nacc = pl if pl < 4 else 4
+    outs = [f'[acc{j}] "+v"(acc{j})' for j in range(nacc)]
+    if pl == 5:
+        outs.append('[acc4] "+v"(acc4)')
+    nused = nv if pl != 5 else (nv + 1) // 2 * 2
+    ins = ['[xp01] "v"(xp01)']
+    if nused > 2:
+        ins.append('[xp23] "v"(xp23)')
+    ins += [f'[o{m}] "v"(o{m})' for m in range(nused)]
+    ins.append('[off0] "v"(off0)')
+    if pl >= 4:
+        ins.append('[off1] "v"(off1)')
+    if pl == 5:
+        ins.append('[ce] "v"(ce)')
+    clob = ", ".join(f'"v{r}"' for r in range(QX, QT + 40))
+    return f"""template <>
+__device__ __forceinline__ void quad_round_own<{nv}, {pl}>(double xp01, double xp23, int o0, int o1, int o2, int o3,
+    int off0, int off1, int ce, double& acc0, double& acc1, double& acc2, double& acc3, double& acc4)
+{{
+    asm volatile("{own_round_block(nv, pl)}"
+                 : {", ".join(outs)}
+                 : {", ".join(ins)}
+                 : {clob});
+}}
+"""
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     out = ["// GENERATED by gen_assign_steps.py -- do not edit.\n",
@@ -410,6 +498,12 @@ def main():
            "int delta, int ce,\n    double& acc0, double& acc1, double& acc2, double& acc3, float& acc4);\n\n"]
     for pl in (1, 2, 4, 5):
         out += [quad_round_func(nv, pl) for nv in range(1, 5)]
+    out.append("// rounds of the own-register form (see gen_assign_steps.py, own_round_block)\n"
+               "template <int NV, int PL>\n__device__ __forceinline__ void quad_round_own(double xp01, double xp23, int o0, "
+               "int o1, int o2, int o3,\n    int off0, int off1, int ce, double& acc0, double& acc1, double& acc2, "
+               "double& acc3, double& acc4);\n\n")
+    for pl in (1, 2, 4, 5):
+        out += [own_round_func(nv, pl) for nv in range(1, 5)]
     with open(os.path.join(here, "quad_steps.inc"), "w") as f:
         f.write("".join(out))
 
