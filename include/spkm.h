@@ -236,9 +236,9 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * spkm_assign_accumulate_dev); info[5] = running total of skipped steps over all calls on this context;
  * info[6] = how the call got its per-cluster sums: 0 = the full accumulation pass with every point's distance, 3 = the
  * full pass WITHOUT distances (lazy statistics, spkm_shard_set_lazy_stats: a run's first call, or too many movers for
- * events; SPKM_NO_SUMS_ONLY=1: A/B switch), 2 = incrementally, by the points that changed cluster (events), 1 = the
- * ONE-PASS form (few centroids: the f32 screen, its certificate and the accumulation fused over one read of the points'
- * records -- csrc/onepass.hip; opt-in, SPKM_ONEPASS=1: it measured slower than the two kernels it replaces);
+ * events; SPKM_NO_SUMS_ONLY=1: A/B switch), 2 = incrementally, by the points that changed cluster (events) -- for a call
+ * that queued both forms and let the device choose (a run's second lazy call: no mover count is back yet; SPKM_NO_DUAL=1:
+ * A/B switch) the value says which one the device opened;
  * info[7] = 2 if the
  * bounds were applied point by point (the list then names points; info[4] still counts the steps whose 16 points all
  * passed): the library switches to that form when the previous call's test passed >= 60 % of the points and whole

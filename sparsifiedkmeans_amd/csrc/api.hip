@@ -5,7 +5,6 @@
 #include "sparse_ops.hip"
 #include "update.hip"
 #include "screen.hip"
-#include "onepass.hip"
 #include "sample.hip"
 #include "dense.hip"
 
@@ -62,7 +61,6 @@ struct spkm_switches {
     bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
     bool no_sums_only = false;    // SPKM_NO_SUMS_ONLY: a lazy call's full pass still evaluates every point's distance
-    bool onepass = false;         // SPKM_ONEPASS: few centroids (K <= 16) take the fused one-pass form (onepass.hip) -- off by default: measured slower
     bool no_dual = false;         // SPKM_NO_DUAL: a run's second lazy call takes the events whatever moves (round 3) instead of deciding on the device
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
@@ -86,7 +84,6 @@ static spkm_switches read_switches()
     w.no_incremental = on("SPKM_NO_INCREMENTAL");
     w.no_support_drift = on("SPKM_NO_SUPPORT_DRIFT");
     w.no_teams = on("SPKM_NO_TEAMS");
-    w.onepass = on("SPKM_ONEPASS");
     w.no_sums_only = on("SPKM_NO_SUMS_ONLY");
     w.no_dual = on("SPKM_NO_DUAL");
     return w;
@@ -126,7 +123,6 @@ struct spkm_ctx {
     bool sort_perm_valid = false;    // ... and perm / offs / items really hold that call's counting sort (not after an incremental call)
     bool last_lib_valid = false;     // the last screen call could compare with the library's previous assignment (movers counted)
     bool last_incremental = false;   // the last screen call updated the sums by events (no exact pass)
-    bool last_onepass = false;       // the last screen call was a one-pass call (onepass.hip)
     bool last_sums_only = false;     // the last screen call's full pass left the distances out (lazy statistics)
     bool last_dual = false;          // the last screen call queued both forms; the device chose (counters[19]: the full pass)
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
@@ -1300,8 +1296,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     int bstat_n = 0; // workgroups of k_bounds_steps whose statistics wait in ctx->bstat
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
     bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false, ev_possible = false;
-    int op_nq = 0;       // > 0: this call is a one-pass call (onepass.hip) with tile rows of 4 op_nq floats
-    size_t op_lds = 0; // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
+    // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
             if (sm->hb) (void)hipFree(sm->hb);
@@ -1365,25 +1360,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             if ((rc = ensure(ctx, ctx->nk_ev, (size_t)2 * K * 8))) return rc;
             zero_later(ctx->nk_ev.p, (size_t)2 * K * 8);
         }
-        // One pass for few centroids (onepass.hip; SPKM_ONEPASS=1, OFF by default): a lazy call that would run the full
-        // accumulation pass -- a run's first call, or too many movers for the events -- reads each point's record once:
-        // screen, certificate and accumulation fused.  Needs the sums of all K clusters (f64) + 16-bit counts + the f32 tile
-        // in LDS.  Measured on config 5 (1.25e8 points, K = 10): 28.4 ms against 9.2 + 14.8 for the two kernels.
-        if (sm->lazy && d_mind == nullptr && !ev_path && ctx->sw.onepass && K >= 2 && K <= 16 && s->fixed_s <= 64 &&
-            sm->cl_cache != nullptr) {
-            const int nq = (K + 3) / 4;
-            const size_t lds = (size_t)(p + 1) * nq * 16 + (size_t)K * p * 8 + (size_t)((K * p + 1) / 2) * 4 + (size_t)K * 4 + 64;
-            if (lds <= ctx->lds_max) {
-                if ((rc = build_records<IR>(ctx, sm))) return rc;
-                if (sm->rec) { op_nq = nq; op_lds = lds; }
-            }
-        }
-        if (op_nq > 0) { // its accumulators: the shard's cache of LOCAL sums and counts (what the call returns), the cluster sizes
-            zero_later(sm->cl_cache, 2 * pk * 8);
-            zero_later(ctx->nk.p, (size_t)K * 8);
-        }
         // hinted two-phase form: needs the carried bounds (the hints are ub + drift) and a split that saves rounds
-        hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds && op_nq == 0;
+        hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds;
         if (hinted) {
             const bool late = sm->pol.take_hinted_split(q_rounds, ctx->sw.no_late_split);
             prune_a = late ? quad_split_late(q_rounds) : quad_split(q_rounds);
@@ -1395,7 +1373,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                 sm->hintu_len = npad;
             }
         }
-        const bool skip_enabled = bounds_ok && !ctx->sw.no_bounds && op_nq == 0; // (a one-pass call rewrites every bound)
+        const bool skip_enabled = bounds_ok && !ctx->sw.no_bounds;
         // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 60 % of the points
         // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
         pt_mode = skip_enabled && sm->pol.pt_next && !ctx->sw.no_point_list;
@@ -1437,86 +1415,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        0, ctx->stream, d_centers, p, K, G, gamma, (float*)ctx->t32.p,
                        (unsigned long long*)ctx->cmax.p, pl_last, quad ? 1 : 0, (double*)ctx->ct.p,
                        quad ? sm->hb_centers : (double*)nullptr);
-    if (op_nq > 0) {
-        // ---- one-pass call (onepass.hip): records -> f32 screen + certificate + per-cluster sums, one read of the data ----
-        const int nwg = std::max(1, ctx->num_cus);
-        const long long per = 65520; // a workgroup's 16-bit counts: fewer than 65 536 points between two flushes
-        const long long m = std::max<long long>(1, (n + nwg * per - 1) / (nwg * per));
-        long long chunk1 = (n + nwg * m - 1) / (nwg * m);
-        chunk1 = std::min<long long>(per, std::max<long long>(4096, (chunk1 + 15) / 16 * 16));
-        const int grid1 = (int)std::min<long long>(nwg, (n + chunk1 - 1) / chunk1);
-        const void* kern = nullptr;
-        // (13 rounds -- s = 49..52, the headline's 51 -- compiled in; any other column length: the round count is read)
-        const bool r13 = q_rounds == 13;
-        switch (op_nq) {
-        case 1: kern = r13 ? (const void*)k_onepass<IR, 1, 13> : (const void*)k_onepass<IR, 1, 0>; break;
-        case 2: kern = r13 ? (const void*)k_onepass<IR, 2, 13> : (const void*)k_onepass<IR, 2, 0>; break;
-        case 3: kern = r13 ? (const void*)k_onepass<IR, 3, 13> : (const void*)k_onepass<IR, 3, 0>; break;
-        default: kern = r13 ? (const void*)k_onepass<IR, 4, 13> : (const void*)k_onepass<IR, 4, 0>; break;
-        }
-        HIP_TRY(allow_lds(ctx, kern, op_lds));
-        double* cache_s = sm->cl_cache;
-        double* cache_c = cache_s + pk;
-        {
-            const char* a_rec = sm->rec;
-            int a_R = sm->rec_R, a_p = p, a_s = s->fixed_s, a_K = K, a_lv = bounds_ok ? 1 : 0, a_chunk = (int)chunk1;
-            long long a_n = n, a_npad = npad;
-            const double* a_cs = (const double*)ctx->ct.p;
-            const double *a_x1 = (const double*)s->xn1, *a_x2 = (const double*)s->xn2;
-            const unsigned long long* a_cm = (const unsigned long long*)ctx->cmax.p;
-            int* a_as = (int*)d_assign;
-            float* a_b = sm->hb;
-            const double* a_cum = (const double*)(sm->hb_cum + sm->cum_par);
-            int* a_list = (int*)ctx->list.p;
-            unsigned* a_nl = (unsigned*)ctx->nlist.p;
-            unsigned long long* a_nk = (unsigned long long*)ctx->nk.p;
-            void* args[] = {&a_rec, &a_R, &a_p, &a_n, &a_s, &a_K, &a_cs, &a_x1, &a_x2, &a_cm, &a_as, &a_b, &a_npad, &a_cum,
-                            &a_lv, &a_list, &a_nl, &cache_s, &cache_c, &a_nk, &a_chunk};
-            HIP_TRY(timing_begin(ctx));
-            HIP_TRY(hipLaunchKernel(kern, dim3(grid1), dim3(1024), args, op_lds, ctx->stream));
-            HIP_TRY(timing_end(ctx));
-        }
-        if (ctx->tlog_both) HIP_TRY(timing_begin(ctx)); // (the log's second slot of a fused call: the listed points)
-        hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
-                           (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
-                           s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
-                           (int*)(sm->hb + 2 * npad), bounds_ok ? 1 : 0, (unsigned*)ctx->nlist.p + 5, (int*)nullptr,
-                           (unsigned long long*)nullptr, sm->hb, (int*)nullptr, (int*)nullptr, (unsigned*)ctx->nlist.p,
-                           s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
-                           (unsigned long long*)nullptr, 0xffffffffu);
-        hipLaunchKernelGGL((k_onepass_listed<IR>), dim3(std::max(1, ctx->num_cus)), dim3(256), 0, ctx->stream,
-                           (const char*)sm->rec, sm->rec_R, p, n, s->fixed_s, (const int*)ctx->list.p, (unsigned*)ctx->nlist.p,
-                           (const int*)d_assign, cache_s, cache_c, (unsigned long long*)ctx->nk.p);
-        if (ctx->tlog_both) HIP_TRY(timing_end(ctx));
-        // the call's sums and counts ARE the cache (k_call_tail copies them out); no objective, no largest distance
-        hipLaunchKernelGGL(k_call_tail, dim3((unsigned)std::max<size_t>((K + 255) / 256, std::min<size_t>((pk + 255) / 256, 1024))), dim3(256),
-                           0, ctx->stream, (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
-                           (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, 0, (unsigned*)ctx->nlist.p, 1,
-                           cache_s, (const double*)cache_c, pk, sums, counts);
-        HIP_TRY(hipGetLastError());
-        sm->hb_K = K;
-        sm->hb_gamma = gamma;
-        sm->hb_valid = true;
-        sm->cl_valid = true;        // the cache holds this call's local sums and counts
-        sm->cl_stats_valid = false; // ... but no per-cluster objective / largest distance
-        ctx->sort_owner = sm;       // (the cluster sizes in ctx->nk are this shard's; there is no sort)
-        ctx->sort_K = K;
-        ctx->sort_n = n;
-        ctx->sort_perm_valid = false;
-        ctx->sort_partial = false;
-        ctx->last_rounds_all = ctx->last_rounds = q_rounds;
-        ctx->last_hinted = false;
-        ctx->last_skipping = false;
-        ctx->last_pt_mode = false;
-        ctx->last_lib_valid = bounds_ok;
-        ctx->last_incremental = false;
-        ctx->last_onepass = true;
-        ctx->last_sums_only = false;
-        ctx->last_dual = false;
-        ctx->last_path = 1;
-        return SPKM_OK;
-    }
-    ctx->last_onepass = false;
     ctx->last_sums_only = false;
     // 1. screen
     const int sweep = 16 * 16;
@@ -2100,9 +1998,9 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         info[0] = ctx->last_mode;
         for (int j = 0; j < 4; j++) info[1 + j] = v[j];
         info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
-        // how the call got its sums: 0 full pass with every distance, 1 one-pass form (onepass.hip), 2 incremental (events),
+        // how the call got its sums: 0 full pass with every distance, 2 incremental (events),
         // 3 full pass without distances (sums only)
-        info[6] = ctx->last_onepass ? 1 : (ctx->last_incremental ? 2 : (ctx->last_sums_only ? 3 : 0));
+        info[6] = ctx->last_incremental ? 2 : (ctx->last_sums_only ? 3 : 0);
         if (ctx->last_dual) { // both forms were queued: which one the device opened (k_pick_form)
             unsigned f[2] = {0, 0};
             HIP_TRY(hipMemcpy(f, (const unsigned*)ctx->nlist.p + 18, 8, hipMemcpyDeviceToHost));

@@ -788,57 +788,6 @@ def test_carried_bounds_stay_bounds_through_every_kind_of_lazy_call(gpu_ctx, ora
     assert 2 in forms and 3 in forms[1:], forms                        # events, and a sums-only pass on valid bounds, both ran
 
 
-@pytest.mark.parametrize("p,s,n,K", [(1024, 51, 20000, 10), (1024, 51, 5003, 2), (256, 26, 30011, 16), (512, 26, 70000, 7),
-                                     (64, 5, 4099, 3), (1024, 49, 9000, 9)])
-def test_one_pass_for_few_centroids(gpu_ctx, oracle, monkeypatch, p, s, n, K):
-    """csrc/onepass.hip: a lazy call that would run the full accumulation pass, K <= 16 and the sums of all clusters
-    fitting LDS, reads the records once -- screen, certificate, accumulation fused.  Every call: assignment and cluster
-    sizes the oracle's bit for bit (an exact tie between two centroids sends points through the exact list), counts
-    exact, sums the members' sums to rounding; the bounds it leaves behind carry the later calls to the oracle's answers
-    too.  The form is opt-in (SPKM_ONEPASS=1: it measured slower than the two kernels it replaces); without the switch the
-    same outputs come from the two-kernel form."""
-    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
-
-    X = random_csc(p, n, s, seed=1000 + K)
-    gam = s / p
-    rng = np.random.default_rng(K)
-    C0 = rng.standard_normal((p, K)) * 0.3
-    if K >= 3:
-        C0[:, K - 1] = C0[:, 1]                                    # an exact tie: nothing certifies between these two
-    shard = Shard.from_scipy(gpu_ctx, X)
-    seen = {}
-    for onepass in (True, False):
-        set_switch(monkeypatch, gpu_ctx, "SPKM_ONEPASS", onepass)
-        shard.reset_policy()
-        shard.set_lazy_stats(True)
-        eng = LloydEngine(shard, K, gam)
-        c = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
-        forms = []
-        for it in range(5):
-            used = c.cpu().numpy().T.copy()
-            out = eng.iterate(c, want_mind=False).cpu().numpy()
-            forms.append(eng.last_screen_mode()[6])
-            ra, rd = oracle.assign(p, n, *parts(X), used, gam)
-            assert np.array_equal(eng.assign.cpu().numpy(), ra), f"iteration {it}"
-            S, Cnt, nk = oracle.accumulate(p, n, K, *parts(X), ra)
-            red = eng.reduce.cpu().numpy()
-            pk = p * K
-            assert np.array_equal(red[pk:2 * pk].reshape(K, p).T, Cnt), f"iteration {it}"
-            assert np.array_equal(red[2 * pk:2 * pk + K], nk.astype(float))
-            assert np.array_equal(eng.nk.cpu().numpy(), nk)
-            assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-10 * max(np.abs(S).max(), 1e-300), f"iteration {it}"
-            want = oracle.finalize_centers(S, Cnt, nk, gam, used)
-            assert np.abs(c.cpu().numpy().T - want).max() <= 1e-9 * np.abs(want).max()
-            if forms[-1] == 1:
-                assert np.isnan(out[1])                            # no objective from a one-pass call
-        seen[onepass] = forms
-        eng.distances(torch.tensor(np.ascontiguousarray(used.T), device="cuda"))
-        assert np.array_equal(eng.mind.cpu().numpy(), rd)
-    shard.set_lazy_stats(False)
-    assert seen[True][0] == 1, seen                                # switched on, a run's first call takes the fused form ...
-    assert all(f != 1 for f in seen[False]), seen                  # ... and by default no call does
-
-
 def test_a_fresh_contexts_second_lazy_call_is_already_incremental(oracle, monkeypatch):
     """A context's first fused call allocates most of its buffers AFTER queueing its counting sort; those first-time
     allocations must not make the library forget the sort (and with it the previous assignment and cluster sizes): the
