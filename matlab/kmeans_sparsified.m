@@ -129,7 +129,10 @@ if o.Sparsify
         if ~isreal(X), error('Code and distance computations require real data'); end
         small_p = max(1, round(gam * p2));
         gam = small_p / p;                                                      % REF:329 (divides by p, not p2)
-        onDevice = haveEngine && o.MLcorrection && ischar(sk) && strcmpi(sk, 'Hadamard') && ~issparse(X) && p2 <= 65536;
+        % (Start = 'uniform' draws between min(X(:)) and max(X(:)) of the SPARSIFIED data (REF:372-374): that needs the sparse
+        %  matrix on the host, so such a run keeps the host route -- as the reference runs it)
+        uniformStart = ischar(o.Start) && strcmpi(o.Start, 'uniform');
+        onDevice = haveEngine && o.MLcorrection && ischar(sk) && strcmpi(sk, 'Hadamard') && ~issparse(X) && p2 <= 65536 && ~uniformStart;
         if onDevice
             % REF:292 (X*(1+2*eps)), :295 (mix), :334 (randsample_fixedNumberEntries) as one fused device pass; the
             % sampled rows come from a counter-based generator keyed by (seed, column) -- any exact without-replacement
@@ -160,7 +163,6 @@ end
 lazyObj = ~show('iter');       % obj is displayed per iteration only under Display = 'iter' (REF:472-475)
 
 if ischar(o.Start) && strcmpi(o.Start, 'uniform')
-    if onDevice, error('kmeans_sparsified:uniformOnDevice', 'Start = uniform needs the sparse data on the host (min / max of X)'); end
     mn = full(min(X(:)));  mx = full(max(X(:)));
 end
 if o.Sparsify && o.unbiasedDistance

@@ -1341,7 +1341,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // (what an incremental call needs is allocated by the first lazy call, whatever path that one takes: a run's
         //  first call is the one that builds things; 3 x 8 B per point here, and the sort buffers at their event sizes below)
         ev_possible = sm->lazy && !ctx->sw.no_incremental && !ctx->sw.no_sort_reuse && (size_t)p * 12 <= 64 * 1024;
-        ev_path = ev_possible && d_mind == nullptr && kept && sm->cl_valid && sm->pol.few_movers((double)n);
+        ev_path = ev_possible && d_mind == nullptr && kept && sm->cl_valid && sm->pol.few_movers((double)n) &&
+                  !sm->pol.refresh_due((double)n);
         if (ev_possible && sm->ev_cap < (size_t)2 * n) {
             if (sm->ev_pt) (void)hipFree(sm->ev_pt);
             if (sm->ev_k) (void)hipFree(sm->ev_k);
@@ -1550,6 +1551,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     ctx->last_lib_valid = bounds_ok;
     ctx->last_incremental = ev_path;
+    if (ev_path) sm->pol.sums_by_events(); else sm->pol.sums_by_full_pass();
     if (ev_path) {
         // ---- incremental call: the per-cluster sums move by the points that changed cluster; no exact pass ----
         // events (point, key) are sorted by key over 2 K keys (K + k: leaves cluster k; k: enters it) with the same

@@ -55,6 +55,12 @@ struct spkm_policy {
     bool pt_next = false;           // the next bounds test lists POINTS, not 16-point steps
     bool movers_known = false;      // last_movers is a count (not before a run's second screen call has been read back)
     unsigned long long last_movers = 0;
+    // incremental sums are a running add / subtract: their rounding error is relative to everything a table entry has
+    // ever held, so a full pass starts them afresh once the points that moved since the last one add up to the whole shard
+    // (or after 256 incremental calls)
+    bool ev_pending = false;        // the call whose counters are pending updated the sums by events
+    int ev_calls = 0;               // incremental calls since the last full accumulation pass
+    unsigned long long ev_cum_movers = 0; // movers counted over those calls
 
     // a new start / new replicate (spkm_shard_reset_policy): nothing learned carries over
     void reset()
@@ -67,6 +73,7 @@ struct spkm_policy {
     void observe(const spkm_policy_counters& c, double n, int tiles, int nr)
     {
         if (mov_pending_valid) { last_movers = (unsigned long long)c.movers; movers_known = true; }
+        if (ev_pending && mov_pending_valid) ev_cum_movers += (unsigned long long)c.movers;
         // more than 5 % of the points on the exact list: the screen pays K-fold exact work for each; 8 calls all-exact
         if (c.listed > 0.05 * n) exact_cooldown = 8;
         // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed (in
@@ -160,5 +167,10 @@ struct spkm_policy {
     // events are counted (screen.hip, k_pick_form) -- the events while there are at most event_cap(n) of them, two per
     // mover, i.e. the same third of the points as above; the full sums-only pass otherwise.
     bool form_on_device() const { return !movers_known; }
+    // A fused call has chosen how it gets its sums: by events (or both forms queued: counted as events) / by a full pass.
+    void sums_by_events() { ev_pending = true; ev_calls++; }
+    void sums_by_full_pass() { ev_pending = false; ev_calls = 0; ev_cum_movers = 0; }
+    // the sums are due for a fresh summation (see ev_calls above)
+    bool refresh_due(double n) const { return ev_calls >= 256 || (double)ev_cum_movers > n; }
     static unsigned long long event_cap(unsigned long long n) { return 2ull * (n / 3ull); }
 };

@@ -253,7 +253,8 @@ class LloydEngine:
                                                 _p(centers), _p(self.out)), "spkm_finalize_dev")
 
     def assign_accumulate_step(self, centers: torch.Tensor, want_mind: bool = True):
-        """assign_step + accumulate_step in one call (same outputs bit for bit; lets the library take its
+        """assign_step + accumulate_step in one call (same assignments, counts and distances bit for bit, sums to the order of
+        summation -- with lazy statistics they are moved by the points that changed cluster; lets the library take its
         certified-screen fast path when the shard qualifies).  want_mind=False: the per-point distances of this call
         are not written (self.mind keeps whatever it held); ``distances(centers_used)`` produces them on demand."""
         assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)

@@ -404,7 +404,8 @@ def kmeans_sparsified(X, K, **options):
                 eng.accumulate_step()
             else:
                 # dense centres: the fused call -- the library's fast path (certified screen, carried bounds) when the
-                # shard qualifies, the exact kernels otherwise; same outputs bit for bit (findClusterAssignments.m:76-82)
+                # shard qualifies, the exact kernels otherwise; same assignments, counts and distances bit for bit, per-cluster sums to
+                # the order of summation (findClusterAssignments.m:76-82)
                 # (per-point distances are not stored per iteration -- a gigabyte of stores per 1e8 points -- but
                 #  produced once after the loop for the iteration that turned out to be the last: spkm_distances_dev)
                 old = centers.clone()

@@ -28,6 +28,9 @@ def pol(tmp_path_factory):
     L.pol_pt_next.argtypes = [C.c_void_p]
     L.pol_few_movers.argtypes = [C.c_void_p, C.c_double]
     L.pol_form_on_device.argtypes = [C.c_void_p]
+    L.pol_sums_by_events.argtypes = [C.c_void_p]
+    L.pol_sums_by_full_pass.argtypes = [C.c_void_p]
+    L.pol_refresh_due.argtypes = [C.c_void_p, C.c_double]
     L.pol_event_cap.argtypes = [C.c_uint64]
     L.pol_event_cap.restype = C.c_uint64
     return L
@@ -187,3 +190,23 @@ def test_a_call_without_a_mover_count_lets_the_device_choose_the_form(pol):
         assert cap == 2 * (n // 3) and cap <= 2 * n
         movers_ok, movers_too_many = n // 3, n // 3 + 1
         assert 2 * movers_ok <= cap < 2 * movers_too_many
+
+
+def test_incremental_sums_are_refreshed_by_a_full_pass(pol):
+    """Sums moved by events accumulate rounding relative to everything an entry ever held: once the movers counted since
+    the last full pass add up to the shard (or after 256 incremental calls) the next call runs the full pass again."""
+    w = Walk(pol)
+    w.call(); pol.pol_sums_by_full_pass(w.p); w.seen()
+    for _ in range(3):                                       # 0.3 N movers per incremental call: due after the fourth
+        assert pol.pol_refresh_due(w.p, N) == 0
+        w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=0.3 * N)
+    assert pol.pol_refresh_due(w.p, N) == 0                  # 0.9 N so far
+    w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=0.3 * N)
+    assert pol.pol_refresh_due(w.p, N) == 1                  # 1.2 N > N
+    w.call(); pol.pol_sums_by_full_pass(w.p); w.seen(movers=0.01 * N)
+    assert pol.pol_refresh_due(w.p, N) == 0                  # the full pass starts the count over (its own movers do not count)
+    for _ in range(255):
+        w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=1.0)
+    assert pol.pol_refresh_due(w.p, N) == 0
+    w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=1.0)
+    assert pol.pol_refresh_due(w.p, N) == 1                  # 256 incremental calls in a row
