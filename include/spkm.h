@@ -127,7 +127,11 @@ int spkm_shard_reset_policy(spkm_shard *s);
  * (few points moved in the previous call, its caches describe the previous call, ...).  A lazy call that has to run the
  * full pass -- a run's first call, one in which too many points move -- runs it WITHOUT the distances (sums and counts
  * only; the statistics are NaN there too); with d_mind != NULL a call evaluates everything, as always.
- * SPKM_NO_INCREMENTAL=1 switches the incremental calls off, SPKM_NO_SUMS_ONLY=1 the distance-free full pass. */
+ * SPKM_NO_INCREMENTAL=1 switches the incremental calls off, SPKM_NO_SUMS_ONLY=1 the distance-free full pass.
+ * While lazy statistics are on, d_assign is the library's to keep between calls: a host that passes the SAME buffer
+ * again must not have written to it -- blocks of 1024 points whose carried bounds settle them as a whole are then not
+ * visited at all, their part of d_assign included (SPKM_NO_BLOCK_SKIP=1: every point is looked at, as without lazy
+ * statistics).  A different buffer is noticed and filled completely. */
 int spkm_shard_set_lazy_stats(spkm_shard *s, int on);
 /* Halve the resident footprint of a fixed-stride shard (every column has the same number of entries, at most 64): build
  * now what the fused call would build on its first use -- the record layout (a point's values and row ids side by side)

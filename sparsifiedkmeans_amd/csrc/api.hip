@@ -61,6 +61,7 @@ struct spkm_switches {
     bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
     bool no_sums_only = false;    // SPKM_NO_SUMS_ONLY: a lazy call's full pass still evaluates every point's distance
+    bool no_block_skip = false;   // SPKM_NO_BLOCK_SKIP: the carried-bounds test reads every point (no per-block summaries)
     bool no_dual = false;         // SPKM_NO_DUAL: a run's second lazy call takes the events whatever moves (round 3) instead of deciding on the device
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
@@ -86,6 +87,7 @@ static spkm_switches read_switches()
     w.no_teams = on("SPKM_NO_TEAMS");
     w.no_sums_only = on("SPKM_NO_SUMS_ONLY");
     w.no_dual = on("SPKM_NO_DUAL");
+    w.no_block_skip = on("SPKM_NO_BLOCK_SKIP");
     return w;
 }
 
@@ -174,6 +176,12 @@ struct spkm_shard {
     bool hb_valid = false;
     // unchanged-cluster shortcut of the exact pass (screen.hip, k_cluster_need): per-cluster cache of the LOCAL sums and
     // counts (2 p K doubles), obj2 / max distance / its index (3 K), flags need | touched | same | ibeg | icnt (5 K ints)
+    // block summaries of the carried bounds (screen.hip, k_bounds_steps): per 1024 points the clusters present (K <= 128
+    // bits), the smallest slack between the bounds, a valid flag -- one allocation of 24 B per block
+    char* sp = nullptr;
+    long long sp_blocks = 0;
+    bool sp_clean = false;            // the last call that wrote bounds maintained the summaries
+    const void* sp_assign = nullptr;  // the caller's assignment buffer of that call (a skipped block's part of it is not touched)
     double* hb_cum = nullptr;  // [2]: drift accumulated since the lower bounds were stored (screen.hip, k_bounds_steps), by call parity
     int cum_par = 0;
     double* cl_cache = nullptr;
@@ -453,6 +461,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xfs) (void)hipFree(s->xfs);
     if (s->rec) (void)hipFree(s->rec);
     if (s->hb_cum) (void)hipFree(s->hb_cum);
+    if (s->sp) (void)hipFree(s->sp);
     if (s->cl_cache) (void)hipFree(s->cl_cache);
     if (s->cl_flags) (void)hipFree(s->cl_flags);
     if (s->irs) (void)hipFree(s->irs);
@@ -1296,6 +1305,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     int bstat_n = 0; // workgroups of k_bounds_steps whose statistics wait in ctx->bstat
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
     bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false, ev_possible = false;
+    bool sp_maintained = false; // this call's bounds test kept the block summaries
     // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
@@ -1398,15 +1408,36 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             const long long bgrid = 4LL * std::max(1, ctx->num_cus); // (8, 16, 32 per CU measured within noise of 4)
             if ((rc = ensure(ctx, ctx->bstat, (size_t)bgrid * 8))) return rc;
             while (span > 1024 && (npad + span - 1) / span < 4 * bgrid) span /= 2;
+            // block summaries: lazy calls only (the only writers of bounds are then this kernel, k_combine_screen and
+            // k_assign_list, the latter two for listed points); the lazy contract (spkm.h) lets a settled block's part of the
+            // caller's assignment buffer go unvisited as long as it is the buffer of the previous call
+            const bool erode = sm->lazy && d_mind == nullptr;
+            const bool sp_on = erode && skip_enabled && K <= 128 && sm->pol.blocks_next && !ctx->sw.no_block_skip;
+            const long long nblk = npad / 1024 + 1;
+            if (sp_on && sm->sp_blocks != nblk) {
+                if (sm->sp) (void)hipFree(sm->sp);
+                sm->sp = nullptr;
+                sm->sp_clean = false;
+                HIP_TRY(hipMalloc((void**)&sm->sp, (size_t)nblk * 24));
+                sm->sp_blocks = nblk;
+            }
+            unsigned* sp_mask = sp_on ? reinterpret_cast<unsigned*>(sm->sp) : nullptr;               // 16 B per block
+            float* sp_slack = sp_on ? reinterpret_cast<float*>(sm->sp + (size_t)nblk * 16) : nullptr;
+            int* sp_valid = sp_on ? reinterpret_cast<int*>(sm->sp + (size_t)nblk * 20) : nullptr;
+            const int sp_reset = (sp_on && sm->sp_clean && sm->sp_assign == (const void*)d_assign) ? 0 : 1;
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
                                pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1),
-                               (int)span, (unsigned*)ctx->bstat.p, (sm->lazy && d_mind == nullptr) ? 1 : 0);
+                               (int)span, (unsigned*)ctx->bstat.p, erode ? 1 : 0, sp_slack, sp_mask, sp_valid, sp_reset,
+                               (const int*)(sm->cl_flags + 2 * K));
+            sp_maintained = sp_on;
             bstat_n = (int)std::min<long long>((npad + span - 1) / span, bgrid);
             if (skip_enabled) sm->cum_par ^= 1; // the drift has been added
         }
         skipping = skip_enabled;
+        sm->sp_clean = sp_maintained; // (any call that writes bounds without them -- a distance pass, a first call -- starts them over)
+        sm->sp_assign = (const void*)d_assign;
         sm->hb_valid = false; // until this call has gone through
     } else
         sm->hb_valid = false;
@@ -1821,6 +1852,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     }
     ctx->last_path = 0;
     ctx->last_dual = false;
+    sm->sp_clean = false;
     sm->hb_valid = false; // the carried bounds describe the previous SCREEN call only
     if (!d_mind) { // the exact kernels produce the distances on their way to the argmin: park them in scratch
         if ((rc = ensure(ctx, ctx->mscr, (size_t)std::max<uint64_t>(s->n, 1) * 8))) return rc;

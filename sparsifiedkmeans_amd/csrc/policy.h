@@ -53,11 +53,13 @@ struct spkm_policy {
     int hint_cooldown = 0;          // calls to wait before the next hinted call
     int hint_fail_streak = 0;       // consecutive hinted calls that did not pay: the pause doubles (2, 4, 8, 16 calls)
     bool pt_next = false;           // the next bounds test lists POINTS, not 16-point steps
+    bool blocks_next = false;       // the next bounds test keeps block summaries (k_bounds_steps: settled blocks are not read)
     bool movers_known = false;      // last_movers is a count (not before a run's second screen call has been read back)
     unsigned long long last_movers = 0;
     // incremental sums are a running add / subtract: their rounding error is relative to everything a table entry has
     // ever held, so a full pass starts them afresh once the points that moved since the last one add up to the whole shard
-    // (or after 256 incremental calls)
+    // eight times over (or after 256 incremental calls; a headline run moves its points once over in its first six
+    // iterations -- a refresh there would cost a full pass, 8 ms at N = 1e8, for rounding noise of 1e-13)
     bool ev_pending = false;        // the call whose counters are pending updated the sums by events
     int ev_calls = 0;               // incremental calls since the last full accumulation pass
     unsigned long long ev_cum_movers = 0; // movers counted over those calls
@@ -86,6 +88,12 @@ struct spkm_policy {
         // at N = 1e8 where the list takes 5-19; a run to convergence there went from 57 to 63 it/s.)
         pt_next = skip_pending && c.kept >= 0.6 * n &&
                   (std::ceil(n / 16.0) - c.skipped) * 16.0 > (pt_next ? 2.5 : 4.0) * (n - c.kept);
+        // block summaries pay when whole 1024-point blocks are settled: nearly every point passes and the points of a
+        // cluster sit together (step lists: with data in arbitrary order every block holds every cluster, and one moving
+        // centroid keeps them all on the per-point path -- the summaries would only cost their upkeep)
+        // -- judged by how the failing points lie, not by the list form: the steps left on the screen are at least an eighth
+        // full of them (scattered failures, a few per cent of the points, leave a quarter of all steps)
+        blocks_next = skip_pending && c.kept >= 0.9 * n && (std::ceil(n / 16.0) - c.skipped) * 16.0 <= 8.0 * (n - c.kept);
         const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
         const int t = std::max(1, tiles);
         if (hint_pending) {
@@ -171,6 +179,6 @@ struct spkm_policy {
     void sums_by_events() { ev_pending = true; ev_calls++; }
     void sums_by_full_pass() { ev_pending = false; ev_calls = 0; ev_cum_movers = 0; }
     // the sums are due for a fresh summation (see ev_calls above)
-    bool refresh_due(double n) const { return ev_calls >= 256 || (double)ev_cum_movers > n; }
+    bool refresh_due(double n) const { return ev_calls >= 256 || (double)ev_cum_movers > 8.0 * n; }
     static unsigned long long event_cap(unsigned long long n) { return 2ull * (n / 3ull); }
 };

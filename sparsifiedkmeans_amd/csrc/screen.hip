@@ -549,6 +549,9 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
         const double d = (sqrt(sel2) * (1.0 + 1e-9) + 0x1p-50 * (sqrt(a2) + sqrt(b2))) / g * (1.0 + 1e-9);
         float f = __double2float_ru(d);
         if (!(f >= 0.f)) f = __builtin_inff(); // NaN centres: nothing is skipped
+        if (!s_diff) f = 0.f; // bitwise the same centroid: every distance to it is what it was (the rounding allowance above
+                              // is for a centroid that CHANGED; a settled cluster's members must not get their bounds bumped
+                              // -- and stored -- call after call)
         delta[k] = f;
         atomicMax(reinterpret_cast<unsigned*>(delta + K), __builtin_bit_cast(unsigned, f));
         if (hterm) {
@@ -579,8 +582,25 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                                                       float* __restrict__ hintu, int skip_enabled,
                                                       int pt_mode, const double* __restrict__ cum_in,
                                                       double* __restrict__ cum_out, int span,
-                                                      unsigned* __restrict__ blkstat, int erode)
+                                                      unsigned* __restrict__ blkstat, int erode,
+                                                      float* __restrict__ sp_slack = nullptr, unsigned* __restrict__ sp_mask = nullptr,
+                                                      int* __restrict__ sp_valid = nullptr, int sp_reset = 0,
+                                                      const int* __restrict__ same = nullptr)
 {
+    // BLOCK SUMMARIES (sp_slack != nullptr; lazy calls with K <= 128 only, api.hip): per 1024 consecutive points
+    //   sp_slack = min_i [ lb_i (1 - 1e-6) - ub_i (1 + 1e-6) ]   (lb as stored: relative to the accumulated drift `cum`)
+    //   sp_mask  = the clusters its points belong to (K bits)
+    //   sp_valid = every point passed the test of the call that wrote the summary
+    // A valid block none of whose clusters moved in this call (same[k], k_center_drift: centroid bitwise unchanged, so
+    // delta_a = 0 for every point) passes the per-point test for ALL its points iff cum_now (1 - 1e-6) < sp_slack -- one
+    // comparison instead of 16 KB of loads: nothing of the block is read, nothing written, its part of the caller's
+    // assignment buffer included (the lazy contract, spkm.h).  A settled run spends most of a call on this test (1.6 GB
+    // at N = 1e8); with the points of a cluster stored together nearly every block qualifies once most clusters have stopped.
+    // Any other block takes the per-point path below, which rewrites its summary.  sp_reset: every summary is rewritten
+    // (the bounds were last written by a call that did not maintain them, or the caller passed another buffer).
+    // (Measured and dropped: letting a block whose clusters moved a little pass too, against a per-block lag that its
+    //  points' upper bounds take later -- no block more was skipped in iterations 10-40 of the headline run, where nearly
+    //  every cluster still exchanges a few points per call and the slack of a block's worst point is small.)
     // erode != 0 (a call whose exact pass will not run: spkm_shard_set_lazy_stats, api.hip): a point that passes keeps
     // its centroid but gets no fresh upper bound from anybody, so the bound is moved by its centroid's drift here,
     // ub <- ub + delta_a rounded up (Hamerly's update).  A store only where the centroid moved at all: the members of
@@ -617,11 +637,38 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     // a workgroup takes several spans: its list is flushed per span (one global atomic, none for a span that lists
     // nothing), its statistics once at the end (at one span per workgroup the 3-4 same-address atomics of 24000
     // workgroups took longer than the test itself)
+    __shared__ float s_rmin[4];
+    __shared__ unsigned s_moved[4], s_bmask[4];
+    const bool sp_on = sp_slack != nullptr && skip_enabled;
+    if (sp_on) { // the clusters whose centroid moved in this call, as a K-bit mask
+        if (threadIdx.x < 4) { s_moved[threadIdx.x] = 0u; s_bmask[threadIdx.x] = 0u; }
+        __syncthreads();
+        if ((int)threadIdx.x < K && !same[threadIdx.x]) atomicOr(&s_moved[threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+        __syncthreads();
+    }
     for (long long span0 = (long long)blockIdx.x * span; span0 < npad; span0 += (long long)gridDim.x * span) {
     for (int it0 = 0; it0 < span / 256; it0 += UN) {
         if (span0 + it0 * 256 >= npad) break; // npad: whole waves
+        const long long blk0 = span0 + (long long)it0 * 256;
+        const long long bsp = blk0 >> 10;
+        if (sp_on && !sp_reset && sp_valid[bsp]) { // (the same words for every thread of the workgroup: a uniform branch)
+            const uint4 mk = *reinterpret_cast<const uint4*>(sp_mask + 4 * bsp);
+            const bool still = ((mk.x & s_moved[0]) | (mk.y & s_moved[1]) | (mk.z & s_moved[2]) | (mk.w & s_moved[3])) == 0u;
+            if (still && cum_now * 0.999999 < (double)sp_slack[bsp]) { // every point of the block passes
+#pragma unroll
+                for (int u = 0; u < UN; u++) {
+                    const long long live = n - (blk0 + u * 256 + (long long)(threadIdx.x & ~63)); // points of this wave's 64 that exist
+                    nkept += (unsigned)(live <= 0 ? 0 : (live >= 64 ? 64 : live));
+                    nskip += (unsigned)(live <= 0 ? 0 : (live >= 64 ? 4 : (live + 15) / 16));
+                }
+                continue;
+            }
+        }
         float ubv[UN], lbv[UN], dav[UN];
         int apv[UN], curv[UN];
+        bool blk_kept = true;          // sp_on: every point of the block passed
+        float tmin = __builtin_inff(); // ... and the smallest slack among them
+        unsigned bm0 = 0u, bm1 = 0u, bm2 = 0u, bm3 = 0u;
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const long long i = span0 + (it0 + u) * 256 + threadIdx.x;
@@ -650,7 +697,15 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const bool keep = !(i < n) || (double)(ubv[u] + dav[u]) * 1.000001 < ((double)lbv[u] - cum_now) * 0.999999; // false for NaN
             const unsigned long long b = __ballot(keep);
             nkept += (unsigned)__popcll(__ballot(keep && i < n));
-            if (erode && keep && i < n && dav[u] > 0.f) bnd[i] = __double2float_ru((double)ubv[u] + (double)dav[u]);
+            const float ubn = (erode && dav[u] > 0.f) ? __double2float_ru((double)ubv[u] + (double)dav[u]) : ubv[u]; // Hamerly's update
+            if (erode && keep && i < n && dav[u] > 0.f) bnd[i] = ubn;
+            if (sp_on && i < n) {
+                blk_kept = blk_kept && keep;
+                tmin = fminf(tmin, __double2float_rd((double)lbv[u] * 0.999999 - (double)ubn * 1.000001));
+                const unsigned bit = 1u << (apv[u] & 31);
+                const int w = apv[u] >> 5;
+                bm0 |= w == 0 ? bit : 0u; bm1 |= w == 1 ? bit : 0u; bm2 |= w == 2 ? bit : 0u; bm3 |= w == 3 ? bit : 0u;
+            }
             if (pt_mode) {
                 if (keep && i < n && curv[u] != apv[u]) assign[i] = apv[u]; // (see the step mode below)
                 if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
@@ -682,6 +737,28 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                 if (lead) s_todo[basepos + __popcll(lm & ((1ull << lane) - 1ull))] = (int)(i >> 4);
             }
             nskip += (unsigned)__popcll(__ballot((lane & 15) == 0 && live_step && skip));
+        }
+        if (sp_on) { // the block's new summary (every thread of the workgroup is here: the trip counts are uniform)
+            for (int off = 32; off > 0; off >>= 1) {
+                tmin = fminf(tmin, __shfl_xor(tmin, off));
+                bm0 |= __shfl_xor(bm0, off); bm1 |= __shfl_xor(bm1, off); bm2 |= __shfl_xor(bm2, off); bm3 |= __shfl_xor(bm3, off);
+            }
+            const int allk = __syncthreads_and(blk_kept ? 1 : 0);
+            if (lane == 0) {
+                s_rmin[threadIdx.x >> 6] = tmin;
+                if (bm0) atomicOr(&s_bmask[0], bm0);
+                if (bm1) atomicOr(&s_bmask[1], bm1);
+                if (bm2) atomicOr(&s_bmask[2], bm2);
+                if (bm3) atomicOr(&s_bmask[3], bm3);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                sp_slack[bsp] = fminf(fminf(s_rmin[0], s_rmin[1]), fminf(s_rmin[2], s_rmin[3]));
+                *reinterpret_cast<uint4*>(sp_mask + 4 * bsp) = make_uint4(s_bmask[0], s_bmask[1], s_bmask[2], s_bmask[3]);
+                sp_valid[bsp] = allk;
+                s_bmask[0] = s_bmask[1] = s_bmask[2] = s_bmask[3] = 0u;
+            }
+            __syncthreads();
         }
     }
     __syncthreads();

@@ -24,6 +24,7 @@ void pol_launched(void* p, int rounds_all, int rounds, int hinted, int late, int
 {
     ((spkm_policy*)p)->launched(rounds_all, rounds, hinted != 0, late != 0, skipping != 0, movers_counted != 0);
 }
+int pol_blocks_next(void* p) { return ((spkm_policy*)p)->blocks_next; }
 int pol_pt_next(void* p) { return ((spkm_policy*)p)->pt_next; }
 int pol_few_movers(void* p, double n) { return ((spkm_policy*)p)->few_movers(n); }
 void pol_sums_by_events(void* p) { ((spkm_policy*)p)->sums_by_events(); }

@@ -672,6 +672,72 @@ def test_lazy_statistics_incremental_sums_stay_the_members_sums(gpu_ctx, oracle,
         assert np.count_nonzero(a1 != a0) <= max(2, n // 10000)
 
 
+def test_settled_blocks_are_not_visited_in_lazy_runs(gpu_ctx, oracle, monkeypatch):
+    """Block summaries of the carried bounds (k_bounds_steps): in a lazy run a block of 1024 points that passed the test
+    as a whole is tested as one point from then on and, passing, is not read -- its part of the caller's assignment
+    buffer included (the lazy contract, spkm.h).  A run into the settled regime with drifting centres (teacher-forced:
+    small random moves, so that the summaries' lag is exercised, then a larger one that sends blocks back to the per-point
+    test): every call's assignment is the oracle's and the bounds stay bounds.  Then the contract, as a witness that blocks
+    really are skipped: a value scribbled into a settled block of the caller's buffer stays there (with
+    SPKM_NO_BLOCK_SKIP=1 the library repairs it, as it does without lazy statistics); a different buffer is filled completely."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 256, 40000, 12, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=15, noise=0.15)
+    rng = np.random.default_rng(3)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    s = synth.small_p_of(gopt, p)
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    gam = s / p
+    jc, ir, x = parts(Y)
+    base = oracle.mix(centres, d, p) * gam
+    sc = np.abs(base).max()
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    set_switch(monkeypatch, gpu_ctx, "SPKM_NO_PRUNE")                    # (plain screen + bounds: the forms are not under test)
+    for noskip in (False, True):
+        set_switch(monkeypatch, gpu_ctx, "SPKM_NO_BLOCK_SKIP", noskip)
+        shard.reset_policy()
+        shard.set_lazy_stats(True)
+        eng = LloydEngine(shard, K, gam)
+        eps = [0.0, 1e-4, 2e-4, 3e-4, 4e-4, 5e-4, 5e-3, 5.1e-3, 5.2e-3, 5.3e-3]
+        kept_share = []
+        for it, e in enumerate(eps):
+            Cm = base + e * sc * np.random.default_rng(50 + it // 1).standard_normal((p, K))
+            c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+            eng.assign_accumulate_step(c, want_mind=False)
+            torch.cuda.synchronize()
+            m = eng.last_screen_mode()
+            assert eng.last_path_info()[0] == 1
+            ra, rd = oracle.assign(p, n, jc, ir, x, Cm, gam)
+            assert np.array_equal(eng.assign.cpu().numpy(), ra), (noskip, it)
+            D = oracle.dist_csc(p, n, jc, ir, x, Cm / gam)
+            ub, lb, la = shard.debug_bounds()
+            own = D[ra, np.arange(n)]
+            Do = D.copy(); Do[ra, np.arange(n)] = np.inf
+            assert np.array_equal(la, ra) and not np.any(ub.astype(np.float64) < own) and not np.any(lb > Do.min(axis=0)), (noskip, it)
+            kept_share.append(m[4] * 16 / n)
+        assert max(kept_share[2:6]) > 0.9, kept_share                    # the quiet calls settle nearly every step
+        # the contract: scribble into a block that is certainly settled (all its points far inside their cluster)
+        Cm = base + 5.3e-3 * sc * np.random.default_rng(50 + 9).standard_normal((p, K))
+        c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+        for _ in range(3):                                               # same centres again: nothing moves, every point passes; the
+            eng.assign_accumulate_step(c, want_mind=False)               # policy sees that one call late and switches the summaries on,
+            torch.cuda.synchronize()                                     # the call after that writes them, the next one uses them
+        good = eng.assign.clone()
+        eng.assign[5000:5010] = K + 5                                    # (the host breaks the contract on purpose)
+        eng.assign_accumulate_step(c, want_mind=False)
+        torch.cuda.synchronize()
+        repaired = bool(torch.equal(eng.assign, good))
+        assert repaired == noskip, (noskip, eng.assign[4995:5015].cpu().numpy())
+        # a different buffer is filled completely whatever the switch says
+        eng.assign = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        eng.assign_accumulate_step(c, want_mind=False)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.assign, good)
+    shard.set_lazy_stats(False)
+
+
 @pytest.mark.parametrize("second_call,expect", [("far", 3), ("near", 2)])
 def test_second_lazy_call_lets_the_device_choose_between_events_and_the_full_pass(gpu_ctx, oracle, monkeypatch, second_call, expect):
     """A run's second lazy call is issued before any mover count has come back: both accumulation forms are queued and

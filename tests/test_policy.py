@@ -26,6 +26,7 @@ def pol(tmp_path_factory):
     L.pol_take_hinted_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.pol_launched.argtypes = [C.c_void_p] + [C.c_int] * 6
     L.pol_pt_next.argtypes = [C.c_void_p]
+    L.pol_blocks_next.argtypes = [C.c_void_p]
     L.pol_few_movers.argtypes = [C.c_void_p, C.c_double]
     L.pol_form_on_device.argtypes = [C.c_void_p]
     L.pol_sums_by_events.argtypes = [C.c_void_p]
@@ -154,6 +155,33 @@ def test_point_lists_enter_at_four_leave_below_two_and_a_half(pol):
     assert after(0.98, 0.96) == 0                            # 2x: back to steps
 
 
+def test_block_summaries_only_where_whole_blocks_settle(pol):
+    """k_bounds_steps keeps its per-block summaries (settled blocks of 1024 points are not read) only when the previous
+    bounds test passed >= 90 % of the points AND the failing points sit together (the steps left on the screen are at least
+    an eighth full of them): with data in arbitrary order every block holds every cluster and one moving centroid keeps
+    them all on the per-point path."""
+    w = Walk(pol)
+    w.call(); w.seen(ambig=0.3 * N)
+    w.call()
+    steps = N / 16
+
+    def after(kept_share, skipped_share):
+        w.seen(ambig=0.3 * N, early=0.5 * N, kept=kept_share * N, skipped=skipped_share * steps)
+        r = (pol.pol_blocks_next(w.p), pol.pol_pt_next(w.p))
+        w.call()
+        return r
+
+    assert after(0.5, 0.4)[0] == 0                           # half the points still fail
+    assert after(0.97, 0.96)[0] == 1                         # settled, failing points sit together (4 % of the steps hold the 3 %): summaries
+    assert after(0.97, 0.70) == (0, 1)                       # settled, but scattered (30 % of the steps left: point lists): no summaries
+    assert after(0.85, 0.80)[0] == 0                         # not settled enough
+    assert after(1.0, 1.0)[0] == 1                           # nothing fails at all
+    assert after(0.999, 0.99)[0] == 0                        # 0.1 % failing, scattered over 1 % of the steps (16x): no
+    assert after(0.999, 0.9985)[0] == 1                      # ... sitting together: yes
+    pol.pol_reset(w.p)
+    assert pol.pol_blocks_next(w.p) == 0
+
+
 def test_incremental_sums_while_at_most_a_third_of_the_points_move(pol):
     w = Walk(pol)
     assert pol.pol_few_movers(w.p, N) == 1                   # no count yet (a run's second call): taken as few
@@ -194,15 +222,15 @@ def test_a_call_without_a_mover_count_lets_the_device_choose_the_form(pol):
 
 def test_incremental_sums_are_refreshed_by_a_full_pass(pol):
     """Sums moved by events accumulate rounding relative to everything an entry ever held: once the movers counted since
-    the last full pass add up to the shard (or after 256 incremental calls) the next call runs the full pass again."""
+    the last full pass add up to eight times the shard (or after 256 incremental calls) the next call runs the full pass again."""
     w = Walk(pol)
     w.call(); pol.pol_sums_by_full_pass(w.p); w.seen()
-    for _ in range(3):                                       # 0.3 N movers per incremental call: due after the fourth
+    for _ in range(26):                                      # 0.3 N movers per incremental call: due after the 27th
         assert pol.pol_refresh_due(w.p, N) == 0
         w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=0.3 * N)
-    assert pol.pol_refresh_due(w.p, N) == 0                  # 0.9 N so far
+    assert pol.pol_refresh_due(w.p, N) == 0                  # 7.8 N so far
     w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=0.3 * N)
-    assert pol.pol_refresh_due(w.p, N) == 1                  # 1.2 N > N
+    assert pol.pol_refresh_due(w.p, N) == 1                  # 8.1 N > 8 N
     w.call(); pol.pol_sums_by_full_pass(w.p); w.seen(movers=0.01 * N)
     assert pol.pol_refresh_due(w.p, N) == 0                  # the full pass starts the count over (its own movers do not count)
     for _ in range(255):
