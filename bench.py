@@ -324,6 +324,31 @@ def main():
     for rl in (rl_screen, rl_acc):
         if rl:   # HBM bytes per launch from the committed PMC passes, and their ratio to the same launches' algorithmic bytes
             rl["traffic"], rl["traffic_over_algorithmic"], rl["traffic_source"] = pmc_traffic(rl["kernel"], n_local, K, p2, args.start)
+    # the timed WINDOW's launches (plain, hinted and list forms mixed): launch-weighted HBM bytes from the committed PMC passes
+    for rl in (rl_screen, rl_acc):
+        if rl:
+            w = pmc_window(rl["kernel"], n_local, K, p2)
+            if w:
+                rl["traffic_window_mean"], rl["traffic_window_source"] = w
+                rl["traffic_window_over_algorithmic"] = (w[0] / rl["algorithmic_bytes_per_launch"]) if rl["algorithmic_bytes_per_launch"] else None
+    # the VALU wall of the screen's formulation: packed f32 add + fma per (stored entry, centroid
+    # pair), 4 issue cycles each on 1024 SIMDs, at the clock the part holds under this kernel (profiles/pmc_latest.json:
+    # GRBM_GUI_ACTIVE over the traced duration) and at the 2.4 GHz it is specified for
+    if path == 1 and scr_name.startswith("k_screen_quad") and rl_screen["kernel_ms"]:
+        pk = (n_local / 16.0) * (K / 32.0) * (((s + 3) // 4) * 4) * 8.0       # wave-instructions of a launch that does ALL the work
+        clk = pmc_clock(scr_name, n_local, K, p2) or 1.79
+        floor_sust, floor_nom = pk * 4.0 / 1024.0 / (clk * 1e9) * 1e3, pk * 4.0 / 1024.0 / 2.4e9 * 1e3
+        rl_screen["valu_floor"] = {
+            "packed_wave_instructions": pk, "issue_cycles_each": 4, "simds": 1024, "sustained_clock_ghz": clk,
+            "valu_floor_ms": floor_sust, "valu_floor_ms_at_2.4GHz": floor_nom,
+            "frac_of_hbm_roofline_at_the_floor": (b_iter / (floor_sust * 1e-3) / 1e9 / HBM_PEAK_GBS),
+            "note": "what a launch that evaluates every (entry, centroid) term would take if it issued nothing but the packed "
+                    "add / fma pairs: the ceiling of this formulation, about 0.4 of the HBM roofline -- the 0.60 of "
+                    "BASELINE.json's target is not reachable by a packed-f32 VALU screen at K = 100.  The plain launch itself "
+                    "(regimes.*.roofline_cold_no_carry) runs 1.7x the floor: 11 VALU instructions per entry where 8 are "
+                    "arithmetic, plus winner selection per step; tools/ubench_quad.hip (profiles/r04_ubench_quad.txt) shows "
+                    "its rounds alone take 28-29 ms-equivalent because the part drops to 1.57 GHz under VALU + LDS together "
+                    "(1.98 GHz VALU only, 2.2 GHz LDS only): power, not issue slots, is what is left"}
     roofline = dict(top)
     roofline["by_kernel"] = {scr_name: rl_screen, **({"k_exact_accumulate": rl_acc} if rl_acc else {})}
     roofline["screen_steps_processed_share"] = done
@@ -482,6 +507,32 @@ def pmc_traffic(kern, n_local, K, p2, start):
     except Exception:
         return None, None, None
     return None, None, None
+
+
+def _pmc_records():
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(pmc) as f:
+            recs = json.load(f)
+        return recs if isinstance(recs, list) else [recs]
+    except Exception:
+        return []
+
+
+def pmc_window(kern, n_local, K, p2):
+    """(launch-weighted mean HBM bytes per launch over ALL forms of ``kern`` in the profiled bench run, what it was taken
+    over) from profiles/pmc_latest.json's `window_for` record -- the counterpart of `traffic`, which is the plain form's."""
+    for rec in _pmc_records():
+        if rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2 and rec.get("window_for") == kern:
+            return rec.get("hbm_bytes_per_launch"), rec.get("note")
+    return None
+
+
+def pmc_clock(kern, n_local, K, p2):
+    for rec in _pmc_records():
+        if rec.get("n_local") == n_local and rec.get("K") == K and rec.get("p2") == p2 and rec.get("headline_for") == kern:
+            return rec.get("effective_clock_ghz")
+    return None
 
 
 def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc, scr_name, b_scr=None):

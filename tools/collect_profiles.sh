@@ -1,20 +1,25 @@
 #!/bin/bash
-# copies the measurement set of tools/gpu_r3_final.sh from gpurun_out/ (scratch) into profiles/ (tracked) and rebuilds
+# usage: tools/collect_profiles.sh r04 -- copies the measurement set of tools/gpu_final.sh from gpurun_out/ (scratch) into profiles/ (tracked) and rebuilds
 # profiles/pmc_latest.json from the PMC passes of tools/prof.sh (FETCH_SIZE x 2 + WRITE_SIZE: MI355X_MICROARCH.md's HBM recipe)
 cd "$(dirname "$0")/.."
-R=r03
+R=${1:-r04}
+export R
 for f in headline headline_100steps headline_shuffled headline_eager_stats config5 config3 k10_n2e7 config2_n1e7 shard_1.25e7 shard_1.25e7_100steps shard_2.5e7 shard_5e7; do
-  [ -f gpurun_out/r3final/bench_$f.json ] && cp gpurun_out/r3final/bench_$f.json profiles/${R}_bench_$f.json
+  [ -f gpurun_out/${R}final/bench_$f.json ] && cp gpurun_out/${R}final/bench_$f.json profiles/${R}_bench_$f.json
 done
 cp gpurun_out/prof_${R}_headline/kernel_stats.csv profiles/${R}_headline_kernel_stats.csv
 cp gpurun_out/prof_${R}_headline/pmc_summary.txt profiles/${R}_headline_pmc_summary.txt
 for t in k10 shuffled config5; do cp gpurun_out/prof_${R}_$t/kernel_stats.csv profiles/${R}_${t}_kernel_stats.csv; done
-cp gpurun_out/r3final/driver_bench_n1e7.txt profiles/${R}_driver_bench_n1e7.txt
+cp gpurun_out/${R}final/driver_bench_n1e7.txt profiles/${R}_driver_bench_n1e7.txt
 cp gpurun_out/timeline_${R}_shard/timeline.txt profiles/${R}_timeline_shard_1.25e7.txt
+cp gpurun_out/${R}final/stress_parity.txt profiles/${R}_stress_parity.txt
+cp gpurun_out/${R}final/ubench_quad.txt profiles/${R}_ubench_quad.txt
 python - <<'PY'
 import json, csv
-pm = json.load(open('gpurun_out/prof_r03_headline/pmc_summary.json'))
-ks = {r['Name'].split('(')[0]: r for r in csv.DictReader(open('gpurun_out/prof_r03_headline/kernel_stats.csv'))}
+import os
+R = os.environ['R']
+pm = json.load(open(f'gpurun_out/prof_{R}_headline/pmc_summary.json'))
+ks = {r['Name'].split('(')[0]: r for r in csv.DictReader(open(f'gpurun_out/prof_{R}_headline/kernel_stats.csv'))}
 n, K, p2, s = 100000000, 100, 1024, 51
 b_iter = n * s * 12 + (n + 1) * 8 + n * 12 + 24 * p2 * K
 b_acc = n * s * 10 + n * 8 + 16 * p2 * K
@@ -25,9 +30,9 @@ def rec(kernel, headline_for, alg_bytes, note):
         print('no PMC record for', kernel); return
     g = lambda x: c[x]['mean_per_dispatch'] if x in c else None
     t = float(ks[kernel]['AverageNs']) / 1e6 if kernel in ks else None
-    r = {"round": 3, "n_local": n, "K": K, "p2": p2, "start": "sample", "kernel": kernel.replace('void ', ''),
+    r = {"round": int(R[1:]), "n_local": n, "K": K, "p2": p2, "start": "sample", "kernel": kernel.replace('void ', ''),
          "headline_for": headline_for,
-         "command": "python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-regimes (tools/prof.sh r03_headline; mean over this kernel's launches)",
+         "command": "python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-regimes (tools/prof.sh " + R + "_headline; mean over this kernel's launches)",
          "dispatches": c['FETCH_SIZE']['dispatches'] if 'FETCH_SIZE' in c else None,
          "FETCH_SIZE_raw_KB": g('FETCH_SIZE'), "WRITE_SIZE_raw_KB": g('WRITE_SIZE'),
          "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B; profiles/r01_fetch_calibration.txt)",
@@ -49,6 +54,20 @@ rec('void k_screen_quad<13, unsigned short, 1, false>', None, None, "hinted / tw
 rec('void k_exact_accumulate_rec<unsigned short, 4, true, false>', 'k_exact_accumulate', b_acc, "full accumulation pass over the record layout, sums only (a lazy run's first call): values + 16-bit row ids once, permutation in; bytes as SURVEY 8(d)'s separate accumulation pass (the upper-bound store it no longer does included)")
 rec('void k_exact_accumulate_rec<unsigned short, 4, false, true>', None, b_acc, "distances + statistics on demand (once per run): the same records, no sums")
 rec('void k_accumulate_events<unsigned short>', None, None, "incremental calls: the points that changed cluster, each read twice (out of its old cluster's sums, into its new one's); bytes = 2 x movers x 512 B")
+# launch-weighted mean over every form of the screen kernel in the profiled run (its 25 launches: 5 warm-up + 20 timed)
+tot_b = tot_d = 0.0
+forms = []
+for kname, cc in pm.items():
+    if 'k_screen_quad' in kname and 'FETCH_SIZE' in cc and 'WRITE_SIZE' in cc:
+        d = cc['FETCH_SIZE']['dispatches']
+        b = (cc['FETCH_SIZE']['mean_per_dispatch'] * 2 + cc['WRITE_SIZE']['mean_per_dispatch']) * 1024
+        tot_b += d * b; tot_d += d
+        forms.append(f"{kname.replace('void ', '')} x{d}")
+if tot_d:
+    recs.append({"round": int(R[1:]), "n_local": n, "K": K, "p2": p2, "start": "sample", "kernel": "k_screen_quad (all forms)",
+                 "window_for": "k_screen_quad", "dispatches": int(tot_d), "hbm_bytes_per_launch": tot_b / tot_d,
+                 "note": "launch-weighted mean of FETCH_SIZE x 2 + WRITE_SIZE over every k_screen_quad launch of the profiled bench run (" + "; ".join(forms) + "): the plain, hinted and list forms of a run's first iterations as the timed window mixes them"})
+    print('window mean', round(tot_b / tot_d / 1e9, 2), 'GB over', int(tot_d), 'launches')
 json.dump(recs, open('profiles/pmc_latest.json', 'w'), indent=1)
 PY
-ls profiles | grep r03
+ls profiles | grep $R

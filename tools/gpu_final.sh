@@ -1,9 +1,10 @@
 #!/bin/bash
-# round-3 measurement set: bench lines for the headline and the other configs, rocprofv3 kernel traces + PMC passes, the
-# shard timeline.  Everything lands under gpurun_out/r3final (tools/collect_profiles.sh copies the summaries to profiles/).
+# Measurement set of a round (usage: tools/gpu_final.sh r04): bench lines for the headline and the other configs, rocprofv3 kernel traces + PMC passes, the
+# shard timeline.  Everything lands under gpurun_out/<round>final (tools/collect_profiles.sh <round> copies the summaries to profiles/).
+R=${1:-r04}
 export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/r3final; mkdir -p $out
+out=$root/gpurun_out/${R}final; mkdir -p $out
 cd $root
 timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench_headline.json 2> $out/bench_headline.err
 timeout 900 python bench.py --steps 100 --warmup 5 --cpu-sample 0 --no-regimes > $out/bench_headline_100steps.json 2>> $out/bench_headline.err
@@ -16,14 +17,16 @@ timeout 600 python bench.py --n-total 1e7 --steps 20 --warmup 5 --cpu-sample 0 >
 for f in 1.25e7 2.5e7 5e7; do timeout 600 python bench.py --n-total $f --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/bench_shard_$f.json 2>> $out/bench_shards.err; done
 for f in 1.25e7; do timeout 600 python bench.py --n-total $f --steps 100 --warmup 5 --cpu-sample 0 --no-regimes > $out/bench_shard_${f}_100steps.json 2>> $out/bench_shards.err; done
 timeout 900 python tools/driver_bench.py 1e7 100 100 2>&1 | grep -v Warn | tail -3 > $out/driver_bench_n1e7.txt
-bash tools/prof.sh r03_headline --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_headline.log 2>&1
-PROF_TRACE_ONLY=1 bash tools/prof.sh r03_k10 --n-total 2e7 --clusters 10 --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_k10.log 2>&1
-PROF_TRACE_ONLY=1 bash tools/prof.sh r03_shuffled --order shuffled --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_shuffled.log 2>&1
-PROF_TRACE_ONLY=1 bash tools/prof.sh r03_config5 --workload config5 --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_config5.log 2>&1
-bash tools/timeline.sh r03_shard --n-total 1.25e7 --steps 30 --warmup 2 --cpu-sample 0 --no-regimes > /dev/null 2>&1
-python - <<'PY'
+bash tools/prof.sh ${R}_headline --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_headline.log 2>&1
+PROF_TRACE_ONLY=1 bash tools/prof.sh ${R}_k10 --n-total 2e7 --clusters 10 --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_k10.log 2>&1
+PROF_TRACE_ONLY=1 bash tools/prof.sh ${R}_shuffled --order shuffled --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_shuffled.log 2>&1
+PROF_TRACE_ONLY=1 bash tools/prof.sh ${R}_config5 --workload config5 --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_config5.log 2>&1
+timeout 1200 python tools/stress_parity.py 400 > $out/stress_parity.txt 2>&1
+./tools/ubench_quad > $out/ubench_quad.txt 2>&1
+bash tools/timeline.sh ${R}_shard --n-total 1.25e7 --steps 30 --warmup 2 --cpu-sample 0 --no-regimes > /dev/null 2>&1
+SPKM_ROUND=$R python - <<'PY'
 import json,glob,os
-for f in sorted(glob.glob(os.path.join(os.environ.get('GRAFT_REPO_ROOT','.'),'gpurun_out/r3final/bench_*.json'))):
+for f in sorted(glob.glob(os.path.join(os.environ.get('GRAFT_REPO_ROOT','.'),'gpurun_out/'+os.environ.get('SPKM_ROUND','r04')+'final/bench_*.json'))):
     try: r=json.load(open(f))
     except Exception as e: print(f,'unreadable'); continue
     print(os.path.basename(f), round(r['value'],2),'it/s', round(r['ms_per_step'],3),'ms', r['roofline']['kernel'], round(r['roofline']['frac'] or 0,3), r['config'].get('hbm_resident_GB'), {k:(round(v['kernel_ms'],3), round(v['frac'],3)) for k,v in r['roofline']['by_kernel'].items() if v['kernel_ms']})

@@ -25,14 +25,14 @@ while time.time() < t_end:
     n = int(rng.integers(50, 40000))
     K = int(rng.integers(2, min(130, n // 4)))
     if rng.random() < 0.25:
-        K = int(rng.integers(2, min(17, n // 4)))             # few centroids: single-tile screen, the opt-in one-pass form
+        K = int(rng.integers(2, min(17, n // 4)))             # few centroids: single-tile screen
     noise = float(rng.choice([0.1, 0.3, 0.6]))
     shuffled = bool(rng.integers(0, 2))
     iters = int(rng.integers(6, 26))
     # the library's A/B switches (none may change an output): each on in about one case of six
     switches = ["SPKM_NO_REC", "SPKM_NO_CLUSTER_SKIP", "SPKM_NO_POINT_LIST", "SPKM_NO_LATE_SPLIT", "SPKM_NO_INCREMENTAL",
                 "SPKM_PTS_NO_REC", "SPKM_NO_HINT", "SPKM_NO_PRUNE", "SPKM_NO_BOUNDS", "SPKM_NO_SORT_REUSE", "SPKM_NO_FUSE",
-                "SPKM_NO_SUPPORT_DRIFT", "SPKM_NO_TEAMS", "SPKM_NO_DUAL", "SPKM_NO_SUMS_ONLY"]
+                "SPKM_NO_SUPPORT_DRIFT", "SPKM_NO_TEAMS", "SPKM_NO_DUAL", "SPKM_NO_SUMS_ONLY", "SPKM_NO_BLOCK_SKIP"]
     on = [w for w in switches if rng.random() < 1 / 6]
     for w in switches:
         os.environ.pop(w, None)
