@@ -65,6 +65,11 @@ def main():
                          "The `overlap` regime reruns the headline at --overlap-noise, where the sampled distances of "
                          "neighbouring clusters overlap and the carried bounds keep failing")
     ap.add_argument("--overlap-noise", type=float, default=1.5)
+    ap.add_argument("--layout", choices=["records", "csc"], default="records",
+                    help="what the device sparsifier writes for the synthetic workloads: the library's record layout, adopted "
+                         "as it is (the entries exist once: peak = resident), or CSC arrays (the reference's format; the "
+                         "library builds its layouts from them on the first call and the arrays are released afterwards: the "
+                         "entries exist twice for a moment).  config5 (streamed ingest) always produces CSC arrays")
     ap.add_argument("--no-regimes", action="store_true", help="skip the traced runs to convergence (quick experiments)")
     ap.add_argument("--workload", choices=["headline", "config3", "config5"], default="headline",
                     help="headline: BASELINE.json's metric config (N=1e8, d=1024, K=100).  config3: MNIST-shaped "
@@ -139,8 +144,11 @@ def main():
             data = synth.streamed_pixel_dataset(ctx, p, n_local, first, K, args.sparsity, seed=args.seed, chunk=args.gen_chunk)
         else:
             data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
-                                               chunk=args.gen_chunk, order=order, noise=noise_sigma)
-        shard = Shard.from_device(ctx, data["p2"], data["jc"], data["ir"], data["x"], nnz=data["nnz"])
+                                               chunk=args.gen_chunk, order=order, noise=noise_sigma, layout=args.layout)
+        if "rec" in data:
+            shard = Shard.from_records(ctx, data["p2"], n_local, data["s"], data["rec"], data["ir_bits"])
+        else:
+            shard = Shard.from_device(ctx, data["p2"], data["jc"], data["ir"], data["x"], nnz=data["nnz"])
         # initial centres: K mixture points in the ORIGINAL space passed through mix(), as the
         # 'Start'-matrix path does (kmeans_sparsified.m:401-406); identical on every rank
         g = torch.Generator(device="cuda")
@@ -264,9 +272,12 @@ def main():
         cpu_data = cpu_sample_arrays(data, centers0, s, min(max(args.cpu_sample, 4_000_000), n_local))
     loop = Loop(shard, centers0)
     loop.steps(max(args.warmup, 1))                 # (at least one call: it builds the shard's record layout and screen copy)
+    torch.cuda.synchronize()
+    free_pk, total_pk = torch.cuda.mem_get_info()   # the moment everything exists at once: dataset + the library's layouts + state
+    hbm_after_first_call_GB = round((total_pk - free_pk) / 1e9, 1)
     # from here on the record layout is the only copy of the exact entries (spkm_shard_release_csc): 53 GB of the
     # 146 GB a 1e8-point shard and its layouts occupy go back to the allocator
-    csc_released = shard.release_csc() if not os.environ.get("SPKM_BENCH_KEEP_CSC") else False
+    csc_released = ("rec" in data) or (shard.release_csc() if not os.environ.get("SPKM_BENCH_KEEP_CSC") else False)
     if csc_released:
         data.pop("x", None)
         data.pop("ir", None)
@@ -386,6 +397,7 @@ def main():
                    "allreduce": allreduce_via,
                    "datagen_s": round(t_gen, 1), "final_obj": final_obj,
                    "hbm_resident_GB": round((total_b - free_b) / 1e9, 1), "csc_released": bool(csc_released),
+                   "hbm_after_first_call_GB": hbm_after_first_call_GB, "dataset_layout": "records" if "rec" in data else "csc",
                    "runs_completed_in_timed_region": loop.runs_completed, "run_lengths": loop.run_lengths,
                    "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "
                                   "bit-identical to the all-exact kernels)" if path == 1 else "exact f64 tiles",
@@ -429,7 +441,7 @@ def main():
             data2, shard2, centers02, t_gen2 = make_dataset(order_, sigma)
             loop2 = Loop(shard2, centers02)
             loop2.steps(1)                                     # set-up of the shard's screen copy happens on the first call
-            if csc_released and shard2.release_csc():
+            if csc_released and "rec" not in data2 and shard2.release_csc():
                 data2.pop("x", None)
                 data2.pop("ir", None)
                 torch.cuda.empty_cache()
@@ -590,6 +602,15 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
         r["roofline_cold_no_carry"] = roofline_obj(scr_name, float(scr[0]), b_scr,
                                                    "plain screen, every 16-point step; " + ("SURVEY 8(d) bytes of an iteration" if b_scr == b_iter
                                                    else "single centroid tile: the bytes the kernel itself moves (f32 / u16 copy + results)"))
+        if scr_name.startswith("k_screen_quad") and b_scr == b_iter:
+            nn, KK, ss = loop.shard.n, loop.eng.K, int(loop.shard.nnz // max(loop.shard.n, 1))
+            clk = pmc_clock(scr_name, nn, KK, loop.shard.p) or 1.79
+            floor = (nn / 16.0) * (KK / 32.0) * (((ss + 3) // 4) * 4) * 8.0 * 4.0 / 1024.0 / (clk * 1e9) * 1e3
+            r["roofline_cold_no_carry"]["valu_floor_ms"] = floor
+            r["roofline_cold_no_carry"]["frac_of_valu_floor"] = floor / float(scr[0]) if scr[0] > 0 else None
+            r["roofline_cold_no_carry"]["valu_floor_note"] = (
+                f"packed add + fma per (entry, centroid pair) only, 4 issue cycles each, 1024 SIMDs, {clk:.2f} GHz sustained: the "
+                "ceiling of a packed-f32 VALU screen (roofline.by_kernel.k_screen_quad.valu_floor)")
         last_pts = loop.eng.exact_pass_points()[1]
         share = last_pts / max(loop.shard.n, 1)
         r["exact_pass_points_share_last_iter"] = share
@@ -618,9 +639,17 @@ def host_cores():
 
 def cpu_sample_arrays(data, centers0, s, n_cpu):
     """host copies of the first n_cpu points (and the start centres) for the CPU legs, taken before the dataset is freed"""
+    import torch
+
     jc = np.arange(0, (n_cpu + 1) * s, s, dtype=np.uint64)
-    ir = data["ir"][: n_cpu * s].cpu().numpy().astype(np.uint16).astype(np.uint64)
-    x = data["x"][: n_cpu * s].cpu().numpy()
+    if "rec" in data:                                   # records: s float64 values, then s 16-bit row ids, per point
+        R = data["R"]
+        r = data["rec"][: n_cpu * R].view(n_cpu, R)
+        x = r[:, : s * 8].contiguous().view(torch.float64).reshape(-1).cpu().numpy()
+        ir = r[:, s * 8: s * 10].contiguous().view(torch.int16).reshape(-1).cpu().numpy().astype(np.uint16).astype(np.uint64)
+    else:
+        ir = data["ir"][: n_cpu * s].cpu().numpy().astype(np.uint16).astype(np.uint64)
+        x = data["x"][: n_cpu * s].cpu().numpy()
     return dict(jc=jc, ir=ir, x=x, C0=centers0.cpu().numpy().T.copy(), n=n_cpu)
 
 

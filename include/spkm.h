@@ -304,6 +304,21 @@ int spkm_mix_sample_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, cons
                         const double *d_sign, double premul, double postdiv, uint64_t s, uint64_t seed,
                         uint64_t col0, void *d_ir_out, int ir_bits, double *d_x_out);
 
+/* The same sparsifier writing RECORDS -- the layout the fused call reads (a point's s values, then its s row ids, in
+ * R = spkm_record_bytes(s, ir_bits) bytes, 16-byte aligned: 512 B at s = 51): column c (global index col0 + c) goes to
+ * d_rec_out + c * R.  A shard made from such a buffer (spkm_shard_create_rec_dev) never holds the separate CSC arrays,
+ * so the entries exist ONCE at every moment (a CSC shard holds them twice -- 166 GB against 100 at N = 1e8 -- from its
+ * first fused call until spkm_shard_release_csc). */
+uint64_t spkm_record_bytes(uint64_t s, int ir_bits);
+int spkm_mix_sample_rec_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, const double *d_x,
+                            const double *d_sign, double premul, double postdiv, uint64_t s, uint64_t seed,
+                            uint64_t col0, int ir_bits, void *d_rec_out);
+/* A shard over n records of exactly s entries each that the caller holds on the device (and keeps alive): what
+ * kmeans_sparsified.m:316-334 produces for one GPU, in the library's own layout.  Everything a CSC shard can do it can do:
+ * an entry point that needs CSC arrays re-materialises library-owned ones from the records first. */
+int spkm_shard_create_rec_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t s, int ir_bits, const void *d_rec,
+                              spkm_shard **out);
+
 /* Widening copy in front of the sparsifier for streamed ingest (private/sampleAndMixFromLargeFile.m:100-113 reads a
  * chunk as doubles; a dataset of 1e9 points is stored narrower): d_dst[i] = (double) d_src[i], exact for every kind.
  * kind: 1 float32, 2 uint8, 3 int16, 4 int32.  Both buffers on the device, `count` elements. */

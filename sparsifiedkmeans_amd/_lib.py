@@ -122,6 +122,10 @@ def lib():
     L.spkm_fwht_dev.argtypes = [_vp, _u64, _u64, _vp, _vp]
     L.spkm_mix_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _dbl, _dbl, _vp]
     L.spkm_mix_sample_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _dbl, _dbl, _u64, _u64, _u64, _vp, C.c_int, _vp]
+    L.spkm_record_bytes.argtypes = [_u64, C.c_int]
+    L.spkm_record_bytes.restype = _u64
+    L.spkm_mix_sample_rec_dev.argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _dbl, _dbl, _u64, _u64, _u64, C.c_int, _vp]
+    L.spkm_shard_create_rec_dev.argtypes = [_vp, _u64, _u64, _u64, C.c_int, _vp, C.POINTER(_vp)]
     L.spkm_last_screen_rounds.argtypes = [_vp, C.POINTER(C.c_int64)]
     L.spkm_last_screen_mode.argtypes = [_vp, C.POINTER(C.c_int64)]
     L.spkm_shard_reset_policy.argtypes = [_vp]

@@ -156,6 +156,7 @@ struct spkm_shard {
     float* xf = nullptr;   // f32 copy of x for the screen (with the same slack)
     char* rec = nullptr;   // record layout of the exact entries (k_build_records): x | ir of a point side by side
     int rec_R = 0;
+    bool rec_owned = true; // false: the caller's buffer (spkm_shard_create_rec_dev)
     bool rec_tried = false; // one attempt per shard (no retry every call when memory is short)
     // screen bookkeeping of THIS data set (see spkm_assign_accumulate_dev)
     unsigned* h_nlist = nullptr; // pinned: uncertified count of the previous screen call, copied back asynchronously
@@ -450,6 +451,32 @@ extern "C" int spkm_shard_create_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint
     return SPKM_OK;
 }
 
+// A shard over RECORDS the caller holds on the device (spkm_mix_sample_rec_dev's output): n points of exactly s entries.
+// The library adopts the buffer (the caller keeps it alive); it is the only copy of the entries -- the state a CSC shard
+// reaches through spkm_shard_release_csc, without ever having held the arrays.  jc is the library's.
+extern "C" int spkm_shard_create_rec_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, uint64_t s_entries, int ir_bits,
+                                         const void* d_rec, spkm_shard** out)
+{
+    if (!ctx || !out || (n && !d_rec)) return SPKM_ERR_NULL_ARG;
+    *out = nullptr;
+    if (p == 0 || p > 0x7fffffffull || n > 0x7ff00000ull) return SPKM_ERR_UNSUPPORTED;
+    if (ir_bits != 16 && ir_bits != 32) return SPKM_ERR_BAD_VALUE;
+    if ((ir_bits == 16 && p > 65536) || s_entries == 0 || s_entries > 64 || s_entries > p) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    spkm_shard* s = new spkm_shard();
+    s->ctx = ctx; s->p = p; s->n = n; s->nnz = n * s_entries; s->ir_bits = ir_bits;
+    s->fixed_s = (int)s_entries;
+    s->rec = (char*)d_rec; s->rec_R = (int)spkm_record_bytes(s_entries, ir_bits); s->rec_owned = false; s->rec_tried = true;
+    s->slack = 48;            // (what ensure_csc gives the arrays it re-materialises)
+    s->csc_released = true;
+    s->owned = true;
+    if (hipMalloc((void**)&s->jc, (n + 1) * 8) != hipSuccess) { delete s; return SPKM_ERR_NO_DEVICE; }
+    hipLaunchKernelGGL(k_fill_jc, dim3((unsigned)std::min<uint64_t>((n + 256) / 256, 4096)), dim3(256), 0, ctx->stream, s->jc,
+                       (long long)n, (long long)s_entries);
+    *out = s;
+    return SPKM_OK;
+}
+
 extern "C" void spkm_shard_destroy(spkm_shard* s)
 {
     if (!s) return;
@@ -459,7 +486,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->xn2) (void)hipFree(s->xn2);
     if (s->xf) (void)hipFree(s->xf);
     if (s->xfs) (void)hipFree(s->xfs);
-    if (s->rec) (void)hipFree(s->rec);
+    if (s->rec && s->rec_owned) (void)hipFree(s->rec);
     if (s->hb_cum) (void)hipFree(s->hb_cum);
     if (s->sp) (void)hipFree(s->sp);
     if (s->cl_cache) (void)hipFree(s->cl_cache);
@@ -623,9 +650,11 @@ static int build_screen_copy(spkm_ctx* ctx, spkm_shard* sm)
     const size_t slots = (size_t)((n + 15) / 16) * ((sm->fixed_s + 3) / 4) * 64; // steps x rounds x lanes
     HIP_TRY(hipMalloc((void**)&sm->xfs, slots * 4));
     HIP_TRY(hipMalloc((void**)&sm->irs, slots * isz));
+    // (from the CSC arrays, or -- a shard created from records, or one that has released its arrays -- from the records)
     hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
                        0, ctx->stream, (const IR*)sm->ir, (const double*)sm->x, n, sm->fixed_s, p, sm->xfs, (IR*)sm->irs,
-                       sm->norms_done ? (double*)nullptr : sm->xn1, sm->norms_done ? (double*)nullptr : sm->xn2);
+                       sm->norms_done ? (double*)nullptr : sm->xn1, sm->norms_done ? (double*)nullptr : sm->xn2,
+                       sm->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R);
     sm->norms_done = true;
     return SPKM_OK;
 }
@@ -1251,7 +1280,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         sm->xf_done = true;
     }
     if (quad && !sm->xfs) {
-        if ((rc = ensure_csc(ctx, s))) return rc;
+        if (!(sm->x == nullptr && sm->rec != nullptr) && (rc = ensure_csc(ctx, s))) return rc; // (the records serve as well)
         if ((rc = build_screen_copy<IR>(ctx, sm))) return rc;
     }
     // Last tile of the 4-lanes-per-point kernel.  <= 4 centroids: no tile of their own -- the workgroups of the
@@ -2300,7 +2329,7 @@ static int check_pow2(uint64_t m)
 static int fwht_launch(spkm_ctx* ctx, uint64_t p_in, uint64_t m, uint64_t n, const double* d_x,
                        const double* d_sign, double premul, double postdiv, double* d_y,
                        const void* gather_ir = nullptr, int gather_bits = 0, int gather_s = 0,
-                       double gather_level = 1.0)
+                       double gather_level = 1.0, long long gather_stride = 0)
 {
     int rc = check_pow2(m);
     if (rc) return rc;
@@ -2322,7 +2351,7 @@ static int fwht_launch(spkm_ctx* ctx, uint64_t p_in, uint64_t m, uint64_t n, con
         const uint64_t want = (n + cpb - 1) / cpb;
         hipLaunchKernelGGL(k_fwht_lds, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)blocks_cap)), dim3(threads),
                            lds, ctx->stream, d_x, d_y, (int)m, logm, (long long)n, (int)p_in, d_sign, premul,
-                           postdiv, cpb, gather_ir, gather_bits, gather_s, gather_level);
+                           postdiv, cpb, gather_ir, gather_bits, gather_s, gather_level, gather_stride);
     } else {
         hipLaunchKernelGGL(k_fwht_load, dim3(blocks_cap), dim3(256), 0, ctx->stream, d_x, d_y, (long long)m,
                            (long long)n, (long long)p_in, d_sign, premul);
@@ -2370,6 +2399,41 @@ extern "C" int spkm_mix_sample_dev(spkm_ctx* ctx, uint64_t p, uint64_t p2, uint6
     // SparsityLevel = small_p / p with p the row count of the mixed matrix (randsample_fixedNumberEntries.m:30-31)
     const double level = (double)s / (double)p2;
     return fwht_launch(ctx, p, p2, n, d_x, d_sign, premul, postdiv, d_x_out, d_ir_out, ir_bits, (int)s, level);
+}
+
+extern "C" uint64_t spkm_record_bytes(uint64_t s, int ir_bits)
+{
+    return (s * (8 + (uint64_t)ir_bits / 8) + 15) / 16 * 16;
+}
+
+// The sparsifier writing RECORDS: column c's s values at d_rec + c R, its row ids s * 8 bytes further (R =
+// spkm_record_bytes(s, ir_bits)) -- the layout the fused call reads, so that a shard made from them
+// (spkm_shard_create_rec_dev) never holds the separate CSC arrays: no second copy of the entries at any time.
+extern "C" int spkm_mix_sample_rec_dev(spkm_ctx* ctx, uint64_t p, uint64_t p2, uint64_t n, const double* d_x,
+                                       const double* d_sign, double premul, double postdiv, uint64_t s, uint64_t seed,
+                                       uint64_t col0, int ir_bits, void* d_rec_out)
+{
+    if (!ctx || (n && (!d_x || !d_rec_out))) return SPKM_ERR_NULL_ARG;
+    if (s == 0 || s > p2 || (ir_bits != 16 && ir_bits != 32) || (ir_bits == 16 && p2 > 65536)) return SPKM_ERR_BAD_VALUE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return SPKM_OK;
+    const long long R = (long long)spkm_record_bytes(s, ir_bits);
+    char* ir0 = (char*)d_rec_out + s * 8;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)std::max(1, ctx->num_cus) * 16);
+    if (ir_bits == 16)
+        hipLaunchKernelGGL((k_sample_rows<unsigned short>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (unsigned long long)seed, (long long)col0, (long long)n, (int)p2, (int)s, (unsigned short*)ir0, R);
+    else
+        hipLaunchKernelGGL((k_sample_rows<unsigned int>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           (unsigned long long)seed, (long long)col0, (long long)n, (int)p2, (int)s, (unsigned int*)ir0, R);
+    HIP_TRY(hipGetLastError());
+    const double level = (double)s / (double)p2;
+    // (the gather reads column c's ids at ir0 + c R and writes its values at d_rec_out + c R)
+    int rc = check_pow2(p2);
+    if (rc) return rc;
+    if (!(p2 >= 16 && p2 <= 16384 && (p2 + p2 / 8) * 8 <= ctx->lds_max)) return SPKM_ERR_UNSUPPORTED;
+    // fwht_launch's gather takes ONE base for ids and ONE for values: the values' base is d_rec_out, the ids' ir0
+    return fwht_launch(ctx, p, p2, n, d_x, d_sign, premul, postdiv, (double*)d_rec_out, ir0, ir_bits, (int)s, level, R);
 }
 
 extern "C" int spkm_widen_f64_dev(spkm_ctx* ctx, int kind, uint64_t count, const void* d_src, double* d_dst)

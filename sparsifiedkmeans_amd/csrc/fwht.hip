@@ -59,10 +59,12 @@ __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x,
                                                    const double* __restrict__ dsign, double premul,
                                                    double postdiv, int cols_per_block,
                                                    const void* __restrict__ gather_ir, int gather_bits, int gather_s,
-                                                   double gather_level)
+                                                   double gather_level, long long gather_stride = 0)
 {
     // gather epilogue (sample.hip): when gather_ir != null the transformed column stays in LDS and only
     // its gather_s sampled rows are written, y[c*gather_s + t] = (Y[row_t] / postdiv) / gather_level.
+    // gather_stride > 0: column c's row ids start gather_stride BYTES after column c - 1's, and so do its values -- the
+    // record layout (k_build_records: a point's values and row ids side by side), written directly by the sparsifier.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int T = m >> 4;                    // threads per column
@@ -156,13 +158,15 @@ __global__ __launch_bounds__(1024) void k_fwht_lds(const double* __restrict__ x,
         } else {
             // each column is gathered by the threads that own it (stays wave-local for T <= 64)
             if (csub < ncols) {
+                const size_t cc = (size_t)(cbase + csub);
+                const char* irc = reinterpret_cast<const char*>(gather_ir) + (gather_stride > 0 ? cc * (size_t)gather_stride : cc * (size_t)gather_s * (gather_bits / 8));
+                double* yc = gather_stride > 0 ? reinterpret_cast<double*>(reinterpret_cast<char*>(y) + cc * (size_t)gather_stride) : y + cc * gather_s;
                 for (int t = tau; t < gather_s; t += T) {
-                    const size_t at = (size_t)(cbase + csub) * gather_s + t;
-                    const int r = (gather_bits == 16) ? (int)reinterpret_cast<const unsigned short*>(gather_ir)[at]
-                                                      : (int)reinterpret_cast<const unsigned int*>(gather_ir)[at];
+                    const int r = (gather_bits == 16) ? (int)reinterpret_cast<const unsigned short*>(irc)[t]
+                                                      : (int)reinterpret_cast<const unsigned int*>(irc)[t];
                     double v = col[padidx(r)];
                     if (postdiv > 0.0) v = v / postdiv;
-                    y[at] = v / gather_level;
+                    yc[t] = v / gather_level;
                 }
             }
         }

@@ -37,12 +37,14 @@ __host__ __device__ inline philox4 philox4x32_10(unsigned c0, unsigned c1, unsig
 // ir_out[(c)*s + t] = t-th smallest sampled row of global column col0 + c.
 template <typename IR>
 __global__ __launch_bounds__(256) void k_sample_rows(unsigned long long seed, long long col0, long long n, int p2,
-                                                     int s, IR* __restrict__ ir_out)
+                                                     int s, IR* __restrict__ ir_out, long long stride_bytes = 0)
 {
+    // stride_bytes > 0: column c's ids start that many BYTES after column c - 1's (the record layout)
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n;
          c += (long long)gridDim.x * blockDim.x) {
         const unsigned long long gc = (unsigned long long)(col0 + c);
-        IR* out = ir_out + (size_t)c * s;
+        IR* out = stride_bytes > 0 ? reinterpret_cast<IR*>(reinterpret_cast<char*>(ir_out) + (size_t)c * (size_t)stride_bytes)
+                                   : ir_out + (size_t)c * s;
         int taken = 0;
         for (int r0 = 0; r0 < p2 && taken < s; r0 += 4) {
             const philox4 rnd = philox4x32_10((unsigned)gc, (unsigned)(gc >> 32), (unsigned)(r0 >> 2), 0u,

@@ -154,8 +154,10 @@ template <typename IR>
 __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ ir, const double* __restrict__ x,
                                                         long long n, int fixed_s, int p, float* __restrict__ xfs,
                                                         IR* __restrict__ irs, double* __restrict__ xn1,
-                                                        double* __restrict__ xn2)
+                                                        double* __restrict__ xn2, const char* __restrict__ rec = nullptr,
+                                                        int rec_R = 0)
 {
+    // rec != nullptr: the entries are read from the record layout (a shard that never had CSC arrays, or has let them go)
     // one step per workgroup pass: 16 lanes per point, up to 4 passes of 16 entries (fixed_s <= 64) held in
     // registers; the partitioned columns are staged in LDS, then written out in lane order
     __shared__ float s_x[16][64];
@@ -181,8 +183,14 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
         for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
             const bool ok = live && e < fixed_s;
-            xv[u] = ok ? x[j0 + e] : 0.0;
-            rv[u] = ok ? ir[j0 + e] : (IR)0;
+            if (rec != nullptr) {
+                const char* rb = rec + (size_t)(live ? i : 0) * (size_t)rec_R;
+                xv[u] = ok ? reinterpret_cast<const double*>(rb)[e] : 0.0;
+                rv[u] = ok ? reinterpret_cast<const IR*>(rb + (size_t)fixed_s * 8)[e] : (IR)0;
+            } else {
+                xv[u] = ok ? x[j0 + e] : 0.0;
+                rv[u] = ok ? ir[j0 + e] : (IR)0;
+            }
             const bool f = ok && ((unsigned)rv[u] & 1u) == want;
             mf[u] = (unsigned)((__ballot(f) >> gsh) & 0xffffull);
             mg[u] = (unsigned)((__ballot(ok && !f) >> gsh) & 0xffffull);
@@ -886,6 +894,12 @@ __global__ void k_pick_form(unsigned* __restrict__ counters, unsigned ev_cap, in
     counters[19] = full ? 1u : 0u;
     nitems[0] = 0;
     nitems[1] = 0;
+}
+
+// jc of a fixed-stride shard that was created from records: jc[i] = i * s
+__global__ void k_fill_jc(long long* __restrict__ jc, long long n, long long s)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x) jc[i] = i * s;
 }
 
 // several small buffers zeroed by ONE launch (the per-call counters, flags and the reduce buffer of the fused

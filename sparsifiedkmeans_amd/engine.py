@@ -60,6 +60,18 @@ class Shard:
                                                     C.byref(h)), "spkm_shard_create_dev")
         return cls(ctx, h, keep=(jc, ir, x))
 
+    @classmethod
+    def from_records(cls, ctx: Context, p: int, n: int, s: int, rec: torch.Tensor, ir_bits: int = 16) -> "Shard":
+        """Adopt a device buffer of n records (``mix_sample_records_device``'s output: a point's s float64 values, then its
+        s row ids, in ``record_bytes(s, ir_bits)`` bytes) -- the layout the fused call reads; the separate CSC arrays never
+        exist (spkm_shard_create_rec_dev)."""
+        assert rec.is_cuda and rec.dtype == torch.uint8 and rec.is_contiguous()
+        assert rec.numel() >= n * record_bytes(s, ir_bits)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().spkm_shard_create_rec_dev(ctx.handle, p, n, s, ir_bits, _p(rec), C.byref(h)),
+                   "spkm_shard_create_rec_dev")
+        return cls(ctx, h, keep=(rec,))
+
     def set_lazy_stats(self, on: bool = True):
         """Allow fused calls without distances to leave obj2 / the largest distance unevaluated (NaN) and to move the
         per-cluster sums by the points that changed cluster (spkm_shard_set_lazy_stats); LloydEngine.distances() then
@@ -364,6 +376,23 @@ def mix_sample_device(ctx: Context, x: torch.Tensor, p2: int, sign: torch.Tensor
     _lib.check(_lib.lib().spkm_mix_sample_dev(ctx.handle, p, p2, n, _p(x), _p(sign) if sign is not None else None,
                                               float(premul), float(postdiv), int(s), int(seed) & (2**64 - 1),
                                               int(col0), _p(ir_out), bits, _p(x_out)), "spkm_mix_sample_dev")
+
+
+def record_bytes(s: int, ir_bits: int = 16) -> int:
+    """bytes of one record of s entries (spkm_record_bytes): s float64 values + s row ids, rounded up to 16"""
+    return int(_lib.lib().spkm_record_bytes(int(s), int(ir_bits)))
+
+
+def mix_sample_records_device(ctx: Context, x: torch.Tensor, p2: int, sign: torch.Tensor | None, premul: float,
+                              postdiv: float, s: int, seed: int, col0: int, rec_out: torch.Tensor, ir_bits: int = 16):
+    """mix_sample_device writing RECORDS: point i of the chunk goes to ``rec_out`` (uint8, at byte i * record_bytes(s)):
+    the layout the fused call reads (spkm_mix_sample_rec_dev).  Same samples, same values as the CSC form."""
+    assert x.dtype == torch.float64 and x.is_contiguous() and x.dim() == 2
+    n, p = x.shape
+    assert rec_out.dtype == torch.uint8 and rec_out.is_contiguous() and rec_out.numel() >= n * record_bytes(s, ir_bits)
+    _lib.check(_lib.lib().spkm_mix_sample_rec_dev(ctx.handle, p, p2, n, _p(x), _p(sign) if sign is not None else None,
+                                                  float(premul), float(postdiv), int(s), int(seed) & (2**64 - 1),
+                                                  int(col0), int(ir_bits), _p(rec_out)), "spkm_mix_sample_rec_dev")
 
 
 def dense_assign_device(ctx: Context, x: torch.Tensor, centers: torch.Tensor):

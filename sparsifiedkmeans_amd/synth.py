@@ -79,7 +79,8 @@ def sparsified_gmm_host(p: int, n: int, K: int, gamma: float, seed: int = 234, f
 # device-side generator for bench-scale workloads (torch only for RNG / sort; the transform is ours)
 # ---------------------------------------------------------------------------------------------
 def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K: int, gamma: float,
-                          seed: int = 234, chunk: int = 65536, noise: float = 0.1, order: str = "block"):
+                          seed: int = 234, chunk: int = 65536, noise: float = 0.1, order: str = "block",
+                          layout: str = "csc"):
     """Generates points [first, first+n_local) of the n_total-point mixture directly into device
     CSC arrays (jc int64, ir int16/int32, x float64), chunk by chunk, never holding more than
     ``chunk`` dense columns.  Every rank generates the same global dataset: cluster means and the
@@ -87,10 +88,12 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
     owns it (chunks are aligned to global multiples of ``chunk``).
     order = "block": point i belongs to cluster floor(i*K/n) -- contiguous equal blocks, as in
     example_sparseKMeans.m:19-22; "shuffled": every point draws its cluster uniformly at random (data in
-    arbitrary order: consecutive points have nothing to do with each other)."""
+    arbitrary order: consecutive points have nothing to do with each other).
+    layout = "records": the sparsifier writes the library's record layout directly (``rec`` uint8, for
+    Shard.from_records) instead of the CSC arrays -- same samples, same values; the entries then exist once."""
     import torch
 
-    from .engine import mix_sample_device
+    from .engine import mix_sample_device, mix_sample_records_device, record_bytes
 
     dev = torch.device("cuda", ctx.device)
     p2 = 1 << int(np.ceil(np.log2(p))) if p > 1 else 2
@@ -102,8 +105,14 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
     sign[sign == 0] = 1.0
     ir_dtype = torch.int16 if p2 <= 65536 else torch.int32   # int16 storage is read as uint16 row ids
     # 48 entries of slack: the fixed-stride kernels read (and ignore) up to 33 entries past a column
-    x = torch.zeros(n_local * s + 48, dtype=torch.float64, device=dev)
-    ir = torch.zeros(n_local * s + 48, dtype=ir_dtype, device=dev)
+    records = layout == "records"
+    R = record_bytes(s, 16 if p2 <= 65536 else 32) if records else 0
+    if records:
+        rec = torch.empty(n_local * R + 256, dtype=torch.uint8, device=dev)
+        x = ir = None
+    else:
+        x = torch.zeros(n_local * s + 48, dtype=torch.float64, device=dev)
+        ir = torch.zeros(n_local * s + 48, dtype=ir_dtype, device=dev)
     premul = float(1.0 + 2.0 * EPS)
     postdiv = float(np.sqrt(np.float64(p2)))
     last = first + n_local
@@ -124,8 +133,15 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
         dense = dense[a:b].contiguous()
         o = (lo - first) * s
         # the product's own device sparsifier: mix -> sample (Philox keyed by the GLOBAL point index) -> CSC
-        mix_sample_device(ctx, dense, p2, sign, premul, postdiv, s, seed, lo, ir[o:], x[o:])
+        if records:
+            mix_sample_records_device(ctx, dense, p2, sign, premul, postdiv, s, seed, lo, rec[(lo - first) * R:],
+                                      16 if p2 <= 65536 else 32)
+        else:
+            mix_sample_device(ctx, dense, p2, sign, premul, postdiv, s, seed, lo, ir[o:], x[o:])
         c += 1
+    if records:
+        return dict(rec=rec, R=R, n=n_local, nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means,
+                    ir_bits=16 if p2 <= 65536 else 32)
     jc = torch.arange(0, (n_local + 1) * s, s, dtype=torch.int64, device=dev)
     return dict(jc=jc, ir=ir, x=x, nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means)
 

@@ -74,3 +74,55 @@ def test_device_pipeline_feeds_the_engine(gpu_ctx, oracle):
     eng.assign_step(torch.tensor(np.ascontiguousarray(Cm.T), device="cuda:0"))
     ra, rd = oracle.assign(p2, n, jc.cpu().numpy().astype(np.uint64), rows.ravel().astype(np.uint64), vals.ravel(), Cm, s / p)
     assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)
+
+
+@pytest.mark.parametrize("p,s,n", [(1024, 51, 3001), (784, 51, 1000), (512, 26, 4097), (64, 5, 333), (256, 64, 700)])
+def test_records_written_by_the_sparsifier_feed_the_engine_like_csc(gpu_ctx, oracle, p, s, n):
+    """spkm_mix_sample_rec_dev + spkm_shard_create_rec_dev: the sparsifier writes the library's record layout directly (a
+    point's s values, then its s row ids, in spkm_record_bytes(s) bytes) and the shard adopts it -- the separate CSC arrays
+    never exist.  The records hold bit for bit what the CSC form of the same call holds; a Lloyd run on them (fused calls:
+    screen copy built FROM the records; the exact kernels: CSC arrays re-materialised from them; columns read back;
+    distances on demand) gives the oracle's assignments and distances."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_sample_records_device, record_bytes
+
+    p2 = 1 << int(np.ceil(np.log2(p)))
+    K, seed, col0 = 9, 77, 123456
+    rng = np.random.default_rng(p + s)
+    X = rng.standard_normal((p, n))
+    d = np.sign(rng.standard_normal(p2)); d[d == 0] = 1
+    rows, vals = _run(gpu_ctx, X, d, p2, s, seed, col0)                     # the CSC form
+    R = record_bytes(s, 16)
+    assert R % 16 == 0 and R >= s * 10 and R < s * 10 + 16
+    rec = torch.zeros(n * R + 256, dtype=torch.uint8, device="cuda:0")
+    mix_sample_records_device(gpu_ctx, torch.tensor(np.ascontiguousarray(X.T), device="cuda:0"), p2, torch.tensor(d, device="cuda:0"),
+                              1.0 + 2 * np.finfo(float).eps, float(np.sqrt(np.float64(p2))), s, seed, col0, rec)
+    torch.cuda.synchronize()
+    r = rec[: n * R].cpu().numpy().reshape(n, R)
+    assert np.array_equal(np.ascontiguousarray(r[:, : s * 8]).view(np.float64), vals)
+    assert np.array_equal(np.ascontiguousarray(r[:, s * 8: s * 10]).view(np.uint16).astype(np.int64), rows)
+    shard = Shard.from_records(gpu_ctx, p2, n, s, rec)
+    assert (shard.p, shard.n, shard.nnz) == (p2, n, n * s)
+    ir0, x0 = shard.column(n - 1)
+    assert np.array_equal(ir0, rows[n - 1]) and np.array_equal(x0, vals[n - 1])
+    gam = s / p
+    jc = np.arange(0, (n + 1) * s, s, dtype=np.uint64)
+    irf, xf = rows.ravel().astype(np.uint64), vals.ravel()
+    eng = LloydEngine(shard, K, gam)
+    c = torch.tensor(np.ascontiguousarray((rng.standard_normal((p2, K)) * 0.3).T), device="cuda:0")
+    for it in range(4):
+        used = c.cpu().numpy().T.copy()
+        eng.iterate(c)                                                     # fused call (the screen where the shape qualifies)
+        ra, rd = oracle.assign(p2, n, jc, irf, xf, used, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd), it
+    S, Cnt, nk = oracle.accumulate(p2, n, K, jc, irf, xf, ra)
+    want = oracle.finalize_centers(S, Cnt, nk, gam, used)
+    assert np.abs(c.cpu().numpy().T - want).max() <= 1e-9 * np.abs(want).max()
+    used = c.cpu().numpy().T.copy()
+    eng.assign_step(c)                                                     # the all-exact kernels: CSC arrays come back from the records
+    ra, rd = oracle.assign(p2, n, jc, irf, xf, used, gam)
+    assert np.array_equal(eng.assign.cpu().numpy(), ra) and np.array_equal(eng.mind.cpu().numpy(), rd)
+    eng.distances(c)
+    assert np.array_equal(eng.mind.cpu().numpy(), rd)
+    assert shard.release_csc()                                             # ... and go again
+    eng.iterate(c)
+    assert np.array_equal(eng.assign.cpu().numpy(), ra)
