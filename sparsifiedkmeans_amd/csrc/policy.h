@@ -54,6 +54,9 @@ struct spkm_policy {
     int hint_fail_streak = 0;       // consecutive hinted calls that did not pay: the pause doubles (2, 4, 8, 16 calls)
     bool pt_next = false;           // the next bounds test lists POINTS, not 16-point steps
     bool blocks_next = false;       // the next bounds test keeps block summaries (k_bounds_steps: settled blocks are not read)
+    bool crowded = false;           // the latest plain call over ALL points found >= 90 % of them with a runner-up within
+                                    // 2.25x of the winner: clusters that overlap -- no partial sum clears a hint there
+                                    // (hinted calls only cost: 32.3 against 31.0 ms at N = 1e8), so none is issued
     bool movers_known = false;      // last_movers is a count (not before a run's second screen call has been read back)
     unsigned long long last_movers = 0;
     // incremental sums are a running add / subtract: their rounding error is relative to everything a table entry has
@@ -75,6 +78,7 @@ struct spkm_policy {
     void observe(const spkm_policy_counters& c, double n, int tiles, int nr)
     {
         if (mov_pending_valid) { last_movers = (unsigned long long)c.movers; movers_known = true; }
+        if (!hint_pending && prune_pending_a == 0 && !skip_pending) crowded = c.ambig >= 0.9 * n; // (a plain call that screened every point)
         if (ev_pending && mov_pending_valid) ev_cum_movers += (unsigned long long)c.movers;
         // more than 5 % of the points on the exact list: the screen pays K-fold exact work for each; 8 calls all-exact
         if (c.listed > 0.05 * n) exact_cooldown = 8;
@@ -146,7 +150,7 @@ struct spkm_policy {
         choice ch;
         ch.exact = cooling;
         ch.prune_a = no_prune ? 0 : prune_next_a;
-        ch.want_hint = ch.prune_a == 0 && !no_prune && !no_hint && hint_cooldown == 0 && quad;
+        ch.want_hint = ch.prune_a == 0 && !no_prune && !no_hint && hint_cooldown == 0 && quad && !crowded;
         return ch;
     }
     // The late-split bookkeeping of a hinted call that is actually issued (run_screen); returns whether it is a late one.

@@ -155,6 +155,21 @@ def test_point_lists_enter_at_four_leave_below_two_and_a_half(pol):
     assert after(0.98, 0.96) == 0                            # 2x: back to steps
 
 
+def test_no_hinted_calls_on_overlapping_clusters(pol):
+    """A plain call over all points that finds >= 90 % of them with a runner-up within 2.25x of the winner marks the data
+    as crowded: no hinted call is issued (nothing would finish early) until a plain call over all points says otherwise."""
+    w = Walk(pol)
+    assert w.call() == "plain"
+    w.seen(ambig=0.95 * N)                                   # overlapping clusters
+    assert [w.call() for _ in range(1)] == ["plain"]         # (bounds exist now: a hinted call would be possible)
+    w.seen(ambig=0.5 * N, skipped=0.0)                       # a call that ran the bounds test: its count says nothing
+    assert w.call() == "plain"
+    w2 = Walk(pol)
+    assert w2.call() == "plain"
+    w2.seen(ambig=0.4 * N)                                   # a third of the points between two centroids: hints pay
+    assert w2.call().startswith("hinted")
+
+
 def test_block_summaries_only_where_whole_blocks_settle(pol):
     """k_bounds_steps keeps its per-block summaries (settled blocks of 1024 points are not read) only when the previous
     bounds test passed >= 90 % of the points AND the failing points sit together (the steps left on the screen are at least
