@@ -69,7 +69,7 @@ def main():
                     help="what the device sparsifier writes for the synthetic workloads: the library's record layout, adopted "
                          "as it is (the entries exist once: peak = resident), or CSC arrays (the reference's format; the "
                          "library builds its layouts from them on the first call and the arrays are released afterwards: the "
-                         "entries exist twice for a moment).  config5 (streamed ingest) always produces CSC arrays")
+                         "entries exist twice for a moment)")
     ap.add_argument("--no-regimes", action="store_true", help="skip the traced runs to convergence (quick experiments)")
     ap.add_argument("--workload", choices=["headline", "config3", "config5"], default="headline",
                     help="headline: BASELINE.json's metric config (N=1e8, d=1024, K=100).  config3: MNIST-shaped "
@@ -141,7 +141,8 @@ def main():
         t = time.time()
         noise_sigma = args.noise if noise_sigma is None else noise_sigma
         if args.workload == "config5":
-            data = synth.streamed_pixel_dataset(ctx, p, n_local, first, K, args.sparsity, seed=args.seed, chunk=args.gen_chunk)
+            data = synth.streamed_pixel_dataset(ctx, p, n_local, first, K, args.sparsity, seed=args.seed, chunk=args.gen_chunk,
+                                                layout=args.layout)
         else:
             data = synth.sparsified_gmm_device(ctx, p, n_local, n_total, first, K, args.sparsity, seed=args.seed,
                                                chunk=args.gen_chunk, order=order, noise=noise_sigma, layout=args.layout)

@@ -472,15 +472,25 @@ class StreamingSparsifier:
     (seed, global index) only, so any chunking / sharding yields the same dataset)."""
 
     def __init__(self, ctx: Context, p: int, n_local: int, s: int, seed: int, sign: torch.Tensor | None,
-                 first: int = 0, sketch: bool = True):
+                 first: int = 0, sketch: bool = True, layout: str = "csc"):
         self.ctx, self.p, self.n, self.s, self.seed, self.first = ctx, int(p), int(n_local), int(s), int(seed), int(first)
         self.p2 = (1 << max(1, int(np.ceil(np.log2(p))))) if sketch else int(p)
         if not sketch:
             raise NotImplementedError("the fused sampler sits behind the Hadamard sketch (power-of-two row count)")
         dev = torch.device("cuda", ctx.device)
         self.sign = sign
-        self.ir = torch.zeros(self.n * self.s + 48, dtype=torch.int16 if self.p2 <= 65536 else torch.int32, device=dev)
-        self.x = torch.zeros(self.n * self.s + 48, dtype=torch.float64, device=dev)
+        # layout = "records": the chunks are appended in the library's record layout (Shard.from_records; columns of at most
+        # 64 entries) -- the resident shard then holds the entries once, from the start; "csc": the reference's format
+        self.records = layout == "records" and self.s <= 64
+        self.ir_bits = 16 if self.p2 <= 65536 else 32
+        if self.records:
+            self.R = record_bytes(self.s, self.ir_bits)
+            self.rec = torch.empty(self.n * self.R + 256, dtype=torch.uint8, device=dev)
+            self.ir = self.x = None
+        else:
+            self.ir = torch.zeros(self.n * self.s + 48, dtype=torch.int16 if self.p2 <= 65536 else torch.int32, device=dev)
+            self.x = torch.zeros(self.n * self.s + 48, dtype=torch.float64, device=dev)
+        self._dev = dev
         self.filled = 0
         self._buf = None                       # float64 chunk on the device (input of the transform)
         self._stage = [None, None]             # device staging buffers in the source's dtype
@@ -505,7 +515,7 @@ class StreamingSparsifier:
         """chunk: [m, p] points as rows (numpy array or torch tensor, host or device; float64 / float32 / uint8 /
         int16 / int32).  A PINNED host tensor is read asynchronously after this returns: call wait_source() before
         overwriting it."""
-        dev = self.x.device
+        dev = self._dev
         t = torch.from_numpy(np.ascontiguousarray(chunk)) if isinstance(chunk, np.ndarray) else chunk
         if t.dtype not in _WIDEN_KIND and t.dtype != torch.float64:
             t = t.to(torch.float64)
@@ -560,9 +570,14 @@ class StreamingSparsifier:
                        "spkm_widen_f64_dev")
             fin = buf
         o = self.filled * self.s
-        mix_sample_device(self.ctx, fin, self.p2, self.sign, 1.0 + 2.0 * float(np.finfo(np.float64).eps),
-                          float(np.sqrt(np.float64(self.p2))), self.s, self.seed, self.first + self.filled,
-                          self.ir[o:], self.x[o:])
+        if self.records:
+            mix_sample_records_device(self.ctx, fin, self.p2, self.sign, 1.0 + 2.0 * float(np.finfo(np.float64).eps),
+                                      float(np.sqrt(np.float64(self.p2))), self.s, self.seed, self.first + self.filled,
+                                      self.rec[self.filled * self.R:], self.ir_bits)
+        else:
+            mix_sample_device(self.ctx, fin, self.p2, self.sign, 1.0 + 2.0 * float(np.finfo(np.float64).eps),
+                              float(np.sqrt(np.float64(self.p2))), self.s, self.seed, self.first + self.filled,
+                              self.ir[o:], self.x[o:])
         if not t.is_cuda:
             self._ev_free[b] = torch.cuda.Event()
             self._ev_free[b].record(main)
@@ -570,8 +585,10 @@ class StreamingSparsifier:
 
     def finish(self) -> Shard:
         assert self.filled == self.n, f"expected {self.n} points, got {self.filled}"
-        jc = torch.arange(0, (self.n + 1) * self.s, self.s, dtype=torch.int64, device=self.x.device)
         self._stage = [None, None]
         self._pin = [None, None]
         self._buf = None
+        if self.records:
+            return Shard.from_records(self.ctx, self.p2, self.n, self.s, self.rec, self.ir_bits)
+        jc = torch.arange(0, (self.n + 1) * self.s, self.s, dtype=torch.int64, device=self._dev)
         return Shard.from_device(self.ctx, self.p2, jc, self.ir, self.x, nnz=self.n * self.s)

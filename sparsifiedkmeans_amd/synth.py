@@ -147,7 +147,7 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
 
 
 def streamed_pixel_dataset(ctx, p: int, n_local: int, first: int, K: int, gamma: float, seed: int = 234,
-                           chunk: int = 131072, pool_points: int = 1 << 20, sign=None):
+                           chunk: int = 131072, pool_points: int = 1 << 20, sign=None, layout: str = "csc"):
     """Config-5-shaped ingest (BASELINE.json: "1e9 x 784 chunk-streamed from host DRAM, K=10"; shape of
     private/sampleAndMixFromLargeFile.m:79-129): 8-bit "pixel" points held in PINNED host memory are streamed chunk
     by chunk over PCIe through engine.StreamingSparsifier (copy stream + two staging buffers -> widen -> mix -> sample
@@ -183,7 +183,7 @@ def streamed_pixel_dataset(ctx, p: int, n_local: int, first: int, K: int, gamma:
         pool[c0:c0 + m].copy_(px.round().clamp_(0, 255).to(torch.uint8))
         labels_pool[c0:c0 + m].copy_(lab)
     torch.cuda.synchronize()
-    sp_ = StreamingSparsifier(ctx, p, n_local, s, seed, sign, first=first)
+    sp_ = StreamingSparsifier(ctx, p, n_local, s, seed, sign, first=first, layout=layout)
     t0 = time.perf_counter()
     done = 0
     while done < n_local:
@@ -194,7 +194,9 @@ def streamed_pixel_dataset(ctx, p: int, n_local: int, first: int, K: int, gamma:
     shard_arrays = (sp_.ir, sp_.x)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    common = dict(nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means, pool=pool, labels_pool=labels_pool,
+                  pool_points=pool_points, ingest=dict(points=n_local, bytes=sp_.bytes_in, seconds=dt, GBs=sp_.bytes_in / dt / 1e9))
+    if sp_.records:
+        return dict(rec=sp_.rec, R=sp_.R, n=n_local, ir_bits=sp_.ir_bits, **common)
     jc = torch.arange(0, (n_local + 1) * s, s, dtype=torch.int64, device=dev)
-    return dict(jc=jc, ir=shard_arrays[0], x=shard_arrays[1], nnz=n_local * s, p2=p2, s=s, gamma=s / p, sign=sign, means=means,
-                pool=pool, labels_pool=labels_pool, pool_points=pool_points,
-                ingest=dict(points=n_local, bytes=sp_.bytes_in, seconds=dt, GBs=sp_.bytes_in / dt / 1e9))
+    return dict(jc=jc, ir=shard_arrays[0], x=shard_arrays[1], **common)

@@ -128,3 +128,41 @@ def test_streaming_sparsifier_accepts_narrow_dtypes_and_pageable_sources(gpu_ctx
             got_r = sp_.ir[: n * s].cpu().numpy().view(np.uint16).astype(np.int64).reshape(n, s)
             assert np.array_equal(got_r, rows) and np.array_equal(got_x, want), (dtype, pinned)
             assert shard.n == n
+
+
+def test_streaming_sparsifier_can_append_records(gpu_ctx, oracle):
+    """layout="records": the streamed chunks land in the library's record layout (spkm_mix_sample_rec_dev) and the shard
+    adopts them (spkm_shard_create_rec_dev): same rows and values as the CSC form of the same stream, column by column
+    through the library's own read-back, and the same assignments from a fused call."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, StreamingSparsifier
+
+    p, n, s, seed, K = 200, 2500, 26, 9, 6
+    p2 = 256
+    rng = np.random.default_rng(2)
+    d = np.sign(rng.standard_normal(p2))
+    src = rng.integers(0, 256, size=(n, p)).astype(np.uint8)
+    sign = torch.tensor(d, device="cuda")
+    shards = {}
+    for layout in ("csc", "records"):
+        sp_ = StreamingSparsifier(gpu_ctx, p, n, s, seed, sign, first=7, layout=layout)
+        c0 = 0
+        for m in (900, 3, 1597):
+            sp_.append(src[c0:c0 + m])
+            c0 += m
+        shards[layout] = (sp_, sp_.finish())
+    torch.cuda.synchronize()
+    assert shards["records"][0].records and not shards["csc"][0].records
+    csc = shards["csc"][0]
+    rows = csc.ir[: n * s].cpu().numpy().view(np.uint16).astype(np.int64).reshape(n, s)
+    vals = csc.x[: n * s].cpu().numpy().reshape(n, s)
+    for i in (0, 1, 899, 900, 903, n - 1):
+        r, v = shards["records"][1].column(i)
+        assert np.array_equal(r, rows[i]) and np.array_equal(v, vals[i]), i
+    c = torch.tensor(np.ascontiguousarray((rng.standard_normal((p2, K)) * 30.0).T), device="cuda")
+    out = {}
+    for layout in ("csc", "records"):
+        eng = LloydEngine(shards[layout][1], K, s / p)
+        cc = c.clone()
+        eng.iterate(cc)
+        out[layout] = (eng.assign.cpu().numpy(), eng.mind.cpu().numpy())
+    assert np.array_equal(out["csc"][0], out["records"][0]) and np.array_equal(out["csc"][1], out["records"][1])
