@@ -6,7 +6,8 @@
  *   spkm_lloyd('sparsify', X, p2, d, s, seed)   X dense p x n (double): chunk by chunk to the GPU, X*(1+2*eps), zero-pad
  *                                               to p2, D = diag(d), FWHT / sqrt(p2), s sampled rows per column scaled by
  *                                               p2 / s (kmeans_sparsified.m:292-334 + randsample_fixedNumberEntries.m:
- *                                               30-64 as ONE fused device pass, spkm_mix_sample_dev); the sparse
+ *                                               30-64 as ONE fused device pass, spkm_mix_sample_rec_dev: written in the
+ *                                               library's record layout, so the entries exist once); the sparse
  *                                               p2 x n result stays resident and never exists on the host
  *   spkm_lloyd('upload', X)                     X sparse p x n, sparsified elsewhere: copied to the GPU once
  *   Y = spkm_lloyd('columns', idx)              sparse p x numel(idx): columns idx (1-based) of the resident data
@@ -48,6 +49,7 @@ static size_t g_n = 0, g_p = 0, g_s = 0;       /* g_s > 0: every column has exac
 static int64_t *g_jc = NULL;
 static void *g_ir = NULL;
 static double *g_x = NULL;
+static void *g_rec = NULL;                      /* ... or its records (columns of <= 64 entries: the entries exist once) */
 /* per-point outputs and per-(p, K) buffers stay allocated between calls */
 static double *g_dmind = NULL, *g_dC = NULL, *g_dred = NULL, *g_dout = NULL, *g_dstats = NULL;
 static int32_t *g_dassign = NULL;
@@ -71,7 +73,7 @@ static void release_all(void)
     g_n = g_p = g_s = 0;
     g_csc_released = 0;
     g_last_sparse = 0;
-    dfree((void **)&g_jc); dfree(&g_ir); dfree((void **)&g_x);
+    dfree((void **)&g_jc); dfree(&g_ir); dfree((void **)&g_x); dfree(&g_rec);
     dfree((void **)&g_dmind); dfree((void **)&g_dassign); dfree((void **)&g_dC); dfree((void **)&g_dred);
     dfree((void **)&g_dout); dfree((void **)&g_dstats);
     g_buf_n = g_buf_pk = g_buf_rl = 0;
@@ -171,29 +173,46 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         release_all();
         double *d_sign = (double *)dmalloc(p2 * 8);
         hipMemcpy(d_sign, mxGetPr(prhs[3]), p2 * 8, hipMemcpyHostToDevice);
-        g_ir = dmalloc((n * s + 48) * 2);                        /* 48 entries of slack: the fixed-stride kernels */
-        g_x = (double *)dmalloc((n * s + 48) * 8);
-        hipMemset(g_ir, 0, (n * s + 48) * 2);
-        hipMemset(g_x, 0, (n * s + 48) * 8);
         /* the dense data crosses PCIe in chunks of at most 256 MB; only 10 B per kept entry stay on the device */
         const size_t chunk = (256u << 20) / (p * 8) ? (256u << 20) / (p * 8) : 1;
         double *d_chunk = (double *)dmalloc((chunk < n ? chunk : n) * p * 8);
         const double *xh = mxGetPr(X);
-        for (size_t c0 = 0; c0 < n; c0 += chunk) {
-            const size_t m = n - c0 < chunk ? n - c0 : chunk;
-            hipMemcpy(d_chunk, xh + c0 * p, m * p * 8, hipMemcpyHostToDevice);
-            check(spkm_mix_sample_dev(ctx, p, p2, m, d_chunk, d_sign, 1.0 + 2.0 * 2.220446049250313e-16, sqrt((double)p2), s, seed, c0,
-                                      (unsigned short *)g_ir + c0 * s, 16, g_x + c0 * s));
+        const double premul = 1.0 + 2.0 * 2.220446049250313e-16, postdiv = sqrt((double)p2);
+        if (s <= 64) {
+            /* columns of at most 64 entries: the sparsifier writes the library's RECORD layout (a point's s values, then
+             * its s row ids, in spkm_record_bytes(s, 16) bytes) and the shard adopts it -- the entries exist once on the
+             * device, from the start (spkm_mix_sample_rec_dev, spkm_shard_create_rec_dev); an entry point that needs CSC
+             * arrays (the K = 1 stream of 'kpp', sparse centres) re-materialises library-owned ones, released again below */
+            const size_t R = (size_t)spkm_record_bytes(s, 16);
+            g_rec = dmalloc(n * R + 256);
+            for (size_t c0 = 0; c0 < n; c0 += chunk) {
+                const size_t m = n - c0 < chunk ? n - c0 : chunk;
+                hipMemcpy(d_chunk, xh + c0 * p, m * p * 8, hipMemcpyHostToDevice);
+                check(spkm_mix_sample_rec_dev(ctx, p, p2, m, d_chunk, d_sign, premul, postdiv, s, seed, c0, 16, (char *)g_rec + c0 * R));
+            }
+            check(spkm_ctx_sync(ctx));
+            check(spkm_shard_create_rec_dev(ctx, p2, n, s, 16, g_rec, &g_shard));
+        } else {
+            g_ir = dmalloc((n * s + 48) * 2);                    /* 48 entries of slack: the fixed-stride kernels */
+            g_x = (double *)dmalloc((n * s + 48) * 8);
+            hipMemset(g_ir, 0, (n * s + 48) * 2);
+            hipMemset(g_x, 0, (n * s + 48) * 8);
+            for (size_t c0 = 0; c0 < n; c0 += chunk) {
+                const size_t m = n - c0 < chunk ? n - c0 : chunk;
+                hipMemcpy(d_chunk, xh + c0 * p, m * p * 8, hipMemcpyHostToDevice);
+                check(spkm_mix_sample_dev(ctx, p, p2, m, d_chunk, d_sign, premul, postdiv, s, seed, c0,
+                                          (unsigned short *)g_ir + c0 * s, 16, g_x + c0 * s));
+            }
+            check(spkm_ctx_sync(ctx));
+            int64_t *jch = (int64_t *)mxMalloc((n + 1) * 8);
+            for (size_t i = 0; i <= n; i++) jch[i] = (int64_t)(i * s);
+            g_jc = (int64_t *)dmalloc((n + 1) * 8);
+            hipMemcpy(g_jc, jch, (n + 1) * 8, hipMemcpyHostToDevice);
+            mxFree(jch);
+            check(spkm_shard_create_dev(ctx, p2, n, n * s, g_jc, g_ir, 16, g_x, n * s + 48, &g_shard));
         }
-        check(spkm_ctx_sync(ctx));
         hipFree(d_chunk);
         hipFree(d_sign);
-        int64_t *jch = (int64_t *)mxMalloc((n + 1) * 8);
-        for (size_t i = 0; i <= n; i++) jch[i] = (int64_t)(i * s);
-        g_jc = (int64_t *)dmalloc((n + 1) * 8);
-        hipMemcpy(g_jc, jch, (n + 1) * 8, hipMemcpyHostToDevice);
-        mxFree(jch);
-        check(spkm_shard_create_dev(ctx, p2, n, n * s, g_jc, g_ir, 16, g_x, n * s + 48, &g_shard));
         g_p = p2; g_n = n; g_s = s;
         return;
     }
