@@ -654,15 +654,33 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
         if ((int)threadIdx.x < K && !same[threadIdx.x]) atomicOr(&s_moved[threadIdx.x >> 5], 1u << (threadIdx.x & 31));
         __syncthreads();
     }
-    for (long long span0 = (long long)blockIdx.x * span; span0 < npad; span0 += (long long)gridDim.x * span) {
+    // per block this workgroup will visit (up to 256 of them: its first spans): passes as a whole.  The summaries are fetched
+    // together up front -- a workgroup walks ~100 blocks at N = 1e8, and one dependent fetch per block was 130 us of latency
+    // for 2 MB of summaries
+    __shared__ int s_pass[256];
+    auto block_passes = [&](long long b) -> int {
+        if ((b << 10) >= npad || !sp_valid[b]) return 0;
+        const uint4 mk = *reinterpret_cast<const uint4*>(sp_mask + 4 * b);
+        const bool still = ((mk.x & s_moved[0]) | (mk.y & s_moved[1]) | (mk.z & s_moved[2]) | (mk.w & s_moved[3])) == 0u;
+        return (still && cum_now * 0.999999 < (double)sp_slack[b]) ? 1 : 0;
+    };
+    const int nbs = span >> 10; // blocks per span
+    if (sp_on && !sp_reset) {
+        const long long sp_i = threadIdx.x / nbs;                  // which of the workgroup's spans, which block of it
+        const long long sp0 = ((long long)blockIdx.x + sp_i * gridDim.x) * span;
+        s_pass[threadIdx.x] = sp0 < npad ? block_passes((sp0 >> 10) + threadIdx.x % nbs) : 0;
+        __syncthreads();
+    }
+    int span_i = 0;
+    for (long long span0 = (long long)blockIdx.x * span; span0 < npad; span0 += (long long)gridDim.x * span, span_i++) {
+    bool span_read = false; // some block of this span took the per-point path (uniform): only then is there a list to flush
     for (int it0 = 0; it0 < span / 256; it0 += UN) {
         if (span0 + it0 * 256 >= npad) break; // npad: whole waves
         const long long blk0 = span0 + (long long)it0 * 256;
         const long long bsp = blk0 >> 10;
-        if (sp_on && !sp_reset && sp_valid[bsp]) { // (the same words for every thread of the workgroup: a uniform branch)
-            const uint4 mk = *reinterpret_cast<const uint4*>(sp_mask + 4 * bsp);
-            const bool still = ((mk.x & s_moved[0]) | (mk.y & s_moved[1]) | (mk.z & s_moved[2]) | (mk.w & s_moved[3])) == 0u;
-            if (still && cum_now * 0.999999 < (double)sp_slack[bsp]) { // every point of the block passes
+        if (sp_on && !sp_reset) { // (the same word for every thread of the workgroup: a uniform branch)
+            const int slot = span_i * nbs + (it0 >> 2);
+            if (slot < 256 ? s_pass[slot] : block_passes(bsp)) { // every point of the block passes
 #pragma unroll
                 for (int u = 0; u < UN; u++) {
                     const long long live = n - (blk0 + u * 256 + (long long)(threadIdx.x & ~63)); // points of this wave's 64 that exist
@@ -672,6 +690,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                 continue;
             }
         }
+        span_read = true;
         float ubv[UN], lbv[UN], dav[UN];
         int apv[UN], curv[UN];
         bool blk_kept = true;          // sp_on: every point of the block passed
@@ -769,6 +788,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             __syncthreads();
         }
     }
+    if (span_read) { // (a span whose blocks all passed as blocks listed nothing: four barriers saved, ~100 spans per workgroup)
     __syncthreads();
     if (threadIdx.x == 0) s_pos = s_cnt ? atomicAdd(counters + 4, s_cnt) : 0u;
     __syncthreads();
@@ -776,6 +796,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     __syncthreads();
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
+    }
     }
     if (lane == 0 && nskip) atomicAdd(&s_skip, nskip);
     if (lane == 0 && nkept) atomicAdd(&s_kept, nkept);
