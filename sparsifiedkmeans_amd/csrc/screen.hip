@@ -658,6 +658,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     // together up front -- a workgroup walks ~100 blocks at N = 1e8, and one dependent fetch per block was 130 us of latency
     // for 2 MB of summaries
     __shared__ int s_pass[256];
+    __shared__ unsigned long long s_bits[4];
     auto block_passes = [&](long long b) -> int {
         if ((b << 10) >= npad || !sp_valid[b]) return 0;
         const uint4 mk = *reinterpret_cast<const uint4*>(sp_mask + 4 * b);
@@ -668,11 +669,24 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     if (sp_on && !sp_reset) {
         const long long sp_i = threadIdx.x / nbs;                  // which of the workgroup's spans, which block of it
         const long long sp0 = ((long long)blockIdx.x + sp_i * gridDim.x) * span;
-        s_pass[threadIdx.x] = sp0 < npad ? block_passes((sp0 >> 10) + threadIdx.x % nbs) : 0;
+        const int okb = sp0 < npad ? block_passes((sp0 >> 10) + threadIdx.x % nbs) : 0;
+        s_pass[threadIdx.x] = okb;
+        const unsigned long long bal = __ballot(okb != 0); // ... and as bits, so that a span whose blocks all pass costs one test
+        if (lane == 0) s_bits[threadIdx.x >> 6] = bal;
         __syncthreads();
     }
     int span_i = 0;
     for (long long span0 = (long long)blockIdx.x * span; span0 < npad; span0 += (long long)gridDim.x * span, span_i++) {
+    if (sp_on && !sp_reset && (span_i + 1) * nbs <= 256 && span0 + span <= n) {
+        // every block of this span passes (nbs is a power of two <= 16: a span's bits lie in one word): nothing to read
+        const int slot0 = span_i * nbs;
+        const unsigned m = (unsigned)(s_bits[slot0 >> 6] >> (slot0 & 63)) & ((1u << nbs) - 1u);
+        if (m == (1u << nbs) - 1u) {
+            nkept += 256u * (unsigned)nbs;
+            nskip += 16u * (unsigned)nbs;
+            continue;
+        }
+    }
     bool span_read = false; // some block of this span took the per-point path (uniform): only then is there a list to flush
     for (int it0 = 0; it0 < span / 256; it0 += UN) {
         if (span0 + it0 * 256 >= npad) break; // npad: whole waves
@@ -681,11 +695,16 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
         if (sp_on && !sp_reset) { // (the same word for every thread of the workgroup: a uniform branch)
             const int slot = span_i * nbs + (it0 >> 2);
             if (slot < 256 ? s_pass[slot] : block_passes(bsp)) { // every point of the block passes
+                if (blk0 + 1024 <= n) { // (a whole block: every wave has 4 x 64 points, 4 x 4 steps of it -- a uniform, scalar test:
+                    nkept += 256u;      //  per-lane 64-bit arithmetic here was 70 of the kernel's 100 us at N = 1e8)
+                    nskip += 16u;
+                } else {
 #pragma unroll
-                for (int u = 0; u < UN; u++) {
-                    const long long live = n - (blk0 + u * 256 + (long long)(threadIdx.x & ~63)); // points of this wave's 64 that exist
-                    nkept += (unsigned)(live <= 0 ? 0 : (live >= 64 ? 64 : live));
-                    nskip += (unsigned)(live <= 0 ? 0 : (live >= 64 ? 4 : (live + 15) / 16));
+                    for (int u = 0; u < UN; u++) {
+                        const long long live = n - (blk0 + u * 256 + (long long)(threadIdx.x & ~63)); // points of this wave's 64 that exist
+                        nkept += (unsigned)(live <= 0 ? 0 : (live >= 64 ? 64 : live));
+                        nskip += (unsigned)(live <= 0 ? 0 : (live >= 64 ? 4 : (live + 15) / 16));
+                    }
                 }
                 continue;
             }
