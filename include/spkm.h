@@ -242,7 +242,9 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * full pass WITHOUT distances (lazy statistics, spkm_shard_set_lazy_stats: a run's first call, or too many movers for
  * events; SPKM_NO_SUMS_ONLY=1: A/B switch), 2 = incrementally, by the points that changed cluster (events) -- for a call
  * that queued both forms and let the device choose (a run's second lazy call: no mover count is back yet; SPKM_NO_DUAL=1:
- * A/B switch) the value says which one the device opened;
+ * A/B switch) the value says which one the device opened; 4 = incrementally, the events applied one by one without
+ * sorting them by cluster first (the previous call counted fewer than 2048 movers: one launch instead of three;
+ * SPKM_NO_DIRECT_EVENTS=1: A/B switch);
  * info[7] = 2 if the
  * bounds were applied point by point (the list then names points; info[4] still counts the steps whose 16 points all
  * passed): the library switches to that form when the previous call's test passed >= 60 % of the points and whole

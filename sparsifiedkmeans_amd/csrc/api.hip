@@ -63,6 +63,7 @@ struct spkm_switches {
     bool no_sums_only = false;    // SPKM_NO_SUMS_ONLY: a lazy call's full pass still evaluates every point's distance
     bool no_block_skip = false;   // SPKM_NO_BLOCK_SKIP: the carried-bounds test reads every point (no per-block summaries)
     bool no_dual = false;         // SPKM_NO_DUAL: a run's second lazy call takes the events whatever moves (round 3) instead of deciding on the device
+    bool no_direct_events = false; // SPKM_NO_DIRECT_EVENTS: a lazy call with few movers still sorts its events (plan, placement, slab kernel)
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
 static spkm_switches read_switches()
@@ -88,6 +89,7 @@ static spkm_switches read_switches()
     w.no_sums_only = on("SPKM_NO_SUMS_ONLY");
     w.no_dual = on("SPKM_NO_DUAL");
     w.no_block_skip = on("SPKM_NO_BLOCK_SKIP");
+    w.no_direct_events = on("SPKM_NO_DIRECT_EVENTS");
     return w;
 }
 
@@ -100,7 +102,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev, fin_ticket;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev, fin_ticket, wgstat;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
@@ -129,6 +131,7 @@ struct spkm_ctx {
     bool last_dual = false;          // the last screen call queued both forms; the device chose (counters[19]: the full pass)
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
+    bool last_direct_events = false; // ... applied its events one by one (k_events_direct)
     bool last_pt_mode = false;       // ... and listed points instead of 16-point steps
     bool last_hinted = false;        // ... used the hinted two-phase form
     char errmsg[256] = {0};
@@ -159,8 +162,13 @@ struct spkm_shard {
     bool rec_owned = true; // false: the caller's buffer (spkm_shard_create_rec_dev)
     bool rec_tried = false; // one attempt per shard (no retry every call when memory is short)
     // screen bookkeeping of THIS data set (see spkm_assign_accumulate_dev)
-    unsigned* h_nlist = nullptr; // pinned: uncertified count of the previous screen call, copied back asynchronously
-    hipEvent_t ev_nlist = nullptr;
+    // the screen call's counters for the host policy, written by the call's last kernel (k_call_tail) straight into pinned,
+    // device-mapped host memory: 16 counters, then the call's sequence number (system-scope release).  The host looks at
+    // them one call later, and only if the number is the one it is waiting for -- no copy, no event, no wait on the hot
+    // path (the copy and its event cost a settled iteration 10 of its 230 us)
+    unsigned* h_nlist = nullptr;
+    unsigned* h_nlist_dev = nullptr; // the same memory as the device addresses it
+    unsigned nlist_seq = 0;          // number of the report the host is waiting for (nlist_pending)
     bool nlist_pending = false;
     spkm_policy pol;             // which form the next fused call takes (policy.h), fed by the counters read back one call late
     // hinted two-phase screen: the hints (written by k_bounds_steps from the carried bounds)
@@ -310,7 +318,7 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->mscr, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->bstat, &ctx->nk_ev, &ctx->fin_ticket};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->bstat, &ctx->nk_ev, &ctx->fin_ticket, &ctx->wgstat};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -498,7 +506,6 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->ev_k) (void)hipFree(s->ev_k);
     if (s->hb_centers) (void)hipFree(s->hb_centers);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
-    if (s->ev_nlist) (void)hipEventDestroy(s->ev_nlist);
     if (s->owned && s->jc) (void)hipFree(s->jc);
     if (s->owned_csc) {
         if (s->ir) (void)hipFree(s->ir);
@@ -1590,6 +1597,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // change an assignment -- and, against the previous call's value, mark the clusters a point left or entered and move
     // the cluster sizes (a separate pass comparing the two arrays used to do that: 0.16 ms per call at N = 1e8)
     int* a_lib = quad ? (int*)(sm->hb + 2 * npad) : (int*)nullptr;
+    if ((rc = ensure(ctx, ctx->wgstat, (size_t)3 * 4096 * 4))) return rc; // k_combine_screen's per-workgroup statistics
     const int cb = (int)std::min<long long>(4096, (n + 255) / 256); // (8192+: the cold pass gains 6 %, the short lists of a converged run lose 70 %)
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), ((nk_incr ? (size_t)K : 0) + (ev_path ? (size_t)2 * K : 0)) * 4, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
@@ -1600,7 +1608,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        bounds_ok ? 1 : 0, cl_skip ? cl_touched : (int*)nullptr, K,
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
                        lazy_ub ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr,
-                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap);
+                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap,
+                       (unsigned*)ctx->wgstat.p);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1609,10 +1618,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        lazy_ub ? sm->hb : (float*)nullptr, ev_path ? sm->ev_pt : (int*)nullptr,
                        ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p,
                        s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
-                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap);
+                       ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap,
+                       (const unsigned*)ctx->wgstat.p, cb);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     ctx->last_lib_valid = bounds_ok;
     ctx->last_incremental = ev_path;
+    ctx->last_direct_events = false;
     if (ev_path) sm->pol.sums_by_events(); else sm->pol.sums_by_full_pass();
     if (ev_path) {
         // ---- incremental call: the per-cluster sums move by the points that changed cluster; no exact pass ----
@@ -1638,6 +1649,19 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         int* nitems_ev = (int*)ctx->nitems.p + (dual ? 1 : 0);
         if (dual)
             hipLaunchKernelGGL(k_pick_form, dim3(1), dim3(1), 0, ctx->stream, (unsigned*)ctx->nlist.p, ev_cap, (int*)ctx->nitems.p);
+        double* cache_s = sm->cl_cache;
+        double* cache_c = cache_s + pk;
+        // few movers (the previous call's count is back and small -- a settled run): the events are applied one by one
+        // where they were appended, no counting sort (k_events_direct).  Should many points move after all, the kernel
+        // still applies them all, only slower than the sorted form would have.  SPKM_NO_DIRECT_EVENTS=1: A/B switch
+        const bool direct = !dual && sm->pol.events_direct() && !ctx->sw.no_direct_events;
+        ctx->last_direct_events = direct;
+        if (direct) {
+            if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
+            hipLaunchKernelGGL((k_events_direct<IR>), dim3(1024), dim3(256), 0, ctx->stream, (const char*)sm->rec, sm->rec_R,
+                               (const IR*)s->ir, (const double*)s->x, (const int*)sm->ev_pt, (const int*)sm->ev_k, ev_n, p,
+                               s->fixed_s, K, cache_s, cache_c);
+        } else {
         // (the histogram over the 2 K keys was collected by k_combine_screen / k_assign_list as they appended the events)
         hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk_ev.p, K2,
                            seg_ev, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
@@ -1645,8 +1669,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const size_t sc_lds_ev = (size_t)((K2 + 1) & ~1) * 4 + (size_t)K2 * 12;
         launch_scatter(ctx, hb_, sc_lds_ev, (const int*)sm->ev_k, 0, K2, gate_ev, (const int*)nullptr, ev_n,
                        (const int*)sm->ev_pt);
-        double* cache_s = sm->cl_cache;
-        double* cache_c = cache_s + pk;
         const size_t slab = (size_t)p * 12;
         const int ab_ev = (int)std::min<long long>(max_items_ev, std::max<long long>(std::max(1, ctx->num_cus) * 8, 1));
         if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
@@ -1654,6 +1676,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                            sm->rec_R, (const IR*)s->ir, (const double*)s->x, (const int*)ctx->perm.p,
                            (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)nitems_ev, p,
                            s->fixed_s, K, cache_s, cache_c);
+        }
         if (dual) {
             // ---- ... and the full sums-only pass, for the case that too many points moved: the same kernels, in the same
             // order, as a call that knows it from the start (below); every one of them returns at once unless
@@ -1697,7 +1720,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         hipLaunchKernelGGL(k_call_tail, dim3((unsigned)std::max<size_t>((K + 255) / 256, std::min<size_t>((pk + 255) / 256, 1024))), dim3(256),
                            0, ctx->stream, (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
                            (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p, 1,
-                           cache_s, (const double*)cache_c, pk, sums, counts);
+                           cache_s, (const double*)cache_c, pk, sums, counts,
+                           sm->nlist_pending ? (unsigned*)nullptr : sm->h_nlist_dev, sm->nlist_seq + 1u);
         HIP_TRY(hipGetLastError());
         sm->hb_K = K;
         sm->hb_gamma = gamma;
@@ -1821,7 +1845,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     hipLaunchKernelGGL(k_call_tail, dim3((K + 255) / 256), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
                        (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p,
-                       sums_only ? 1 : 0);
+                       sums_only ? 1 : 0, (double*)nullptr, (const double*)nullptr, (size_t)0, (double*)nullptr, (double*)nullptr,
+                       sm->nlist_pending ? (unsigned*)nullptr : sm->h_nlist_dev, sm->nlist_seq + 1u);
     HIP_TRY(hipGetLastError());
     if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
         sm->hb_K = K;
@@ -1847,7 +1872,12 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
     //  * two-phase screen (partial sums for all centroids, only each tile's leader finished -- screen.hip):
     //    switched on when a plain screen found < 0.2 % of the points with a runner-up within 2.25x of the winner
     //    (converged iterations on separated data), switched off for 16 calls when it listed > 0.5 %.
-    if (sm->nlist_pending && hipEventQuery(sm->ev_nlist) == hipSuccess) {
+    if (!sm->h_nlist) {
+        HIP_TRY(hipHostMalloc((void**)&sm->h_nlist, 128, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(sm->h_nlist, 0, 128);
+        HIP_TRY(hipHostGetDevicePointer((void**)&sm->h_nlist_dev, sm->h_nlist, 0));
+    }
+    if (sm->nlist_pending && __atomic_load_n(sm->h_nlist + 16, __ATOMIC_ACQUIRE) == sm->nlist_seq) {
         sm->nlist_pending = false;
         ctx->last_listed = sm->h_nlist[0];
         spkm_policy_counters c;
@@ -1868,13 +1898,8 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
                                 : run_screen<unsigned int>(ctx, s, (int)K64, d_centers, gamma, d_assign, d_mind, d_reduce, prune_a, want_hint, d_stats, d_nk_u64);
         if (rc) return rc;
         ctx->last_mode = ctx->last_hinted ? 2 : (ctx->last_rounds_all < ctx->last_rounds ? 1 : 0);
-        if (!sm->h_nlist) {
-            HIP_TRY(hipHostMalloc((void**)&sm->h_nlist, 64, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&sm->ev_nlist, hipEventDisableTiming));
-        }
-        if (!sm->nlist_pending) {
-            HIP_TRY(hipMemcpyAsync(sm->h_nlist, ctx->nlist.p, 64, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipEventRecord(sm->ev_nlist, ctx->stream));
+        if (!sm->nlist_pending) { // (run_screen's k_call_tail was told to report under the number nlist_seq + 1)
+            sm->nlist_seq++;
             sm->nlist_pending = true;
             sm->pol.launched(ctx->last_rounds_all, ctx->last_rounds, ctx->last_hinted, ctx->last_hint_late, ctx->last_skipping,
                              ctx->last_lib_valid);
@@ -2065,7 +2090,7 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         info[5] = (int64_t)(((unsigned long long)v[9] << 32) | v[8]);
         // how the call got its sums: 0 full pass with every distance, 2 incremental (events),
         // 3 full pass without distances (sums only)
-        info[6] = ctx->last_incremental ? 2 : (ctx->last_sums_only ? 3 : 0);
+        info[6] = ctx->last_incremental ? (ctx->last_direct_events ? 4 : 2) : (ctx->last_sums_only ? 3 : 0);
         if (ctx->last_dual) { // both forms were queued: which one the device opened (k_pick_form)
             unsigned f[2] = {0, 0};
             HIP_TRY(hipMemcpy(f, (const unsigned*)ctx->nlist.p + 18, 8, hipMemcpyDeviceToHost));

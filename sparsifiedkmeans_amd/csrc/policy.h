@@ -67,6 +67,11 @@ struct spkm_policy {
     int ev_calls = 0;               // incremental calls since the last full accumulation pass
     unsigned long long ev_cum_movers = 0; // movers counted over those calls
 
+    // an incremental call whose predecessor counted fewer movers than this applies its events one by one (k_events_direct:
+    // one launch, one f64 atomic per entry) instead of sorting them by cluster first (three launches)
+    static constexpr unsigned long long direct_events_below = 2048;
+    bool events_direct() const { return movers_known && last_movers < direct_events_below; }
+
     // a new start / new replicate (spkm_shard_reset_policy): nothing learned carries over
     void reset()
     {
@@ -90,8 +95,15 @@ struct spkm_policy {
         // overlapping clusters -- slack between the bounds small everywhere, eroded by a steady drift -- 10-40 % of the
         // points fail for many iterations in a row, scattered over all steps: whole steps meant the full screen, 27 ms
         // at N = 1e8 where the list takes 5-19; a run to convergence there went from 57 to 63 it/s.)
-        pt_next = skip_pending && c.kept >= 0.6 * n &&
-                  (std::ceil(n / 16.0) - c.skipped) * 16.0 > (pt_next ? 2.5 : 4.0) * (n - c.kept);
+        // SHORT lists (at most 2 % of the points fail -- a settled run): the gathers meet in L2 and a listed point costs
+        // 1.4x a point of a listed step, not 2x (N = 1e8, block order: 0.20 ms + 0.32 ns per listed point against
+        // 0.20 ms + 0.23 ns per point of a listed step), so the bars are 2.5x / 1.5x there.  With 4x / 2.5x a settled run
+        // left the point lists every sixth call -- the points that fail while their neighbours' bounds age grow from 0.3
+        // to 0.9 % between two step calls (which refresh all 2 % that share a step with one) -- and paid 0.66 ms twice
+        // where a point call takes 0.47.
+        const bool short_list = (n - c.kept) <= 0.02 * n;
+        const double bar = short_list ? (pt_next ? 1.5 : 2.5) : (pt_next ? 2.5 : 4.0);
+        pt_next = skip_pending && c.kept >= 0.6 * n && (std::ceil(n / 16.0) - c.skipped) * 16.0 > bar * (n - c.kept);
         // block summaries pay when whole 1024-point blocks are settled: nearly every point passes and the points of a
         // cluster sit together (step lists: with data in arbitrary order every block holds every cluster, and one moving
         // centroid keeps them all on the per-point path -- the summaries would only cost their upkeep)

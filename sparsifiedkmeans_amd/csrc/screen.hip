@@ -982,8 +982,13 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         int* __restrict__ touched, int K,
                                                         unsigned long long* __restrict__ nk,
                                                         int lazy, int* __restrict__ ev_pt, int* __restrict__ ev_k,
-                                                        unsigned long long* __restrict__ nk_ev, unsigned ev_cap)
+                                                        unsigned long long* __restrict__ nk_ev, unsigned ev_cap,
+                                                        unsigned* __restrict__ wgstat)
 {
+    // wgstat[3 b .. 3 b + 2]: workgroup b's ambiguous points, "some assignment changed" flag and movers, as plain stores;
+    // k_assign_list (the next launch) adds them up into nlist[1], nlist[5], nlist[14].  One atomic per workgroup and counter
+    // on ONE cache line is served at ~10 ns apiece: 3500 workgroups of a settled call's point list (N = 1e8) spent 80 of
+    // this kernel's 130 us queueing for them.
     // ev_cap: events appended at a position beyond it are counted but NOT stored -- the call's accumulation form is
     // chosen on the device from the count (k_pick_form: more than ev_cap events -> the full pass, which needs none of
     // them), so once the running count has passed the cap the stores (16 B per mover) would be wasted
@@ -1023,7 +1028,10 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     // skipping: k_bounds_steps has settled the skipped steps; only the listed ones (nlist[4] of them) are looked at
     const long long total = skipping ? (pt_mode ? (long long)nlist[4] : (long long)nlist[4] * 16) : n;
     __shared__ unsigned s_amb, s_chg;
-    if ((long long)blockIdx.x * blockDim.x >= total) return; // (whole workgroup)
+    if ((long long)blockIdx.x * blockDim.x >= total) { // (whole workgroup)
+        if (threadIdx.x == 0) { wgstat[3 * blockIdx.x] = 0u; wgstat[3 * blockIdx.x + 1] = 0u; wgstat[3 * blockIdx.x + 2] = 0u; }
+        return;
+    }
     if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; s_over = 0u; }
     if (nk) for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
     if (ev_pt) for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) evc[k] = 0u;
@@ -1129,9 +1137,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     if (__any(changed) && (threadIdx.x & 63) == 0) s_chg = 1u;
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (s_amb) atomicAdd(nlist + 1, s_amb);
-        if (s_chg) atomicAdd(nlist + 5, 1u);
-        if (s_mov) atomicAdd(nlist + 14, s_mov);
+        wgstat[3 * blockIdx.x] = s_amb;
+        wgstat[3 * blockIdx.x + 1] = s_chg;
+        wgstat[3 * blockIdx.x + 2] = s_mov;
     }
     if (nk)
         for (int k = threadIdx.x; k < K; k += blockDim.x)
@@ -1154,8 +1162,22 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      float* __restrict__ ubv, int* __restrict__ ev_pt,
                                                      int* __restrict__ ev_k, unsigned* __restrict__ counters,
                                                      const char* __restrict__ rec, int rec_R,
-                                                     unsigned long long* __restrict__ nk_ev, unsigned ev_cap)
+                                                     unsigned long long* __restrict__ nk_ev, unsigned ev_cap,
+                                                     const unsigned* __restrict__ wgstat, int nwg)
 {
+    // wgstat / nwg: k_combine_screen's per-workgroup statistics (ambiguous points, changed flag, movers); the LAST
+    // workgroup of this launch adds them into counters[1], *changed (counters[5]) and counters[14] -- nobody reads those
+    // before this kernel has finished
+    if (blockIdx.x == gridDim.x - 1) {
+        unsigned a = 0u, c = 0u, m = 0u;
+        for (int b = threadIdx.x; b < nwg; b += blockDim.x) { a += wgstat[3 * b]; c += wgstat[3 * b + 1]; m += wgstat[3 * b + 2]; }
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); m += __shfl_down(m, off); }
+        if ((threadIdx.x & 63) == 0) {
+            if (a) atomicAdd(counters + 1, a);
+            if (c) atomicAdd(changed, c);
+            if (m) atomicAdd(counters + 14, m);
+        }
+    }
     // alib / lib_valid / touched / nk: the library's copy of the assignment and what follows from a change, as in
     // k_combine_screen (these points kept their previous value there); few points: global atomics
     // ubv != nullptr (lazy calls): the point's upper bound = its exact distance, rounded up; ev_pt / ev_k: the two
@@ -1184,33 +1206,36 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
         }
         double best = __builtin_inf();
         int bk = 0x7fffffff;
-        for (int k = lane; k < K; k += 64) {
-            double acc = 0.0;
+        // two centroids per lane at a time (k and k + 64): their gathers are in flight together -- with K = 100 a wave used to
+        // walk the column twice, one dependent batch of loads after the other (a short list is all latency); each sum keeps
+        // its own storage-order additions, and the candidates are compared in ascending k
+        for (int k = lane; k < K; k += 128) {
+            const bool two = k + 64 < K;
+            const int kb = two ? k + 64 : k;
+            double acc = 0.0, accb = 0.0;
             int j = 0;
-            for (; j + 8 <= ne; j += 8) { // eight independent gathers in flight; the additions stay in storage order
-                double c[8], d[8];
+            for (; j + 8 <= ne; j += 8) { // eight (sixteen) independent gathers in flight; the additions stay in storage order
+                double c[8], d[8], cb[8], db[8];
+                int r[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) c[u] = Cs[(size_t)rq[j + u] * K + k];
+                for (int u = 0; u < 8; u++) r[u] = (int)rq[j + u];
 #pragma unroll
-                for (int u = 0; u < 8; u++) d[u] = xq[j + u] - c[u];
+                for (int u = 0; u < 8; u++) { c[u] = Cs[(size_t)r[u] * K + k]; cb[u] = Cs[(size_t)r[u] * K + kb]; }
 #pragma unroll
-                for (int u = 0; u < 8; u++) acc = acc + d[u] * d[u];
-            }
-            for (; j + 4 <= ne; j += 4) {
-                const double c0 = Cs[(size_t)rq[j] * K + k], c1 = Cs[(size_t)rq[j + 1] * K + k],
-                             c2 = Cs[(size_t)rq[j + 2] * K + k], c3 = Cs[(size_t)rq[j + 3] * K + k];
-                const double d0 = xq[j] - c0, d1 = xq[j + 1] - c1, d2 = xq[j + 2] - c2, d3 = xq[j + 3] - c3;
-                acc = acc + d0 * d0;
-                acc = acc + d1 * d1;
-                acc = acc + d2 * d2;
-                acc = acc + d3 * d3;
+                for (int u = 0; u < 8; u++) { const double xv = xq[j + u]; d[u] = xv - c[u]; db[u] = xv - cb[u]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { acc = acc + d[u] * d[u]; accb = accb + db[u] * db[u]; }
             }
             for (; j < ne; j++) {
-                const double d = xq[j] - Cs[(size_t)rq[j] * K + k];
+                const double xv = xq[j];
+                const size_t r = (size_t)rq[j] * K;
+                const double d = xv - Cs[r + k], db = xv - Cs[r + kb];
                 acc = acc + d * d;
+                accb = accb + db * db;
             }
-            const double dd = sqrt(acc);
+            const double dd = sqrt(acc), ddb = sqrt(accb);
             if (dd < best) { best = dd; bk = k; }
+            if (two && ddb < best) { best = ddb; bk = kb; }
         }
         for (int off = 32; off > 0; off >>= 1) {
             const double ob = __shfl_xor(best, off);
@@ -1740,10 +1765,10 @@ template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const 
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int);
 
 // ============================================================================================
 // K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through

@@ -609,6 +609,41 @@ __global__ __launch_bounds__(256) void k_accumulate_events(const char* __restric
     }
 }
 
+// FEW events (a settled run moves some hundred points per call; api.hip takes this form when the previous call counted
+// fewer than spkm_policy::direct_events_below movers): no counting sort, no slab -- a wave per event adds the point's
+// entries to (key < K) or takes them out of (key >= K) its cluster's rows of the table, one f64 atomic per entry and
+// table.  Three launches (plan, placement, k_accumulate_events: 27 us of latency for 200 events) become one of 6 us.
+// The events are read where k_combine_screen / k_assign_list appended them; their number is read on the device.
+template <typename IR>
+__global__ __launch_bounds__(256) void k_events_direct(const char* __restrict__ rec, int R, const IR* __restrict__ ir,
+                                                       const double* __restrict__ x, const int* __restrict__ ev_pt,
+                                                       const int* __restrict__ ev_k, const unsigned* __restrict__ n_ev,
+                                                       int p, int s, int K, double* __restrict__ sums,
+                                                       double* __restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long cnt = (long long)*n_ev;
+    for (long long e = wave; e < cnt; e += nwaves) {
+        const long long i = (long long)(unsigned)ev_pt[e];
+        const int key = ev_k[e];
+        const int k = key >= K ? key - K : key;
+        const double sign = key >= K ? -1.0 : 1.0;
+        for (int j = lane; j < s; j += 64) {
+            double xe;
+            int re;
+            if (rec != nullptr) {
+                const char* b = rec + (size_t)i * (size_t)R;
+                xe = reinterpret_cast<const double*>(b)[j];
+                re = (int)reinterpret_cast<const IR*>(b + (size_t)s * 8)[j];
+            } else { xe = x[i * s + j]; re = (int)ir[i * s + j]; }
+            unsafeAtomicAdd(&sums[(size_t)k * p + re], sign * xe);
+            unsafeAtomicAdd(&counts[(size_t)k * p + re], sign);
+        }
+    }
+}
+
 // centers(:,k) = (gamma*S(:,k)) ./ (Cnt(:,k) + 1e-16) for non-empty clusters (kmeans_sparsified.m:448);
 // empty clusters keep their old column (the host applies EmptyAction, :432-445).
 // blk_dff2[b] = partial sum of (old - new)^2, reduced in fixed order by k_reduce_dff.
@@ -672,8 +707,10 @@ __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, do
                             unsigned long long* __restrict__ d_nk, const unsigned* __restrict__ bstat, int bstat_n,
                             unsigned* __restrict__ counters, int lazy = 0, double* __restrict__ cache_s = nullptr,
                             const double* __restrict__ cache_c = nullptr, size_t pk = 0, double* __restrict__ sums = nullptr,
-                            double* __restrict__ counts = nullptr)
+                            double* __restrict__ counts = nullptr, unsigned* __restrict__ host_out = nullptr, unsigned seq = 0u)
 {
+    // host_out != nullptr: pinned host memory, device-mapped -- the call's 16 counters for the host policy go there, then
+    // the report's number `seq` with a system-scope release (api.hip reads them one call later, if the number is there)
     // cache_s != nullptr (incremental calls): the call's sums and counts ARE the cache.  One repair on the way: a row of a
     // cluster that no member stores any more (count 0) must have the sum EXACTLY 0 -- a fresh summation gives that, an
     // add-and-subtract history leaves a residual of rounding noise, and kmeans_sparsified.m:448 divides it by 1e-16.
@@ -705,6 +742,10 @@ __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, do
             counters[3] += s_s[0];
             *reinterpret_cast<unsigned long long*>(counters + 8) += (unsigned long long)s_s[0];
         }
+    }
+    if (host_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { // (thread 0 made the last changes to the counters itself)
+        for (int j = 0; j < 16; j++) host_out[j] = counters[j];
+        __hip_atomic_store(host_out + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) {

@@ -310,7 +310,7 @@ class LloydEngine:
         """(form of the last screen call: 0 plain / 1 two-phase / 2 hinted / -1 none, then its counters:
         listed points, ambiguous points, early-finished (step, tile) pairs, steps skipped on the carried bounds,
         the running total of skipped steps on this context, how the sums were formed (0 full pass with distances, 3 full
-        pass without, 2 events, 1 one-pass form), 2 if the bounds list named points; blocks) -- spkm_last_screen_mode."""
+        pass without, 2 events, 4 events applied one by one), 2 if the bounds list named points; blocks) -- spkm_last_screen_mode."""
         a = (C.c_int64 * 8)()
         _lib.check(_lib.lib().spkm_last_screen_mode(self.ctx.handle, a))
         return tuple(int(v) for v in a)

@@ -31,6 +31,7 @@ void pol_sums_by_events(void* p) { ((spkm_policy*)p)->sums_by_events(); }
 void pol_sums_by_full_pass(void* p) { ((spkm_policy*)p)->sums_by_full_pass(); }
 int pol_refresh_due(void* p, double n) { return ((spkm_policy*)p)->refresh_due(n); }
 int pol_form_on_device(void* p) { return ((spkm_policy*)p)->form_on_device(); }
+int pol_events_direct(void* p) { return ((spkm_policy*)p)->events_direct(); }
 unsigned long long pol_event_cap(unsigned long long n) { return spkm_policy::event_cap(n); }
 int pol_quad_split(int nr) { return quad_split(nr); }
 int pol_quad_split_late(int nr) { return quad_split_late(nr); }

@@ -854,6 +854,65 @@ def test_carried_bounds_stay_bounds_through_every_kind_of_lazy_call(gpu_ctx, ora
     assert 2 in forms and 3 in forms[1:], forms                        # events, and a sums-only pass on valid bounds, both ran
 
 
+@pytest.mark.parametrize("direct", [True, False])
+def test_few_movers_are_applied_one_by_one_and_give_the_members_sums(gpu_ctx, oracle, monkeypatch, direct):
+    """An incremental call whose predecessor counted fewer than 2048 movers applies its events without sorting them
+    (k_events_direct; spkm_last_screen_mode info[6] = 4); SPKM_NO_DIRECT_EVENTS=1 keeps the sorted form (2).  Either way
+    assignments and per-row counts are the oracle's, the sums its sums to 1e-10 (north-star bar 1e-6) -- through drifts
+    that move a handful of points, none at all, and a jump that moves thousands (the jump call itself still runs direct,
+    on the small count it knew: it must apply them all the same)."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 256, 30000, 12, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=7, noise=1.0)   # (clusters that touch: a small drift moves some dozen points)
+    rng = np.random.default_rng(3)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    s = synth.small_p_of(gopt, p)
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    gam = s / p
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    set_switch(monkeypatch, gpu_ctx, "SPKM_NO_PRUNE")
+    set_switch(monkeypatch, gpu_ctx, "SPKM_NO_DIRECT_EVENTS", not direct)
+    shard.reset_policy()
+    shard.set_lazy_stats(True)
+    eng = LloydEngine(shard, K, gam)
+    jc, ir, x = parts(Y)
+    base = oracle.mix(centres, d, p) * gam
+    scale = np.abs(base).max()
+    jump = base.copy()
+    jump[:, :4] = base[:, [1, 2, 3, 0]]                               # four centroids trade places: a third of the points move
+    seq = [("drift", 0.0), ("drift", 6e-3), ("drift", 9e-3), ("drift", 9e-3), ("drift", 12e-3), ("jump", 12e-3), ("jump", 15e-3),
+           ("drift", 15e-3), ("drift", 18e-3)]
+    forms, movers = [], []
+    prev = None
+    for it, (what, eps) in enumerate(seq):
+        Cm = (jump if what == "jump" else base) + eps * scale * np.random.default_rng(200 + int(eps * 1e4)).standard_normal((p, K))
+        c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+        eng.assign_accumulate_step(c, want_mind=False)
+        torch.cuda.synchronize()                                       # (lets the counters land: the next call knows the movers)
+        forms.append(eng.last_screen_mode()[6])
+        ra, rd = oracle.assign(p, n, jc, ir, x, Cm, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra), (it, what)
+        movers.append(-1 if prev is None else int(np.count_nonzero(ra != prev)))
+        prev = ra
+        S, Cnt, nk = oracle.accumulate(p, n, K, jc, ir, x, ra)
+        red = eng.reduce.cpu().numpy()
+        pk = p * K
+        assert np.array_equal(red[pk:2 * pk].reshape(K, p).T, Cnt), (it, what, forms)
+        assert np.array_equal(eng.nk.cpu().numpy(), nk), (it, what)
+        assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-10 * np.abs(S).max(), (it, what, forms)
+    shard.set_lazy_stats(False)
+    assert forms[0] == 3, forms                                        # the run's first call: full pass, sums only
+    assert movers[3] == 0 and 0 < movers[2] < 2048 and movers[5] > 2048, movers
+    if direct:
+        assert forms[3] == 4 and forms[4] == 4, (forms, movers)        # few movers counted by the call before: no sort
+        assert forms[5] == 4, (forms, movers)                          # ... the jump call too: the count it knew was still small
+        assert forms[6] != 4, (forms, movers)                          # the jump's count is back: sorted events (or the full pass)
+    else:
+        assert 4 not in forms, forms
+
+
 def test_a_fresh_contexts_second_lazy_call_is_already_incremental(oracle, monkeypatch):
     """A context's first fused call allocates most of its buffers AFTER queueing its counting sort; those first-time
     allocations must not make the library forget the sort (and with it the previous assignment and cluster sizes): the

@@ -29,6 +29,7 @@ def pol(tmp_path_factory):
     L.pol_blocks_next.argtypes = [C.c_void_p]
     L.pol_few_movers.argtypes = [C.c_void_p, C.c_double]
     L.pol_form_on_device.argtypes = [C.c_void_p]
+    L.pol_events_direct.argtypes = [C.c_void_p]
     L.pol_sums_by_events.argtypes = [C.c_void_p]
     L.pol_sums_by_full_pass.argtypes = [C.c_void_p]
     L.pol_refresh_due.argtypes = [C.c_void_p, C.c_double]
@@ -134,7 +135,7 @@ def test_hints_that_do_not_pay_are_paused_with_doubling(pol):
     assert forms[at[3]] == "hinted-early" and forms[at[4]] == "hinted-late"
 
 
-def test_point_lists_enter_at_four_leave_below_two_and_a_half(pol):
+def test_point_lists_enter_at_four_leave_below_two_and_a_half_and_lower_bars_for_short_lists(pol):
     w = Walk(pol)
     w.call(); w.seen(ambig=0.3 * N)
     w.call()                                                 # a call that ran the bounds test
@@ -149,10 +150,16 @@ def test_point_lists_enter_at_four_leave_below_two_and_a_half(pol):
     assert after(0.55, 0.0) == 0                             # < 60 % of the points passed
     assert after(0.85, 0.1) == 1                             # 15 % failing, scattered (90 % of the steps left): 6x -> lists
     assert after(0.55, 0.0) == 0                             # ... and off again when too many fail
-    assert after(0.98, 0.95) == 0                            # steps left hold 5 % of the points vs 2 % failing: 2.5x < 4x
-    assert after(0.98, 0.90) == 1                            # 10 % vs 2 %: 5x -> point lists
-    assert after(0.98, 0.94) == 1                            # 3x: stays (left only below 2.5x)
-    assert after(0.98, 0.96) == 0                            # 2x: back to steps
+    assert after(0.97, 0.925) == 0                           # steps left hold 7.5 % of the points vs 3 % failing: 2.5x < 4x
+    assert after(0.97, 0.85) == 1                            # 15 % vs 3 %: 5x -> point lists
+    assert after(0.97, 0.91) == 1                            # 3x: stays (left only below 2.5x)
+    assert after(0.97, 0.94) == 0                            # 2x: back to steps
+    # short lists (<= 2 % failing): the bars are 2.5x / 1.5x -- a listed point costs 1.4x a point of a listed step there
+    assert after(0.97, 0.93) == 0                            # 3 % failing is not a short list: 2.3x < 4x
+    assert after(0.99, 0.97) == 1                            # 1 % failing in 3 % of the steps: 3x -> point lists
+    assert after(0.99, 0.982) == 1                           # 1.8x: stays (left only below 1.5x)
+    assert after(0.99, 0.986) == 0                           # 1.4x: back to steps
+    assert after(0.99, 0.98) == 0                            # 2x: not entered below 2.5x
 
 
 def test_no_hinted_calls_on_overlapping_clusters(pol):
@@ -233,6 +240,25 @@ def test_a_call_without_a_mover_count_lets_the_device_choose_the_form(pol):
         assert cap == 2 * (n // 3) and cap <= 2 * n
         movers_ok, movers_too_many = n // 3, n // 3 + 1
         assert 2 * movers_ok <= cap < 2 * movers_too_many
+
+
+def test_few_movers_are_applied_without_a_sort(pol):
+    """An incremental call applies its events one by one (k_events_direct: no plan, no placement, no slab kernel) when the
+    previous call counted fewer than 2048 movers -- never on a guess: not before a count is back."""
+    w = Walk(pol)
+    assert pol.pol_events_direct(w.p) == 0                   # nothing known
+    w.call(); w.seen()                                       # a first call counts no movers
+    assert pol.pol_events_direct(w.p) == 0
+    w.call(); w.seen(movers=5000)
+    assert pol.pol_events_direct(w.p) == 0
+    w.call(); w.seen(movers=2047)
+    assert pol.pol_events_direct(w.p) == 1
+    w.call(); w.seen(movers=0)
+    assert pol.pol_events_direct(w.p) == 1
+    w.call(); w.seen(movers=2048)
+    assert pol.pol_events_direct(w.p) == 0
+    pol.pol_reset(w.p)
+    assert pol.pol_events_direct(w.p) == 0
 
 
 def test_incremental_sums_are_refreshed_by_a_full_pass(pol):
