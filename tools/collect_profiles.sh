@@ -12,6 +12,7 @@ cp gpurun_out/prof_${R}_headline/pmc_summary.txt profiles/${R}_headline_pmc_summ
 for t in k10 shuffled config5; do cp gpurun_out/prof_${R}_$t/kernel_stats.csv profiles/${R}_${t}_kernel_stats.csv; done
 cp gpurun_out/${R}final/driver_bench_n1e7.txt profiles/${R}_driver_bench_n1e7.txt
 cp gpurun_out/timeline_${R}_shard/timeline.txt profiles/${R}_timeline_shard_1.25e7.txt
+[ -f gpurun_out/timeline_${R}_shard100/timeline.txt ] && cp gpurun_out/timeline_${R}_shard100/timeline.txt profiles/${R}_timeline_shard_1.25e7_100steps.txt
 cp gpurun_out/${R}final/stress_parity.txt profiles/${R}_stress_parity.txt
 cp gpurun_out/${R}final/ubench_quad.txt profiles/${R}_ubench_quad.txt
 python - <<'PY'

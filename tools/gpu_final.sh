@@ -24,6 +24,7 @@ PROF_TRACE_ONLY=1 bash tools/prof.sh ${R}_config5 --workload config5 --steps 20 
 timeout 1200 python tools/stress_parity.py 400 > $out/stress_parity.txt 2>&1
 ./tools/ubench_quad > $out/ubench_quad.txt 2>&1
 bash tools/timeline.sh ${R}_shard --n-total 1.25e7 --steps 30 --warmup 2 --cpu-sample 0 --no-regimes > /dev/null 2>&1
+TIMELINE_SHOW=60,90 bash tools/timeline.sh ${R}_shard100 --n-total 1.25e7 --steps 100 --warmup 2 --cpu-sample 0 --no-regimes > /dev/null 2>&1
 SPKM_ROUND=$R python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob(os.path.join(os.environ.get('GRAFT_REPO_ROOT','.'),'gpurun_out/'+os.environ.get('SPKM_ROUND','r04')+'final/bench_*.json'))):
