@@ -490,6 +490,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (!s) return;
     if (s->ctx && s->ctx->sort_owner == s) s->ctx->sort_owner = nullptr;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream); // (a queued k_call_tail may still report into h_nlist)
     if (s->xn1) (void)hipFree(s->xn1);
     if (s->xn2) (void)hipFree(s->xn2);
     if (s->xf) (void)hipFree(s->xf);
