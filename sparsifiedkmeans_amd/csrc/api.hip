@@ -154,8 +154,7 @@ struct spkm_shard {
     float* xfs = nullptr;  // screen copy for the 4-lanes-per-point kernel: f32 values, columns partitioned by row parity
     void* irs = nullptr;   // ... and their row ids
     bool norms_done = false, xf_done = false;
-    double* xn1 = nullptr; // per-point sum |x| and sum x^2 (screen error bound), built on first use
-    double* xn2 = nullptr;
+    float* xnr = nullptr; // per point: >= sqrt(sum x^2), rounded up (the screen's error bound, screen.hip), built on first use
     float* xf = nullptr;   // f32 copy of x for the screen (with the same slack)
     char* rec = nullptr;   // record layout of the exact entries (k_build_records): x | ir of a point side by side
     int rec_R = 0;
@@ -491,8 +490,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->ctx && s->ctx->sort_owner == s) s->ctx->sort_owner = nullptr;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream); // (a queued k_call_tail may still report into h_nlist)
-    if (s->xn1) (void)hipFree(s->xn1);
-    if (s->xn2) (void)hipFree(s->xn2);
+    if (s->xnr) (void)hipFree(s->xnr);
     if (s->xf) (void)hipFree(s->xf);
     if (s->xfs) (void)hipFree(s->xfs);
     if (s->rec && s->rec_owned) (void)hipFree(s->rec);
@@ -649,10 +647,7 @@ static int build_screen_copy(spkm_ctx* ctx, spkm_shard* sm)
     // (k_screen_reorder), and the certificate's per-point norms on the same pass
     const long long n = (long long)sm->n;
     const int p = (int)sm->p;
-    if (!sm->xn1) {
-        HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
-        HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
-    }
+    if (!sm->xnr) HIP_TRY(hipMalloc((void**)&sm->xnr, (size_t)n * 4));
     if (sm->xfs) return SPKM_OK;
     const size_t isz = sizeof(IR);
     const size_t slots = (size_t)((n + 15) / 16) * ((sm->fixed_s + 3) / 4) * 64; // steps x rounds x lanes
@@ -661,7 +656,7 @@ static int build_screen_copy(spkm_ctx* ctx, spkm_shard* sm)
     // (from the CSC arrays, or -- a shard created from records, or one that has released its arrays -- from the records)
     hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
                        0, ctx->stream, (const IR*)sm->ir, (const double*)sm->x, n, sm->fixed_s, p, sm->xfs, (IR*)sm->irs,
-                       sm->norms_done ? (double*)nullptr : sm->xn1, sm->norms_done ? (double*)nullptr : sm->xn2,
+                       sm->norms_done ? (float*)nullptr : sm->xnr,
                        sm->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R);
     sm->norms_done = true;
     return SPKM_OK;
@@ -1273,10 +1268,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     double* obj2 = nk_f + K;
     int rc;
     spkm_shard* sm = const_cast<spkm_shard*>(s);
-    if (!quad && !sm->xn1) {
-        HIP_TRY(hipMalloc((void**)&sm->xn1, (size_t)n * 8));
-        HIP_TRY(hipMalloc((void**)&sm->xn2, (size_t)n * 8));
-    }
+    if (!quad && !sm->xnr) HIP_TRY(hipMalloc((void**)&sm->xnr, (size_t)n * 4));
     if (!quad && (rc = ensure_csc(ctx, s))) return rc; // (the 16-lanes-per-point screen streams the CSC arrays themselves)
     if (!quad && !sm->xf) {
         // f32 copy of the values in storage order
@@ -1285,7 +1277,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     }
     if (!quad && (!sm->norms_done || !sm->xf_done)) {
         hipLaunchKernelGGL(k_point_norms, dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256), 0,
-                           ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xn1, sm->xn2, sm->xf);
+                           ctx->stream, (const long long*)s->jc, (const double*)s->x, n, s->fixed_s, sm->xnr, sm->xf);
         sm->norms_done = true;
         sm->xf_done = true;
     }
@@ -1601,8 +1593,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     if ((rc = ensure(ctx, ctx->wgstat, (size_t)3 * 4096 * 4))) return rc; // k_combine_screen's per-workgroup statistics
     const int cb = (int)std::min<long long>(4096, (n + 255) / 256); // (8192+: the cold pass gains 6 %, the short lists of a converged run lose 70 %)
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), ((nk_incr ? (size_t)K : 0) + (ev_path ? (size_t)2 * K : 0)) * 4, ctx->stream, (const float*)ctx->scr_m1.p,
-                       (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const double*)s->xn1,
-                       (const double*)s->xn2, s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
+                       (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const float*)s->xnr,
+                       s->fixed_s, (const unsigned long long*)ctx->cmax.p, (int*)d_assign,
                        (int*)ctx->list.p, (unsigned int*)ctx->nlist.p, quad ? sm->hb : (float*)nullptr, npad,
                        skipping ? 1 : 0, (const int*)ctx->todo.p, pt_mode ? 1 : 0,
                        quad ? (const double*)(sm->hb_cum + sm->cum_par) : (const double*)nullptr,

@@ -23,7 +23,9 @@
 // in f64; true distance D_k = ||x - c_k|| over the point's support.  The screen uses x~ = fl32(x),
 // c~ = fl32(c), t~_j = fl32(x~_j - c~_jk):  |t~_j - (x_j - c_jk)| <= (2u+u^2)(|x_j|+|c_jk|) =: e_j, so by the
 // triangle inequality | ||t~|| - D_k | <= E := sqrt(sum e_j^2) <= (2u+u^2) sqrt(W),
-// W = sum_j (|x_j| + Cmax)^2 = xn2 + 2 Cmax xn1 + s Cmax^2  (per-point norms xn1, xn2 precomputed).
+// W = sum_j (|x_j| + Cmax)^2 = xn2 + 2 Cmax xn1 + s Cmax^2 <= (sqrt(xn2) + sqrt(s) Cmax)^2  (xn1 = sum |x_j| <= sqrt(s xn2),
+// Cauchy-Schwarz over the column's <= s entries): ONE per-point value, xnr >= sqrt(sum x_j^2) rounded up to f32, is kept
+// (4 B per point in the certification pass instead of the 16 B of xn1 and xn2 in f64; E grows by < 25 %, of 1e-7 r).
 // The f32 FMA accumulation of s terms gives a~ in ||t~||^2 (1 +- g), g = (s+1)u(1+1e-4), hence
 // |sqrt(a~) - ||t~||| <= g sqrt(a~).  Together |sqrt(a~_k) - D_k| <= eps_k := E + g sqrt(a~_k) + 1e-20
 // (the last term covers f32 subnormal products).  dist_k itself is within D_k (1 +- 2^-45).
@@ -107,12 +109,16 @@ __global__ void k_prep_tiles_f32(const double* __restrict__ C, int p, int K, int
     }
 }
 
-// xn1[i] = sum_j |x_j|, xn2[i] = sum_j x_j^2 over column i (any order: used only inside an upper bound),
+// (the f64 sum of s squares is within s 2^-53 of the true one: 1e-12 covers it and the sqrt; NaN / inf stay NaN / inf and
+//  fail every certificate)
+__device__ __forceinline__ float point_norm_up(double sumsq) { return __double2float_ru(sqrt(sumsq) * (1.0 + 1e-12)); }
+
+// xnr[i] >= sqrt(sum_j x_j^2) over column i, rounded up to f32 (any summation order: used only inside an upper bound),
 // and the f32 copy of the values the screen streams (4 B instead of 8 B per entry).
 // 16 lanes per point so that the loads of a wave cover four contiguous columns.
 __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict__ jc, const double* __restrict__ x,
-                                                     long long n, int fixed_s, double* __restrict__ xn1,
-                                                     double* __restrict__ xn2, float* __restrict__ xf)
+                                                     long long n, int fixed_s, float* __restrict__ xnr,
+                                                     float* __restrict__ xf)
 {
     const int sub = threadIdx.x & 15;
     const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -120,19 +126,18 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
     const long long rounds = (n + ng - 1) / ng;
     for (long long t = 0; t < rounds; t++) {
         const long long i = g0 + t * ng;
-        double a = 0.0, b = 0.0;
+        double b = 0.0;
         if (i < n) {
             const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
             const long long j1 = fixed_s > 0 ? j0 + fixed_s : jc[i + 1];
             for (long long j = j0 + sub; j < j1; j += 16) {
                 const double v = x[j];
-                a += fabs(v);
                 b += v * v;
                 if (xf) xf[j] = (float)v; // the screen's x~ = fl32(x)
             }
         }
-        for (int off = 8; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-        if (i < n && sub == 0) { xn1[i] = a; xn2[i] = b; }
+        for (int off = 8; off > 0; off >>= 1) b += __shfl_xor(b, off);
+        if (i < n && sub == 0) xnr[i] = point_norm_up(b);
     }
 }
 
@@ -153,8 +158,8 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
 template <typename IR>
 __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ ir, const double* __restrict__ x,
                                                         long long n, int fixed_s, int p, float* __restrict__ xfs,
-                                                        IR* __restrict__ irs, double* __restrict__ xn1,
-                                                        double* __restrict__ xn2, const char* __restrict__ rec = nullptr,
+                                                        IR* __restrict__ irs, float* __restrict__ xnr,
+                                                        const char* __restrict__ rec = nullptr,
                                                         int rec_R = 0)
 {
     // rec != nullptr: the entries are read from the record layout (a shard that never had CSC arrays, or has let them go)
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
         IR rv[4];
         unsigned mf[4], mg[4];
         int nfirst = 0;
-        double na = 0.0, nb = 0.0;
+        double nb = 0.0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
@@ -195,7 +200,6 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
             mf[u] = (unsigned)((__ballot(f) >> gsh) & 0xffffull);
             mg[u] = (unsigned)((__ballot(ok && !f) >> gsh) & 0xffffull);
             nfirst += __builtin_popcount(mf[u]);
-            na += fabs(xv[u]);
             nb += xv[u] * xv[u];
         }
         int cf = 0, cs = 0;
@@ -221,9 +225,9 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
             ro[idx] = s_r[L >> 2][e];
         }
         __syncthreads();
-        // the certificate's per-point norms (sum |x|, sum x^2; any order) ride on the same pass over x
-        for (int off = 8; off > 0; off >>= 1) { na += __shfl_xor(na, off); nb += __shfl_xor(nb, off); }
-        if (live && sub == 0 && xn1) { xn1[i] = na; xn2[i] = nb; }
+        // the certificate's per-point norm (root of sum x^2, rounded up; any order) rides on the same pass over x
+        for (int off = 8; off > 0; off >>= 1) nb += __shfl_xor(nb, off);
+        if (live && sub == 0 && xnr) xnr[i] = point_norm_up(nb);
     }
 }
 
@@ -971,8 +975,7 @@ __global__ void k_zero_u64_gated(unsigned long long* __restrict__ dst, int n, co
 __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict__ scr_m1,
                                                         const float* __restrict__ scr_m2,
                                                         const int* __restrict__ scr_k, long long n, int G,
-                                                        const double* __restrict__ xn1,
-                                                        const double* __restrict__ xn2, int fixed_s,
+                                                        const float* __restrict__ xnr, int fixed_s,
                                                         const unsigned long long* __restrict__ cmax_bits,
                                                         int* __restrict__ assign, int* __restrict__ list,
                                                         unsigned int* __restrict__ nlist,
@@ -1023,6 +1026,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     const double u = 0x1p-24;
     const double eu = (2.0 * u + u * u) * (1.0 + 1e-9);
     const double gacc = (double)(fixed_s + 1) * u * (1.0 + 1e-4);
+    const double sqrt_s = sqrt((double)fixed_s) * (1.0 + 1e-15);
     const double nu = 0x1p-45;
     unsigned nambig = 0;
     // skipping: k_bounds_steps has settled the skipped steps; only the listed ones (nlist[4] of them) are looked at
@@ -1066,8 +1070,8 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
             else { b2 = fminf(b2, m1); }
             b2 = fminf(b2, m2);
         }
-        const double W = (xn2[i] + 2.0 * cmax * xn1[i] + (double)fixed_s * cmax * cmax) * (1.0 + 1e-9);
-        const double E = eu * sqrt(W) * (1.0 + 1e-9);
+        const double E = eu * ((double)xnr[i] + sqrt_s * cmax) * (1.0 + 1e-9) * (1.0 + 1e-9); // eu sqrt(W), W as in the header
+
         const double r1 = sqrt((double)b1), r2 = sqrt((double)b2);
         const double e1 = E + gacc * r1 + 1e-20, e2 = E + gacc * r2 + 1e-20;
         const bool certified = (bk >= 0) && ((r1 + e1) * (1.0 + nu) < (r2 - e2) * (1.0 - nu));
