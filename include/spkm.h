@@ -254,6 +254,13 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * one; SPKM_PTS_NO_REC=1 reads the screen's own step-major copy instead.)
  * Blocks on the stream. */
 int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[8]);
+/* How the last fused call moved the per-cluster sums when it did so incrementally (spkm_last_screen_mode info[6] = 2 or 4):
+ * info[0] = 0 not an incremental call, 1 events sorted by cluster and applied through LDS slabs, 2 events applied one by
+ * one (few movers); info[1] = 1 if the call recorded PAIR events -- one per mover, (point, new cluster, old cluster),
+ * sorted by (new, old) pair so that a mover's entries are read once and go into the new cluster's sums and out of the
+ * old one's together (K <= 128; SPKM_NO_PAIR_EVENTS=1: A/B switch) -- 0 if two events per mover, each applied on its
+ * own (kmeans_sparsified.m:447-448's S and Cnt either way).  Does not block. */
+int spkm_last_events_form(spkm_ctx *ctx, int64_t info[2]);
 
 /* Unchanged-cluster shortcut of the fused call's exact pass.  A cluster (i) whose centroid is BITWISE the one the
  * previous fused call on this shard was given and (ii) that no point left or entered is not streamed again: every

@@ -128,6 +128,7 @@ def lib():
     L.spkm_shard_create_rec_dev.argtypes = [_vp, _u64, _u64, _u64, C.c_int, _vp, C.POINTER(_vp)]
     L.spkm_last_screen_rounds.argtypes = [_vp, C.POINTER(C.c_int64)]
     L.spkm_last_screen_mode.argtypes = [_vp, C.POINTER(C.c_int64)]
+    L.spkm_last_events_form.argtypes = [_vp, C.POINTER(C.c_int64)]
     L.spkm_shard_reset_policy.argtypes = [_vp]
     L.spkm_dense_assign_dev.argtypes = [_vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp]
     L.spkm_dense_accumulate_dev.argtypes = [_vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp]

@@ -63,6 +63,7 @@ struct spkm_switches {
     bool no_sums_only = false;    // SPKM_NO_SUMS_ONLY: a lazy call's full pass still evaluates every point's distance
     bool no_block_skip = false;   // SPKM_NO_BLOCK_SKIP: the carried-bounds test reads every point (no per-block summaries)
     bool no_dual = false;         // SPKM_NO_DUAL: a run's second lazy call takes the events whatever moves (round 3) instead of deciding on the device
+    bool no_pair_events = false;   // SPKM_NO_PAIR_EVENTS: two events per mover over 2 K keys (each applied on its own: the record is read twice) also for K <= 128
     bool no_direct_events = false; // SPKM_NO_DIRECT_EVENTS: a lazy call with few movers still sorts its events (plan, placement, slab kernel)
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
@@ -90,6 +91,7 @@ static spkm_switches read_switches()
     w.no_dual = on("SPKM_NO_DUAL");
     w.no_block_skip = on("SPKM_NO_BLOCK_SKIP");
     w.no_direct_events = on("SPKM_NO_DIRECT_EVENTS");
+    w.no_pair_events = on("SPKM_NO_PAIR_EVENTS");
     return w;
 }
 
@@ -102,7 +104,7 @@ struct spkm_ctx {
     size_t mem_bytes = 0;
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
-        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev, fin_ticket, wgstat;
+        bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev, fin_ticket, wgstat, offs2, cursor2, hist2, items2, perm_o;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
@@ -132,6 +134,7 @@ struct spkm_ctx {
     int last_mode = 0;               // 0 plain screen, 1 two-phase, 2 hinted two-phase (last screen call)
     bool last_skipping = false;      // the last screen call ran the carried-bounds test
     bool last_direct_events = false; // ... applied its events one by one (k_events_direct)
+    bool last_pair_events = false;   // ... recorded one event per mover (pair events)
     bool last_pt_mode = false;       // ... and listed points instead of 16-point steps
     bool last_hinted = false;        // ... used the hinted two-phase form
     char errmsg[256] = {0};
@@ -205,6 +208,8 @@ struct spkm_shard {
     bool cl_stats_valid = false; // cl_cache's obj2 / max / argmax describe the previous call (false after an incremental call)
     int* ev_pt = nullptr;        // events of the current call: point | key (K + old cluster, or new cluster); 2 n each
     int* ev_k = nullptr;
+    int* ev_o = nullptr;         // pair events (K <= 128): the mover's old cluster (-1: none); n + 4096 of them
+    size_t ev_o_cap = 0;
     size_t ev_cap = 0;
 };
 
@@ -317,7 +322,8 @@ extern "C" void spkm_ctx_destroy(spkm_ctx* ctx)
     devbuf* all[] = {&ctx->tiles, &ctx->part_acc, &ctx->part_k, &ctx->blk_obj, &ctx->blk_max, &ctx->blk_imax,
                      &ctx->nk, &ctx->stats, &ctx->perm, &ctx->offs, &ctx->cursor, &ctx->items, &ctx->nitems,
                      &ctx->bmap, &ctx->blk_dff, &ctx->ct, &ctx->tmp_assign, &ctx->tmp_mind, &ctx->mscr, &ctx->dbg, &ctx->t32, &ctx->scr_m1, &ctx->scr_m2,
-                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->bstat, &ctx->nk_ev, &ctx->fin_ticket, &ctx->wgstat};
+                     &ctx->scr_k, &ctx->cmax, &ctx->list, &ctx->nlist, &ctx->dn_x, &ctx->dn_c, &ctx->dn_nk, &ctx->bmapq, &ctx->todo, &ctx->bstat, &ctx->nk_ev, &ctx->fin_ticket, &ctx->wgstat, &ctx->offs2, &ctx->cursor2, &ctx->hist2,
+                     &ctx->items2, &ctx->perm_o};
     for (devbuf* b : all) release(*b);
     for (auto& pr : ctx->tlog) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -503,6 +509,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->hintu) (void)hipFree(s->hintu);
     if (s->ev_pt) (void)hipFree(s->ev_pt);
     if (s->ev_k) (void)hipFree(s->ev_k);
+    if (s->ev_o) (void)hipFree(s->ev_o);
     if (s->hb_centers) (void)hipFree(s->hb_centers);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
     if (s->owned && s->jc) (void)hipFree(s->jc);
@@ -1335,7 +1342,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     const long long npad = (n + 63) / 64 * 64;
     int bstat_n = 0; // workgroups of k_bounds_steps whose statistics wait in ctx->bstat
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
-    bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false, ev_possible = false;
+    bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false, ev_possible = false, pair_ev = false;
     bool sp_maintained = false; // this call's bounds test kept the block summaries
     // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
@@ -1382,7 +1389,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // (what an incremental call needs is allocated by the first lazy call, whatever path that one takes: a run's
         //  first call is the one that builds things; 3 x 8 B per point here, and the sort buffers at their event sizes below)
         ev_possible = sm->lazy && !ctx->sw.no_incremental && !ctx->sw.no_sort_reuse && (size_t)p * 12 <= 64 * 1024;
-        ev_path = ev_possible && d_mind == nullptr && kept && sm->cl_valid && sm->pol.few_movers((double)n) &&
+        const bool pair_capable = K <= 128 && !ctx->sw.no_pair_events; // (pair events, below: the bar for "few" is higher)
+        ev_path = ev_possible && d_mind == nullptr && kept && sm->cl_valid && sm->pol.few_movers((double)n, pair_capable) &&
                   !sm->pol.refresh_due((double)n);
         if (ev_possible && sm->ev_cap < (size_t)2 * n) {
             if (sm->ev_pt) (void)hipFree(sm->ev_pt);
@@ -1397,6 +1405,20 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                 ev_path = ev_possible = false; // (no room: the full pass)
             } else
                 sm->ev_cap = (size_t)2 * n;
+        }
+        // PAIR events (K <= 128): one event per mover, sorted by (new, old) pair -- the accumulation reads every mover's
+        // record once (k_accumulate_events<.., PAIR>; two events per mover read it twice).  SPKM_NO_PAIR_EVENTS=1: A/B switch
+        pair_ev = ev_path && pair_capable;
+        if (pair_ev && sm->ev_o_cap < (size_t)n + 4096) {
+            if (sm->ev_o) (void)hipFree(sm->ev_o);
+            sm->ev_o = nullptr;
+            sm->ev_o_cap = 0;
+            if (hipMalloc((void**)&sm->ev_o, ((size_t)n + 4096) * 4 + 64) != hipSuccess) {
+                (void)hipGetLastError();
+                sm->ev_o = nullptr;
+                pair_ev = false; // (no room: two events per mover)
+            } else
+                sm->ev_o_cap = (size_t)n + 4096;
         }
         if (ev_path) {
             if ((rc = ensure(ctx, ctx->nk_ev, (size_t)2 * K * 8))) return rc;
@@ -1571,7 +1593,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // (policy.h, few_movers: events while at most a third of the points move).  Round 3 took the events blindly there:
     // 12.1 ms of gathers where the pass takes 8.5 (N = 1e8), 25.0 against 21 ms for a config-5 iteration.
     const bool dual = ev_path && sm->pol.form_on_device() && cl_on && !ctx->sw.no_dual && !ctx->sw.no_sums_only;
-    const unsigned ev_cap = dual ? (unsigned)std::min<unsigned long long>(spkm_policy::event_cap((unsigned long long)n), 0xfffffff0ull) : 0xffffffffu;
+    // (pair events: one per mover, so half the count stands for the same third of the points)
+    const unsigned ev_cap = dual ? (unsigned)std::min<unsigned long long>(spkm_policy::event_cap((unsigned long long)n, pair_ev), 0xfffffff0ull) : 0xffffffffu;
     ctx->last_dual = dual;
     int* cl_need = cl_on ? sm->cl_flags : nullptr;
     int* cl_touched = cl_on ? sm->cl_flags + K : nullptr;
@@ -1602,7 +1625,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
                        lazy_ub ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr,
                        ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap,
-                       (unsigned*)ctx->wgstat.p);
+                       (unsigned*)ctx->wgstat.p, pair_ev ? sm->ev_o : (int*)nullptr);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1612,11 +1635,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p,
                        s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
                        ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap,
-                       (const unsigned*)ctx->wgstat.p, cb);
+                       (const unsigned*)ctx->wgstat.p, cb, pair_ev ? sm->ev_o : (int*)nullptr);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     ctx->last_lib_valid = bounds_ok;
     ctx->last_incremental = ev_path;
     ctx->last_direct_events = false;
+    ctx->last_pair_events = pair_ev;
     if (ev_path) sm->pol.sums_by_events(); else sm->pol.sums_by_full_pass();
     if (ev_path) {
         // ---- incremental call: the per-cluster sums move by the points that changed cluster; no exact pass ----
@@ -1653,6 +1677,53 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
             hipLaunchKernelGGL((k_events_direct<IR>), dim3(1024), dim3(256), 0, ctx->stream, (const char*)sm->rec, sm->rec_R,
                                (const IR*)s->ir, (const double*)s->x, (const int*)sm->ev_pt, (const int*)sm->ev_k, ev_n, p,
+                               s->fixed_s, K, cache_s, cache_c, pair_ev ? (const int*)sm->ev_o : (const int*)nullptr);
+        } else if (pair_ev) {
+            // ---- pair events: two-level counting sort by (new, old), then one slab per run of one pair (update.hip) ----
+            const int Kp = K * (K + 1);
+            constexpr int CH = 8192; // events per chunk of a new-cluster bucket (the second level's work items)
+            const int max_items1 = (int)(n / CH) + K + 1;
+            const int max_items2 = (int)(n / seg_ev) + Kp + 1;
+            int* perm1 = (int*)ctx->perm.p;          // points, by new cluster
+            int* perm2 = (int*)ctx->perm.p + n;      // points, by (new, old) pair
+            if ((rc = ensure(ctx, ctx->perm_o, (size_t)n * 4 + 64))) return rc; // old clusters, by new cluster
+            if ((rc = ensure(ctx, ctx->offs2, (size_t)(Kp + 1) * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->cursor2, (size_t)Kp * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->hist2, (size_t)Kp * 8))) return rc;
+            if ((rc = ensure(ctx, ctx->items2, (size_t)max_items2 * 16))) return rc;
+            if ((rc = ensure(ctx, ctx->items, (size_t)max_items1 * 16))) return rc;
+            int* nitems1 = (int*)ctx->nitems.p + 2;
+            HIP_TRY(hipMemsetAsync(ctx->hist2.p, 0, (size_t)Kp * 8, ctx->stream));
+            hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk_ev.p, K,
+                               CH, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
+                               nitems1, gate_ev, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+            {
+                const size_t sc1 = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
+                if (sc1 > 48 * 1024) {
+                    (void)allow_lds(ctx, (const void*)k_scatter_by_cluster<true>, sc1);
+                    (void)allow_lds(ctx, (const void*)k_scatter_by_cluster<false>, sc1);
+                }
+                hipLaunchKernelGGL(k_scatter_by_cluster<true>, dim3(hb_), dim3(256), sc1, ctx->stream, (const int*)sm->ev_k, 0LL, K,
+                                   (unsigned long long*)ctx->cursor.p, perm1, gate_ev, (const int*)nullptr, ev_n,
+                                   (const int*)sm->ev_pt, (const int*)sm->ev_o, (int*)ctx->perm_o.p);
+            }
+            const int gb = std::min(max_items1, std::max(1, ctx->num_cus) * 8);
+            const size_t l2 = (size_t)((K + 2) & ~1) * 4 + (size_t)(K + 1) * 8;
+            hipLaunchKernelGGL(k_pair_hist, dim3(gb), dim3(256), l2, ctx->stream, (const int*)ctx->perm_o.p,
+                               (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)nitems1, K,
+                               (unsigned long long*)ctx->hist2.p, gate_ev);
+            hipLaunchKernelGGL(k_plan_segments_wide, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->hist2.p, Kp,
+                               seg_ev, (long long*)ctx->offs2.p, (unsigned long long*)ctx->cursor2.p, (int4*)ctx->items2.p,
+                               nitems_ev, gate_ev);
+            hipLaunchKernelGGL(k_pair_scatter, dim3(gb), dim3(256), l2, ctx->stream, (const int*)perm1, (const int*)ctx->perm_o.p,
+                               (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)nitems1, K,
+                               (unsigned long long*)ctx->cursor2.p, perm2, gate_ev);
+            const size_t slab = (size_t)p * 12;
+            const int ab_ev = (int)std::min<long long>(max_items2, std::max<long long>(std::max(1, ctx->num_cus) * 8, 1));
+            if (ctx->tlog_both) HIP_TRY(timing_begin(ctx));
+            hipLaunchKernelGGL((k_accumulate_events<IR, true>), dim3(ab_ev), dim3(256), slab, ctx->stream, (const char*)sm->rec,
+                               sm->rec_R, (const IR*)s->ir, (const double*)s->x, (const int*)perm2,
+                               (const long long*)ctx->offs2.p, (const int4*)ctx->items2.p, (const int*)nitems_ev, p,
                                s->fixed_s, K, cache_s, cache_c);
         } else {
         // (the histogram over the 2 K keys was collected by k_combine_screen / k_assign_list as they appended the events)
@@ -2091,6 +2162,15 @@ extern "C" int spkm_last_screen_mode(spkm_ctx* ctx, int64_t info[8])
         }
         info[7] = ctx->last_pt_mode ? 2 : 0; // 2: point-granular list
     }
+    return SPKM_OK;
+}
+
+extern "C" int spkm_last_events_form(spkm_ctx* ctx, int64_t info[2])
+{
+    if (!ctx || !info) return SPKM_ERR_NULL_ARG;
+    const bool inc = ctx->last_path == 1 && ctx->last_incremental;
+    info[0] = inc ? (ctx->last_direct_events ? 2 : 1) : 0;
+    info[1] = (inc && ctx->last_pair_events) ? 1 : 0;
     return SPKM_OK;
 }
 

@@ -185,7 +185,12 @@ struct spkm_policy {
     // Incremental sums (events) instead of a full accumulation pass: while not too many points move -- at most a third
     // in the previous counted call (an event pair reads the point twice, through a gather: 0.2 ms per million movers at
     // s = 51 against 10.4 ms for a full pass over 1e8 points); no count yet (a run's second call): taken as few.
-    bool few_movers(double n) const { return !movers_known || (double)last_movers * 3.0 <= n; }
+    // pair_events (api.hip: K <= 128): one event per mover, its record read once -- 12.9 ms per 1e8 movers, sort included,
+    // against 8.8 ms for the full pass with its own sort at N = 1e8: events pay up to two thirds of the points; taken up to half.
+    bool few_movers(double n, bool pair_events = false) const
+    {
+        return !movers_known || (double)last_movers * (pair_events ? 2.0 : 3.0) <= n;
+    }
     // ... and a call issued without a count (a run's second: the counters come back one call late; from a random start
     // nearly every point moves there) does not guess: it queues BOTH forms and the device opens one of them once the
     // events are counted (screen.hip, k_pick_form) -- the events while there are at most event_cap(n) of them, two per
@@ -196,5 +201,5 @@ struct spkm_policy {
     void sums_by_full_pass() { ev_pending = false; ev_calls = 0; ev_cum_movers = 0; }
     // the sums are due for a fresh summation (see ev_calls above)
     bool refresh_due(double n) const { return ev_calls >= 256 || (double)ev_cum_movers > 8.0 * n; }
-    static unsigned long long event_cap(unsigned long long n) { return 2ull * (n / 3ull); }
+    static unsigned long long event_cap(unsigned long long n, bool pair_events = false) { return pair_events ? n / 2ull : 2ull * (n / 3ull); }
 };

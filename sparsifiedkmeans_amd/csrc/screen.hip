@@ -938,6 +938,7 @@ __global__ void k_pick_form(unsigned* __restrict__ counters, unsigned ev_cap, in
     counters[19] = full ? 1u : 0u;
     nitems[0] = 0;
     nitems[1] = 0;
+    nitems[2] = 0; // (pair events: the first-level plan's chunk list)
 }
 
 // jc of a fixed-stride shard that was created from records: jc[i] = i * s
@@ -986,8 +987,12 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         unsigned long long* __restrict__ nk,
                                                         int lazy, int* __restrict__ ev_pt, int* __restrict__ ev_k,
                                                         unsigned long long* __restrict__ nk_ev, unsigned ev_cap,
-                                                        unsigned* __restrict__ wgstat)
+                                                        unsigned* __restrict__ wgstat, int* __restrict__ ev_o = nullptr)
 {
+    // ev_o != nullptr: PAIR events -- ONE event per mover, (point, new cluster in ev_k, old cluster or -1 in ev_o), and the
+    // histogram nk_ev over the K new clusters only: the events are then sorted by (new, old) pair and every mover's record
+    // is read once, into its new cluster's sums and out of its old one's (api.hip, k_accumulate_events<.., PAIR>); else
+    // two events per mover, (point, K + old) and (point, new), over 2 K keys, each applied on its own.
     // wgstat[3 b .. 3 b + 2]: workgroup b's ambiguous points, "some assignment changed" flag and movers, as plain stores;
     // k_assign_list (the next launch) adds them up into nlist[1], nlist[5], nlist[14].  One atomic per workgroup and counter
     // on ONE cache line is served at ~10 ns apiece: 3500 workgroups of a settled call's point list (N = 1e8) spent 80 of
@@ -1005,6 +1010,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     // would take tens of milliseconds).  nlist[14] counts the movers in every mode, nlist[16] the events.
     constexpr int EVCAP = 2048;
     __shared__ int s_evp[EVCAP], s_evk[EVCAP];
+    const bool pair = ev_o != nullptr; // (staged as new | (old + 1) << 16 in s_evk: pair events are for K <= 128)
     __shared__ unsigned s_evn, s_evbase, s_mov, s_over; // s_over: the running event count has passed ev_cap -- this workgroup stops collecting events
     const double cum_now = cum ? *cum : 0.0; // lower bounds are stored relative to the accumulated drift (k_bounds_steps)
     // The library's own copy of the assignment (bnd + 2 npad) is kept up to date here and in k_assign_list -- the only
@@ -1038,14 +1044,19 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     }
     if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; s_over = 0u; }
     if (nk) for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
-    if (ev_pt) for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) evc[k] = 0u;
+    if (ev_pt) for (int k = threadIdx.x; k < (pair ? K : 2 * K); k += blockDim.x) evc[k] = 0u;
     __syncthreads();
     unsigned nmov = 0;
     auto flush_events = [&]() { // (whole workgroup)
         if (threadIdx.x == 0) { s_evbase = atomicAdd(nlist + 16, s_evn); if (s_evbase > ev_cap) s_over = 1u; }
         __syncthreads();
         if (s_evbase <= ev_cap)
-            for (unsigned j = threadIdx.x; j < s_evn; j += blockDim.x) { ev_pt[s_evbase + j] = s_evp[j]; ev_k[s_evbase + j] = s_evk[j]; }
+            for (unsigned j = threadIdx.x; j < s_evn; j += blockDim.x) {
+                ev_pt[s_evbase + j] = s_evp[j];
+                const int kv = s_evk[j];
+                ev_k[s_evbase + j] = pair ? (kv & 0xffff) : kv;
+                if (pair) ev_o[s_evbase + j] = (kv >> 16) - 1;
+            }
         __syncthreads();
         if (threadIdx.x == 0) s_evn = 0u;
         __syncthreads();
@@ -1111,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
       // (s_over: the full pass will run whatever else moves, k_pick_form -- no event of this workgroup is needed any more;
       //  the flag changes only inside flush_events, between barriers: the same for every thread of a trip)
       if (ev_pt && !s_over && __syncthreads_or(mover ? 1 : 0)) { // (every thread of the workgroup gets here in every trip; no mover: nothing to stage)
-        const int cnt = mover ? (mv_old >= 0 ? 2 : 1) : 0;
+        const int cnt = mover ? ((mv_old >= 0 && !pair) ? 2 : 1) : 0;
         // exclusive prefix of cnt inside the wave, one LDS atomic per wave for its total
         int incl = cnt;
         for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if ((int)(threadIdx.x & 63) >= off) incl += t; }
@@ -1123,8 +1134,8 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         }
         if (mover) {
             unsigned at = wbase + (unsigned)(incl - cnt);
-            if (mv_old >= 0) { s_evp[at] = (int)i; s_evk[at] = K + mv_old; at++; atomicAdd(&evc[K + mv_old], 1u); }
-            s_evp[at] = (int)i; s_evk[at] = mv_new;
+            if (!pair && mv_old >= 0) { s_evp[at] = (int)i; s_evk[at] = K + mv_old; at++; atomicAdd(&evc[K + mv_old], 1u); }
+            s_evp[at] = (int)i; s_evk[at] = pair ? (mv_new | ((mv_old + 1) << 16)) : mv_new;
             atomicAdd(&evc[mv_new], 1u);
         }
         __syncthreads();
@@ -1149,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         for (int k = threadIdx.x; k < K; k += blockDim.x)
             if (delta[k]) atomicAdd(&nk[k], (unsigned long long)(long long)delta[k]);
     if (ev_pt)
-        for (int k = threadIdx.x; k < 2 * K; k += blockDim.x)
+        for (int k = threadIdx.x; k < (pair ? K : 2 * K); k += blockDim.x)
             if (evc[k]) atomicAdd(&nk_ev[k], (unsigned long long)evc[k]);
 }
 
@@ -1167,8 +1178,10 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      int* __restrict__ ev_k, unsigned* __restrict__ counters,
                                                      const char* __restrict__ rec, int rec_R,
                                                      unsigned long long* __restrict__ nk_ev, unsigned ev_cap,
-                                                     const unsigned* __restrict__ wgstat, int nwg)
+                                                     const unsigned* __restrict__ wgstat, int nwg,
+                                                     int* __restrict__ ev_o = nullptr)
 {
+    // ev_o != nullptr: pair events, one per mover (k_combine_screen)
     // wgstat / nwg: k_combine_screen's per-workgroup statistics (ambiguous points, changed flag, movers); the LAST
     // workgroup of this launch adds them into counters[1], *changed (counters[5]) and counters[14] -- nobody reads those
     // before this kernel has finished
@@ -1260,7 +1273,11 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                         const bool vo = (unsigned)old < (unsigned)K;
                         if (touched) { if (vo) touched[old] = 1; touched[bk] = 1; }
                         if (nk) { if (vo) atomicAdd(&nk[old], ~0ull); atomicAdd(&nk[bk], 1ull); }
-                        if (ev_pt) {
+                        if (ev_pt && ev_o != nullptr) {
+                            const unsigned at = atomicAdd(counters + 16, 1u);
+                            if (at <= ev_cap) { ev_pt[at] = (int)i; ev_k[at] = bk; ev_o[at] = vo ? old : -1; }
+                            atomicAdd(&nk_ev[bk], 1ull);
+                        } else if (ev_pt) {
                             const unsigned at = atomicAdd(counters + 16, vo ? 2u : 1u);
                             if (at <= ev_cap) { // (k_combine_screen: past the cap the events are only counted)
                                 if (vo) { ev_pt[at] = (int)i; ev_k[at] = K + old; }
@@ -1769,10 +1786,10 @@ template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const 
     int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int, int*);
 template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
     const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int);
+    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int, int*);
 
 // ============================================================================================
 // K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through

@@ -349,6 +349,56 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
     if (tid == 0) { offs[K] = s_run_pts; *nitems = s_run_items; }
 }
 
+// The same plan for MANY keys (pair events: K (K + 1) of them, 10^4 at K = 100): every thread owns a contiguous range of keys,
+// one scan over the 256 range totals instead of one per 256 keys (40 scans of 16 barriers took 0.2-0.3 ms per call).
+__global__ __launch_bounds__(256) void k_plan_segments_wide(const unsigned long long* __restrict__ nk, int K, int seg,
+                                                            long long* __restrict__ offs,
+                                                            unsigned long long* __restrict__ cursor,
+                                                            int4* __restrict__ items, int* __restrict__ nitems,
+                                                            const unsigned* __restrict__ gate)
+{
+    __shared__ long long s_pts[256];
+    __shared__ int s_items[256];
+    if (gate != nullptr && *gate == 0u) return;
+    const int tid = threadIdx.x;
+    const int per = (K + 255) / 256;
+    const int k_lo = min(K, tid * per), k_hi = min(K, k_lo + per);
+    long long pts = 0;
+    int its = 0;
+    for (int k = k_lo; k < k_hi; k++) {
+        const long long cnt = (long long)nk[k];
+        pts += cnt;
+        its += (int)((cnt + seg - 1) / seg);
+    }
+    s_pts[tid] = pts;
+    s_items[tid] = its;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const long long a = (tid >= off) ? s_pts[tid - off] : 0;
+        const int b = (tid >= off) ? s_items[tid - off] : 0;
+        __syncthreads();
+        s_pts[tid] += a;
+        s_items[tid] += b;
+        __syncthreads();
+    }
+    long long pbase = s_pts[tid] - pts;
+    int ibase = s_items[tid] - its;
+    for (int k = k_lo; k < k_hi; k++) {
+        const long long cnt = (long long)nk[k];
+        const int nseg = (int)((cnt + seg - 1) / seg);
+        offs[k] = pbase;
+        cursor[k] = (unsigned long long)pbase;
+        for (int sg = 0; sg < nseg; sg++) {
+            const long long st = (long long)sg * seg;
+            const long long len = (cnt - st < seg) ? cnt - st : seg;
+            items[ibase + sg] = make_int4(k, (int)st, (int)len, 0);
+        }
+        pbase += cnt;
+        ibase += nseg;
+    }
+    if (tid == 255) { offs[K] = s_pts[255]; *nitems = s_items[255]; }
+}
+
 // perm[cursor[assign[i]]++] = i, with one global atomic per (block, cluster) via an LDS histogram.
 // VEC: the assignment is read four points at a time (16-B loads; the pointer must be 16-B aligned) -- two passes over
 // 4 B per point are latency bound with one 4-B load per lane in flight.
@@ -358,8 +408,11 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
                                                             int* __restrict__ perm, const unsigned* __restrict__ gate,
                                                             const int* __restrict__ need,
                                                             const unsigned* __restrict__ n_dev = nullptr,
-                                                            const int* __restrict__ ids = nullptr)
+                                                            const int* __restrict__ ids = nullptr,
+                                                            const int* __restrict__ ids2 = nullptr,
+                                                            int* __restrict__ perm2 = nullptr)
 {
+    // ids2 / perm2: a second payload placed like the first (pair events: the mover's old cluster travels with its point)
     // n_dev != nullptr: the number of entries is *n_dev (an event list whose length only the device knows);
     // ids != nullptr: entry i stands for point ids[i] (perm receives ids[i], not i)
     if (n_dev != nullptr) n = (long long)*n_dev;
@@ -410,6 +463,7 @@ __global__ __launch_bounds__(256) void k_scatter_by_cluster(const int* __restric
         } else
             r = atomicAdd(&cnt[k], 1u);
         perm[base[k] + r] = ids != nullptr ? ids[i] : (int)i;
+        if (ids2 != nullptr) perm2[base[k] + r] = ids2[i];
     };
     if constexpr (VEC) {
         const long long hv = lo + ((hi - lo) & ~3LL); // whole groups of four
@@ -530,7 +584,11 @@ __global__ __launch_bounds__(256) void k_accumulate_sorted(const long long* __re
 // same order of magnitude as the summation-order noise of a full pass (1e-16 relative per operation; bar: 1e-6).
 // A cluster no point entered or left is not touched at all: its sums, and with them its centroid, stay bitwise the same.
 // Fixed-stride shards only; rec != nullptr: the record layout (x | ir side by side), else the two arrays.
-template <typename IR>
+// PAIR (round 4): the events were sorted by (new, old) PAIR -- key = new (K + 1) + old, old = K for a mover without a
+// valid old cluster -- so an item is a run of points that all go from one cluster to one other: its slab is added to the
+// new cluster's rows and subtracted from the old one's, and every mover's record is read ONCE (two events per mover, each
+// applied on its own, read it twice: 34 GB of gathers for a third of 1e8 points).
+template <typename IR, bool PAIR = false>
 __global__ __launch_bounds__(256) void k_accumulate_events(const char* __restrict__ rec, int R,
                                                            const IR* __restrict__ ir, const double* __restrict__ x,
                                                            const int* __restrict__ perm,
@@ -547,8 +605,9 @@ __global__ __launch_bounds__(256) void k_accumulate_events(const char* __restric
     for (int item = blockIdx.x; item < *nitems; item += gridDim.x) {
         const int4 it = items[item];
         const int key = it.x;
-        const int k = key >= K ? key - K : key;
-        const double sign = key >= K ? -1.0 : 1.0;
+        const int k = PAIR ? key / (K + 1) : (key >= K ? key - K : key);  // (PAIR: the cluster entered)
+        const int kold = PAIR ? key - k * (K + 1) : -1;                   // (PAIR: the cluster left; K: none)
+        const double sign = (!PAIR && key >= K) ? -1.0 : 1.0;
         const long long start = offs[key] + it.y;
         const int len = it.z;
         for (int r = tid; r < p; r += blockDim.x) { ssum[r] = 0.0; scnt[r] = 0u; }
@@ -603,7 +662,80 @@ __global__ __launch_bounds__(256) void k_accumulate_events(const char* __restric
             if (c) {
                 unsafeAtomicAdd(&sums[(size_t)k * p + r], sign * ssum[r]);
                 unsafeAtomicAdd(&counts[(size_t)k * p + r], sign * (double)c);
+                if (PAIR && kold < K) {
+                    unsafeAtomicAdd(&sums[(size_t)kold * p + r], -ssum[r]);
+                    unsafeAtomicAdd(&counts[(size_t)kold * p + r], -(double)c);
+                }
             }
+        }
+        __syncthreads();
+    }
+}
+
+// Pair events, second level of the sort.  After the placement by NEW cluster (k_scatter_by_cluster over K keys; the old
+// clusters travel as the second payload) the events of bucket b lie together; the work items of that first plan are
+// chunks of one bucket.  k_pair_hist counts, per chunk, the old clusters in an LDS table of K + 1 bins and adds them to
+// hist2[b (K + 1) + old]; k_plan_segments over those K (K + 1) keys gives every pair its range and the accumulation its
+// items; k_pair_scatter walks the same chunks again and places the points: one global atomic per (chunk, old cluster) in
+// each pass -- a one-level sort over 10^4 keys would need an LDS table of that size per workgroup and 10^7 of them.
+__global__ __launch_bounds__(256) void k_pair_hist(const int* __restrict__ olds, const long long* __restrict__ offs1,
+                                                   const int4* __restrict__ items1, const int* __restrict__ nitems1,
+                                                   int K, unsigned long long* __restrict__ hist2,
+                                                   const unsigned* __restrict__ gate)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate != nullptr && *gate == 0u) return;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem); // K + 1
+    for (int item = blockIdx.x; item < *nitems1; item += gridDim.x) {
+        const int4 it = items1[item];
+        const int b = it.x;
+        const long long start = offs1[b] + it.y;
+        const int len = it.z;
+        for (int o = threadIdx.x; o <= K; o += blockDim.x) cnt[o] = 0u;
+        __syncthreads();
+        for (int j = threadIdx.x; j < len; j += blockDim.x) {
+            const int o = olds[start + j];
+            atomicAdd(&cnt[(unsigned)o < (unsigned)K ? o : K], 1u);
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o <= K; o += blockDim.x)
+            if (cnt[o]) atomicAdd(&hist2[(size_t)b * (K + 1) + o], (unsigned long long)cnt[o]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pair_scatter(const int* __restrict__ pts, const int* __restrict__ olds,
+                                                      const long long* __restrict__ offs1,
+                                                      const int4* __restrict__ items1, const int* __restrict__ nitems1,
+                                                      int K, unsigned long long* __restrict__ cursor2,
+                                                      int* __restrict__ perm2, const unsigned* __restrict__ gate)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate != nullptr && *gate == 0u) return;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem);                                     // K + 1
+    unsigned long long* base = reinterpret_cast<unsigned long long*>(cnt + ((K + 2) & ~1)); // K + 1
+    for (int item = blockIdx.x; item < *nitems1; item += gridDim.x) {
+        const int4 it = items1[item];
+        const int b = it.x;
+        const long long start = offs1[b] + it.y;
+        const int len = it.z;
+        for (int o = threadIdx.x; o <= K; o += blockDim.x) cnt[o] = 0u;
+        __syncthreads();
+        for (int j = threadIdx.x; j < len; j += blockDim.x) {
+            const int o = olds[start + j];
+            atomicAdd(&cnt[(unsigned)o < (unsigned)K ? o : K], 1u);
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o <= K; o += blockDim.x) {
+            base[o] = cnt[o] ? atomicAdd(&cursor2[(size_t)b * (K + 1) + o], (unsigned long long)cnt[o]) : 0ull;
+            cnt[o] = 0u;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < len; j += blockDim.x) {
+            const int oo = olds[start + j];
+            const int o = (unsigned)oo < (unsigned)K ? oo : K;
+            const unsigned r = atomicAdd(&cnt[o], 1u);
+            perm2[base[o] + r] = pts[start + j];
         }
         __syncthreads();
     }
@@ -619,8 +751,9 @@ __global__ __launch_bounds__(256) void k_events_direct(const char* __restrict__ 
                                                        const double* __restrict__ x, const int* __restrict__ ev_pt,
                                                        const int* __restrict__ ev_k, const unsigned* __restrict__ n_ev,
                                                        int p, int s, int K, double* __restrict__ sums,
-                                                       double* __restrict__ counts)
+                                                       double* __restrict__ counts, const int* __restrict__ ev_o = nullptr)
 {
+    // ev_o != nullptr: pair events (one per mover: into cluster ev_k, out of cluster ev_o unless that is -1)
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -628,8 +761,9 @@ __global__ __launch_bounds__(256) void k_events_direct(const char* __restrict__ 
     for (long long e = wave; e < cnt; e += nwaves) {
         const long long i = (long long)(unsigned)ev_pt[e];
         const int key = ev_k[e];
-        const int k = key >= K ? key - K : key;
-        const double sign = key >= K ? -1.0 : 1.0;
+        const int k = (ev_o == nullptr && key >= K) ? key - K : key;
+        const double sign = (ev_o == nullptr && key >= K) ? -1.0 : 1.0;
+        const int kold = ev_o != nullptr ? ev_o[e] : -1;
         for (int j = lane; j < s; j += 64) {
             double xe;
             int re;
@@ -640,6 +774,10 @@ __global__ __launch_bounds__(256) void k_events_direct(const char* __restrict__ 
             } else { xe = x[i * s + j]; re = (int)ir[i * s + j]; }
             unsafeAtomicAdd(&sums[(size_t)k * p + re], sign * xe);
             unsafeAtomicAdd(&counts[(size_t)k * p + re], sign);
+            if ((unsigned)kold < (unsigned)K) {
+                unsafeAtomicAdd(&sums[(size_t)kold * p + re], -xe);
+                unsafeAtomicAdd(&counts[(size_t)kold * p + re], -1.0);
+            }
         }
     }
 }

@@ -315,6 +315,13 @@ class LloydEngine:
         _lib.check(_lib.lib().spkm_last_screen_mode(self.ctx.handle, a))
         return tuple(int(v) for v in a)
 
+    def last_events_form(self) -> tuple[int, int]:
+        """(0 not incremental / 1 events sorted by cluster / 2 applied one by one, 1 if pair events: one per mover, its
+        record read once) of the last fused call -- spkm_last_events_form."""
+        a = (C.c_int64 * 2)()
+        _lib.check(_lib.lib().spkm_last_events_form(self.ctx.handle, a))
+        return int(a[0]), int(a[1])
+
     def iterate(self, centers: torch.Tensor, want_mind: bool = True):
         """One full Lloyd iteration in place on ``centers``; returns the device tensor
         [dff^2, obj^2] (no host sync).  One library call (spkm_lloyd_iter: fused assignment + accumulation, the

@@ -27,12 +27,14 @@ void pol_launched(void* p, int rounds_all, int rounds, int hinted, int late, int
 int pol_blocks_next(void* p) { return ((spkm_policy*)p)->blocks_next; }
 int pol_pt_next(void* p) { return ((spkm_policy*)p)->pt_next; }
 int pol_few_movers(void* p, double n) { return ((spkm_policy*)p)->few_movers(n); }
+int pol_few_movers_pair(void* p, double n) { return ((spkm_policy*)p)->few_movers(n, true); }
 void pol_sums_by_events(void* p) { ((spkm_policy*)p)->sums_by_events(); }
 void pol_sums_by_full_pass(void* p) { ((spkm_policy*)p)->sums_by_full_pass(); }
 int pol_refresh_due(void* p, double n) { return ((spkm_policy*)p)->refresh_due(n); }
 int pol_form_on_device(void* p) { return ((spkm_policy*)p)->form_on_device(); }
 int pol_events_direct(void* p) { return ((spkm_policy*)p)->events_direct(); }
 unsigned long long pol_event_cap(unsigned long long n) { return spkm_policy::event_cap(n); }
+unsigned long long pol_event_cap_pair(unsigned long long n) { return spkm_policy::event_cap(n, true); }
 int pol_quad_split(int nr) { return quad_split(nr); }
 int pol_quad_split_late(int nr) { return quad_split_late(nr); }
 }

@@ -913,6 +913,64 @@ def test_few_movers_are_applied_one_by_one_and_give_the_members_sums(gpu_ctx, or
         assert 4 not in forms, forms
 
 
+@pytest.mark.parametrize("pair,K", [(True, 12), (False, 12), (True, 100), (True, 128), (None, 130)])
+def test_pair_events_read_a_mover_once_and_give_the_members_sums(gpu_ctx, oracle, monkeypatch, pair, K):
+    """Sorted events in their two formats: PAIR events (K <= 128: one event per mover, two-level counting sort by (new, old),
+    one slab per run of a pair added to the new cluster's rows and subtracted from the old one's -- a mover's record is
+    read once) and two events per mover over 2 K keys (SPKM_NO_PAIR_EVENTS=1, and always for K > 128).  Direct application
+    is switched off so that every incremental call sorts.  Drifts that move some dozen points, none, a jump that moves a
+    third: assignments and per-row counts the oracle's, sums to 1e-10, whatever the format."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, gopt = 256, 30000, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=9, noise=1.0)
+    rng = np.random.default_rng(4)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    s = synth.small_p_of(gopt, p)
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    gam = s / p
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    set_switch(monkeypatch, gpu_ctx, "SPKM_NO_PRUNE")
+    set_switch(monkeypatch, gpu_ctx, "SPKM_NO_DIRECT_EVENTS")
+    set_switch(monkeypatch, gpu_ctx, "SPKM_NO_PAIR_EVENTS", pair is False)
+    shard.reset_policy()
+    shard.set_lazy_stats(True)
+    eng = LloydEngine(shard, K, gam)
+    jc, ir, x = parts(Y)
+    base = oracle.mix(centres, d, p) * gam
+    scale = np.abs(base).max()
+    jump = base.copy()
+    q = max(4, K // 3)
+    jump[:, :q] = base[:, np.roll(np.arange(q), 1)]                   # a third of the centroids trade places
+    seq = [("drift", 0.0), ("drift", 6e-3), ("drift", 9e-3), ("drift", 9e-3), ("drift", 12e-3), ("jump", 12e-3), ("drift", 12e-3),
+           ("drift", 15e-3), ("jump", 15e-3)]
+    forms, movers = [], []
+    prev = None
+    for it, (what, eps) in enumerate(seq):
+        Cm = (jump if what == "jump" else base) + eps * scale * np.random.default_rng(300 + int(eps * 1e4)).standard_normal((p, K))
+        c = torch.tensor(np.ascontiguousarray(Cm.T), device="cuda")
+        eng.assign_accumulate_step(c, want_mind=False)
+        torch.cuda.synchronize()
+        forms.append((eng.last_screen_mode()[6],) + eng.last_events_form())
+        ra, rd = oracle.assign(p, n, jc, ir, x, Cm, gam)
+        assert np.array_equal(eng.assign.cpu().numpy(), ra), (it, what)
+        movers.append(-1 if prev is None else int(np.count_nonzero(ra != prev)))
+        prev = ra
+        S, Cnt, nk = oracle.accumulate(p, n, K, jc, ir, x, ra)
+        red = eng.reduce.cpu().numpy()
+        pk = p * K
+        assert np.array_equal(red[pk:2 * pk].reshape(K, p).T, Cnt), (it, what, forms, movers)
+        assert np.array_equal(eng.nk.cpu().numpy(), nk), (it, what)
+        assert np.abs(red[:pk].reshape(K, p).T - S).max() <= 1e-10 * np.abs(S).max(), (it, what, forms, movers)
+    shard.set_lazy_stats(False)
+    want_pair = 1 if (pair is True) else 0
+    inc = [f for f in forms if f[0] == 2]
+    assert len(inc) >= 4, (forms, movers)                              # the drifts and the first jump are incremental calls
+    assert all(f[1] == 1 and f[2] == want_pair for f in inc), (forms, movers)   # sorted, in the expected format
+    assert forms[5][0] == 2 and movers[5] > 2048, (forms, movers)      # the jump call itself sorted thousands of events
+
+
 def test_a_fresh_contexts_second_lazy_call_is_already_incremental(oracle, monkeypatch):
     """A context's first fused call allocates most of its buffers AFTER queueing its counting sort; those first-time
     allocations must not make the library forget the sort (and with it the previous assignment and cluster sizes): the

@@ -28,6 +28,7 @@ def pol(tmp_path_factory):
     L.pol_pt_next.argtypes = [C.c_void_p]
     L.pol_blocks_next.argtypes = [C.c_void_p]
     L.pol_few_movers.argtypes = [C.c_void_p, C.c_double]
+    L.pol_few_movers_pair.argtypes = [C.c_void_p, C.c_double]
     L.pol_form_on_device.argtypes = [C.c_void_p]
     L.pol_events_direct.argtypes = [C.c_void_p]
     L.pol_sums_by_events.argtypes = [C.c_void_p]
@@ -35,6 +36,8 @@ def pol(tmp_path_factory):
     L.pol_refresh_due.argtypes = [C.c_void_p, C.c_double]
     L.pol_event_cap.argtypes = [C.c_uint64]
     L.pol_event_cap.restype = C.c_uint64
+    L.pol_event_cap_pair.argtypes = [C.c_uint64]
+    L.pol_event_cap_pair.restype = C.c_uint64
     return L
 
 
@@ -215,6 +218,14 @@ def test_incremental_sums_while_at_most_a_third_of_the_points_move(pol):
     assert pol.pol_few_movers(w.p, N) == 1
     pol.pol_reset(w.p)
     assert pol.pol_few_movers(w.p, N) == 1
+    # pair events (one per mover, its record read once): the bar is half of the points, on the host and on the device
+    w.call(); w.seen()
+    w.call(); w.seen(movers=0.45 * N)
+    assert pol.pol_few_movers(w.p, N) == 0 and pol.pol_few_movers_pair(w.p, N) == 1
+    w.call(); w.seen(movers=0.55 * N)
+    assert pol.pol_few_movers_pair(w.p, N) == 0
+    for n in (0, 1, 2, 3, 100, 10**8):
+        assert pol.pol_event_cap_pair(n) == n // 2
 
 
 def test_a_call_without_a_mover_count_lets_the_device_choose_the_form(pol):
