@@ -64,6 +64,7 @@ struct spkm_switches {
     bool no_block_skip = false;   // SPKM_NO_BLOCK_SKIP: the carried-bounds test reads every point (no per-block summaries)
     bool no_dual = false;         // SPKM_NO_DUAL: a run's second lazy call takes the events whatever moves (round 3) instead of deciding on the device
     bool no_pair_events = false;   // SPKM_NO_PAIR_EVENTS: two events per mover over 2 K keys (each applied on its own: the record is read twice) also for K <= 128
+    bool force_pair_events = false; // SPKM_FORCE_PAIR_EVENTS: pair events also when few movers per pair are expected (tests)
     bool no_direct_events = false; // SPKM_NO_DIRECT_EVENTS: a lazy call with few movers still sorts its events (plan, placement, slab kernel)
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
 };
@@ -92,6 +93,7 @@ static spkm_switches read_switches()
     w.no_block_skip = on("SPKM_NO_BLOCK_SKIP");
     w.no_direct_events = on("SPKM_NO_DIRECT_EVENTS");
     w.no_pair_events = on("SPKM_NO_PAIR_EVENTS");
+    w.force_pair_events = on("SPKM_FORCE_PAIR_EVENTS");
     return w;
 }
 
@@ -1389,7 +1391,13 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // (what an incremental call needs is allocated by the first lazy call, whatever path that one takes: a run's
         //  first call is the one that builds things; 3 x 8 B per point here, and the sort buffers at their event sizes below)
         ev_possible = sm->lazy && !ctx->sw.no_incremental && !ctx->sw.no_sort_reuse && (size_t)p * 12 <= 64 * 1024;
-        const bool pair_capable = K <= 128 && !ctx->sw.no_pair_events; // (pair events, below: the bar for "few" is higher)
+        // (pair events, below: the bar for "few" is higher.  Only while a pair's run is long enough to pay for its slab --
+        //  flushed to BOTH clusters, 4 p atomics per work item -- and for the four extra launches of the second sort level:
+        //  at least 256 movers per pair expected, from the previous call's count (n / 3 while there is none).  N = 1e8,
+        //  K = 100: 3300 per pair in the iterations that matter; config 3, 6e4 points: never -- 0.28 against 0.16 ms there)
+        const unsigned long long est_movers = sm->pol.movers_known ? sm->pol.last_movers : (unsigned long long)n / 3ull;
+        const bool pair_capable = K <= 128 && !ctx->sw.no_pair_events &&
+                                  (est_movers >= 256ull * (unsigned long long)K * (unsigned long long)(K + 1) || ctx->sw.force_pair_events);
         ev_path = ev_possible && d_mind == nullptr && kept && sm->cl_valid && sm->pol.few_movers((double)n, pair_capable) &&
                   !sm->pol.refresh_due((double)n);
         if (ev_possible && sm->ev_cap < (size_t)2 * n) {
@@ -1693,10 +1701,10 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             if ((rc = ensure(ctx, ctx->items2, (size_t)max_items2 * 16))) return rc;
             if ((rc = ensure(ctx, ctx->items, (size_t)max_items1 * 16))) return rc;
             int* nitems1 = (int*)ctx->nitems.p + 2;
-            HIP_TRY(hipMemsetAsync(ctx->hist2.p, 0, (size_t)Kp * 8, ctx->stream));
             hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->nk_ev.p, K,
                                CH, (long long*)ctx->offs.p, (unsigned long long*)ctx->cursor.p, (int4*)ctx->items.p,
-                               nitems1, gate_ev, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+                               nitems1, gate_ev, (const int*)nullptr, (int*)nullptr, (int*)nullptr,
+                               (unsigned long long*)ctx->hist2.p, Kp); // (clears the second level's histogram on the way)
             {
                 const size_t sc1 = (size_t)((K + 1) & ~1) * 4 + (size_t)K * 12;
                 if (sc1 > 48 * 1024) {
@@ -1712,7 +1720,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             hipLaunchKernelGGL(k_pair_hist, dim3(gb), dim3(256), l2, ctx->stream, (const int*)ctx->perm_o.p,
                                (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)nitems1, K,
                                (unsigned long long*)ctx->hist2.p, gate_ev);
-            hipLaunchKernelGGL(k_plan_segments_wide, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->hist2.p, Kp,
+            HIP_TRY(allow_lds(ctx, (const void*)k_plan_segments_wide, (size_t)128 * 129 * 4)); // (66 KB of dynamic LDS at K = 128)
+            hipLaunchKernelGGL(k_plan_segments_wide, dim3(1), dim3(1024), (size_t)Kp * 4, ctx->stream, (const unsigned long long*)ctx->hist2.p, Kp,
                                seg_ev, (long long*)ctx->offs2.p, (unsigned long long*)ctx->cursor2.p, (int4*)ctx->items2.p,
                                nitems_ev, gate_ev);
             hipLaunchKernelGGL(k_pair_scatter, dim3(gb), dim3(256), l2, ctx->stream, (const int*)perm1, (const int*)ctx->perm_o.p,

@@ -304,10 +304,13 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
                                                        int4* __restrict__ items, int* __restrict__ nitems,
                                                        const unsigned* __restrict__ gate,
                                                        const int* __restrict__ need = nullptr,  // items only for need[k] != 0
-                                                       int* __restrict__ ibeg = nullptr, int* __restrict__ icnt = nullptr)
+                                                       int* __restrict__ ibeg = nullptr, int* __restrict__ icnt = nullptr,
+                                                       unsigned long long* __restrict__ zero = nullptr, int zero_n = 0)
 {
     __shared__ long long s_pts[256];
     if (gate != nullptr && *gate == 0u) return; // nothing changed: the previous plan stands (see k_hist)
+    // zero: a table the NEXT kernels of the stream accumulate into (pair events: the second-level histogram), cleared on the way
+    for (int t = threadIdx.x; t < zero_n; t += blockDim.x) zero[t] = 0ull;
     __shared__ int s_items[256];
     __shared__ long long s_run_pts;
     __shared__ int s_run_items;
@@ -349,54 +352,64 @@ __global__ __launch_bounds__(256) void k_plan_segments(const unsigned long long*
     if (tid == 0) { offs[K] = s_run_pts; *nitems = s_run_items; }
 }
 
-// The same plan for MANY keys (pair events: K (K + 1) of them, 10^4 at K = 100): every thread owns a contiguous range of keys,
-// one scan over the 256 range totals instead of one per 256 keys (40 scans of 16 barriers took 0.2-0.3 ms per call).
-__global__ __launch_bounds__(256) void k_plan_segments_wide(const unsigned long long* __restrict__ nk, int K, int seg,
-                                                            long long* __restrict__ offs,
-                                                            unsigned long long* __restrict__ cursor,
-                                                            int4* __restrict__ items, int* __restrict__ nitems,
-                                                            const unsigned* __restrict__ gate)
+// The same plan for MANY keys (pair events: K (K + 1) of them, 10^4 at K = 100).  One workgroup of 1024 threads; the counts
+// are staged in LDS with coalesced loads (u32: an event list holds fewer than 2^31), every thread owns a contiguous range of
+// keys, ONE scan over the 1024 range totals, and the offsets go back through LDS so that the stores are coalesced too
+// (a scan per 256 keys took 0.2-0.3 ms per call, a strided walk over global memory 0.12 -- fixed costs that an eighth of
+// the data pays in full).  Dynamic LDS: 4 K bytes.
+__global__ __launch_bounds__(1024) void k_plan_segments_wide(const unsigned long long* __restrict__ nk, int K, int seg,
+                                                             long long* __restrict__ offs,
+                                                             unsigned long long* __restrict__ cursor,
+                                                             int4* __restrict__ items, int* __restrict__ nitems,
+                                                             const unsigned* __restrict__ gate)
 {
-    __shared__ long long s_pts[256];
-    __shared__ int s_items[256];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned s_pts[1024];
+    __shared__ int s_items[1024];
     if (gate != nullptr && *gate == 0u) return;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem); // K counts, then K offsets in place
     const int tid = threadIdx.x;
-    const int per = (K + 255) / 256;
+    for (int k = tid; k < K; k += 1024) cnt[k] = (unsigned)nk[k];
+    __syncthreads();
+    const int per = (K + 1023) / 1024;
     const int k_lo = min(K, tid * per), k_hi = min(K, k_lo + per);
-    long long pts = 0;
+    unsigned pts = 0;
     int its = 0;
     for (int k = k_lo; k < k_hi; k++) {
-        const long long cnt = (long long)nk[k];
-        pts += cnt;
-        its += (int)((cnt + seg - 1) / seg);
+        pts += cnt[k];
+        its += (int)((cnt[k] + (unsigned)seg - 1u) / (unsigned)seg);
     }
     s_pts[tid] = pts;
     s_items[tid] = its;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const long long a = (tid >= off) ? s_pts[tid - off] : 0;
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned a = (tid >= off) ? s_pts[tid - off] : 0u;
         const int b = (tid >= off) ? s_items[tid - off] : 0;
         __syncthreads();
         s_pts[tid] += a;
         s_items[tid] += b;
         __syncthreads();
     }
-    long long pbase = s_pts[tid] - pts;
+    unsigned pbase = s_pts[tid] - pts;
     int ibase = s_items[tid] - its;
     for (int k = k_lo; k < k_hi; k++) {
-        const long long cnt = (long long)nk[k];
-        const int nseg = (int)((cnt + seg - 1) / seg);
-        offs[k] = pbase;
-        cursor[k] = (unsigned long long)pbase;
+        const unsigned c = cnt[k];
+        const int nseg = (int)((c + (unsigned)seg - 1u) / (unsigned)seg);
         for (int sg = 0; sg < nseg; sg++) {
-            const long long st = (long long)sg * seg;
-            const long long len = (cnt - st < seg) ? cnt - st : seg;
+            const unsigned st = (unsigned)sg * (unsigned)seg;
+            const unsigned len = (c - st < (unsigned)seg) ? c - st : (unsigned)seg;
             items[ibase + sg] = make_int4(k, (int)st, (int)len, 0);
         }
-        pbase += cnt;
+        cnt[k] = pbase; // (the count is not needed again: the slot becomes the key's offset)
+        pbase += c;
         ibase += nseg;
     }
-    if (tid == 255) { offs[K] = s_pts[255]; *nitems = s_items[255]; }
+    __syncthreads();
+    for (int k = tid; k < K; k += 1024) {
+        offs[k] = (long long)cnt[k];
+        cursor[k] = (unsigned long long)cnt[k];
+    }
+    if (tid == 1023) { offs[K] = (long long)s_pts[1023]; *nitems = s_items[1023]; }
 }
 
 // perm[cursor[assign[i]]++] = i, with one global atomic per (block, cluster) via an LDS histogram.

@@ -934,6 +934,7 @@ def test_pair_events_read_a_mover_once_and_give_the_members_sums(gpu_ctx, oracle
     set_switch(monkeypatch, gpu_ctx, "SPKM_NO_PRUNE")
     set_switch(monkeypatch, gpu_ctx, "SPKM_NO_DIRECT_EVENTS")
     set_switch(monkeypatch, gpu_ctx, "SPKM_NO_PAIR_EVENTS", pair is False)
+    set_switch(monkeypatch, gpu_ctx, "SPKM_FORCE_PAIR_EVENTS")         # (by itself the library takes pairs when it expects >= 256 movers per pair)
     shard.reset_policy()
     shard.set_lazy_stats(True)
     eng = LloydEngine(shard, K, gam)
