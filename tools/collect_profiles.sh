@@ -54,7 +54,8 @@ rec('void k_screen_quad<13, unsigned short, 2, false>', None, b_iter, "hinted fo
 rec('void k_screen_quad<13, unsigned short, 1, false>', None, None, "hinted / two-phase form with the early split (3 of 13 rounds); most launches run over a short list of steps")
 rec('void k_exact_accumulate_rec<unsigned short, 4, true, false>', 'k_exact_accumulate', b_acc, "full accumulation pass over the record layout, sums only (a lazy run's first call): values + 16-bit row ids once, permutation in; bytes as SURVEY 8(d)'s separate accumulation pass (the upper-bound store it no longer does included)")
 rec('void k_exact_accumulate_rec<unsigned short, 4, false, true>', None, b_acc, "distances + statistics on demand (once per run): the same records, no sums")
-rec('void k_accumulate_events<unsigned short>', None, None, "incremental calls: the points that changed cluster, each read twice (out of its old cluster's sums, into its new one's); bytes = 2 x movers x 512 B")
+rec('void k_accumulate_events<unsigned short, true>', None, None, "incremental calls, pair events: the points that changed cluster, each read ONCE (one slab per run of an (old, new) pair, added to the new cluster's rows and subtracted from the old one's); bytes = movers x 512 B")
+rec('void k_accumulate_events<unsigned short, false>', None, None, "incremental calls with few movers per pair: two events per mover, each read on its own; bytes = 2 x movers x 512 B")
 # launch-weighted mean over every form of the screen kernel in the profiled run (its 25 launches: 5 warm-up + 20 timed)
 tot_b = tot_d = 0.0
 forms = []
