@@ -71,6 +71,11 @@ def main():
                          "library builds its layouts from them on the first call and the arrays are released afterwards: the "
                          "entries exist twice for a moment)")
     ap.add_argument("--no-regimes", action="store_true", help="skip the traced runs to convergence (quick experiments)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this invocation (two short child runs of this script under "
+                         "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, before the dataset is generated; single GPU, "
+                         "screen path only): the figure then comes from the committed profile and says so")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # (a child run of the PMC passes)
     ap.add_argument("--workload", choices=["headline", "config3", "config5"], default="headline",
                     help="headline: BASELINE.json's metric config (N=1e8, d=1024, K=100).  config3: MNIST-shaped "
                          "60000 x 784 -> 1024, K=10.  config5: one GPU's shard of the 1e9 x 784 one-pass config "
@@ -128,6 +133,11 @@ def main():
             allreduce_via = f"torch.distributed.all_reduce ({dist.get_backend()}); libspkm communicator unavailable: {e}"
     n_total = int(args.n_total)
     p, K = args.dim, args.clusters
+    # roofline.traffic, measured in THIS invocation: HBM bytes of the full-work launch of the assignment kernel from two
+    # counter passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc only, no trace domain)
+    live_pmc = None
+    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child and args.workload != "config5":
+        live_pmc = pmc_passes(args)
     first = rank * n_total // world
     n_local = (rank + 1) * n_total // world - first
 
@@ -206,6 +216,7 @@ def main():
             self.restart()
             self.runs_completed, self.run_lengths = 0, []
             self.forms = []
+            self.calls, self.cold_calls = 0, []     # fused calls issued / which of them were a run's first (cold) iteration
 
         def restart(self):
             self.centers.copy_(self.c0)
@@ -217,6 +228,9 @@ def main():
             self.prev.copy_(self.centers)
             out = self.eng.iterate(self.centers, want_mind=False).cpu().numpy()   # host sync: the driver needs dff to decide
             self.it += 1
+            if self.it == 1:
+                self.cold_calls.append(self.calls)
+            self.calls += 1
             if DUMP:   # diagnostics: the form each call took (rounds for all centroids, early-finished pairs, skipped steps)
                 md = self.eng.last_screen_mode()
                 self.forms.append((self.it, md[0], self.eng.last_screen_rounds()[0], md[3], md[4]))
@@ -285,6 +299,8 @@ def main():
         torch.cuda.empty_cache()
     loop.restart()                                  # the timed steps start a run, whatever W was
     loop.runs_completed, loop.run_lengths = 0, []
+    loop.calls, loop.cold_calls = 0, []
+    work0 = loop.eng.screen_work_totals()                                  # running totals of screen rounds (executed, full-work)
     skipped0 = loop.eng.last_screen_mode()[5] if args.warmup > 0 else 0   # running total of steps skipped so far
     acc_pts0 = loop.eng.exact_pass_points()[0]                             # ... and of points the exact pass streamed
     _lib.check(L.spkm_timing_log(ctx.handle, 2))   # screen path: two pairs per call (screen, exact accumulation)
@@ -299,6 +315,23 @@ def main():
         elapsed = float(t.item())
 
     eng = loop.eng
+    # the exchange as the library saw it (a SCALE record then proves RCCL ran over N ranks) and what ONE all-reduce of the
+    # reduce buffer costs here, timed by itself after the window (20 back-to-back, barrier on both sides, max over ranks)
+    from sparsifiedkmeans_amd.engine import comm_info
+    c_n, c_r = comm_info(ctx)
+    exchange = {"library_comm_nranks": c_n, "library_comm_rank": c_r, "world_size": world, "reduce_buffer_bytes": int(eng.reduce.numel() * 8),
+                "allreduce_ms": None}
+    if world > 1:
+        keep = eng.reduce.clone()
+        sync_all()
+        ta = time.perf_counter()
+        for _ in range(20):
+            eng.allreduce_step()
+        sync_all()
+        dt_ar = torch.tensor([(time.perf_counter() - ta) / 20.0 * 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt_ar, op=dist.ReduceOp.MAX)
+        exchange["allreduce_ms"] = float(dt_ar.item())
+        eng.reduce.copy_(keep)
     path, listed = eng.last_path_info()
     mode = eng.last_screen_mode()
     kms = read_tlog(2 * max(args.steps, 1))
@@ -310,19 +343,33 @@ def main():
         screen_ms, acc_ms = float(kms[0::2].mean()), float(kms[1::2].mean())
     else:                                       # all-exact path (or a mix after a back-off): the tile kernel only
         screen_ms, acc_ms = (float(kms.mean()) if kms.size else float("nan")), 0.0
-    # share of the screen's 16-point steps that the timed launches actually processed (the others were skipped on the
-    # bounds carried between calls): the screen is credited with that share of the algorithmic bytes only
+    # What the timed window's screen launches did, two ways: the share of their 16-point steps they entered at all (the
+    # others were skipped on the bounds carried between calls), and -- what the window's byte credit is weighted by -- the
+    # share of their ROUNDS they executed for all centroids (a step that the two-phase forms finish after A of NR rounds is
+    # credited A / NR, not 1: spkm_screen_work_totals, counted on the device)
     done = 1.0 - (mode[5] - skipped0) / (steps_per_tile * args.steps) if path == 1 and steps_per_tile else 1.0
+    work1 = eng.screen_work_totals()
+    rounds_share = ((work1[0] - work0[0]) / (work1[1] - work0[1])) if path == 1 and work1[1] > work0[1] else done
     # share of the points the exact pass streamed in the timed launches (clusters that no point left or entered and whose
     # centroid did not move are not streamed again): it is credited with that share of its bytes only
     acc_share = (eng.exact_pass_points()[0] - acc_pts0) / (n_local * args.steps) if path == 1 and n_local else 1.0
     scr_name = dominant_kernel(path, s)
-    rl_screen = roofline_obj(scr_name, screen_ms, int(b_screen * done),
-                             f"assignment kernel; mean over the timed launches, which processed {done:.3f} of their 16-point "
-                             "steps (the rest skipped on carried bounds; "
-                             + ("SURVEY 8(d) bytes of an iteration" if b_screen == b_iter else
-                                "single centroid tile: the bytes of its own f32 / u16 copy + its 12-B results, less than SURVEY 8(d)'s 632 B per point")
-                             + " scaled by that share).  VALU-issue / LDS bound at K=100, not HBM bound (DESIGN.md section 4)")
+    bytes_note = ("SURVEY 8(d) bytes of an iteration" if b_screen == b_iter else
+                  "single centroid tile: the bytes of its own f32 / u16 copy + its 12-B results, less than SURVEY 8(d)'s 632 B per point")
+    # (1) THE roofline quantity: the launch that does ALL the work -- the plain form over every 16-point step,
+    # a run's first (cold) iteration -- against an iteration's algorithmic bytes.  The timed window always begins with one.
+    cold = [c for c in loop.cold_calls if 2 * c < kms.size] if path == 1 and kms.size == 2 * args.steps else []
+    full_ms = float(np.mean([kms[2 * c] for c in cold])) if cold else (screen_ms if path != 1 else float("nan"))
+    rl_full = roofline_obj(scr_name, full_ms, int(b_screen),
+                           f"assignment kernel, the launch that does all the work: every 16-point step, every round, all K centroids "
+                           f"(the cold first iteration of a run; {len(cold)} such launch(es) in the timed window, HIP events on the "
+                           f"library's stream); {bytes_note}.  VALU / LDS bound under the power cap at K=100, not HBM bound (DESIGN.md section 4)")
+    # (2) the window's mean launch under the share model (what the timed steps mix: plain, hinted and list forms)
+    rl_screen = roofline_obj(scr_name, screen_ms, int(b_screen * rounds_share),
+                             f"assignment kernel; mean over the {args.steps} timed launches, which executed {rounds_share:.3f} of their "
+                             f"rounds for all centroids ({done:.3f} of their 16-point steps were entered at all; the rest skipped on "
+                             f"carried bounds, steps finished early by the two-phase forms credited by the rounds they ran); {bytes_note} "
+                             "scaled by the rounds share -- a work-avoidance figure, not the section 8(d) roofline quantity")
     rl_acc = roofline_obj("k_exact_accumulate", acc_ms, int(b_acc * acc_share),
                           f"accumulation pass (k_exact_accumulate_rec over every member, or k_accumulate_stream on small K x p; in "
                           "incremental calls k_accumulate_events over the points that changed cluster, credited 0 streamed points); "
@@ -330,12 +377,22 @@ def main():
                           "HBM bound: one pass over the f64 values and row ids in counting-sort order, reference arithmetic "
                           "for each point's distance to its centroid fused with the per-cluster sums (DESIGN.md section 4.2); "
                           "bytes = nnz*(8+2) + n*8 + 16*p*K, all streamed in every launch") if acc_ms > 0 else None
-    # top-level roofline: the kernel that took more of the timed region (both are always listed under by_kernel, each
-    # with ONE byte model, so either can be followed from round to round)
-    top = rl_acc if (rl_acc and acc_ms > screen_ms) else rl_screen
+    # traffic: HBM bytes per launch of the full-work form -- measured by this invocation's own counter passes
+    # (pmc_passes), else read from the committed profile of the same workload and SAID so
+    if live_pmc and live_pmc.get("hbm_bytes_per_launch"):
+        rl_full["traffic"] = live_pmc["hbm_bytes_per_launch"]
+        rl_full["traffic_over_algorithmic"] = live_pmc["hbm_bytes_per_launch"] / b_screen if b_screen else None
+        rl_full["traffic_source"] = {"source": "pmc passes of this invocation", **{k: v for k, v in live_pmc.items() if k != "hbm_bytes_per_launch"}}
+    else:
+        t, ratio, which = pmc_traffic(scr_name, n_local, K, p2, args.start)
+        rl_full["traffic"], rl_full["traffic_over_algorithmic"] = t, ratio
+        rl_full["traffic_source"] = {"source": "committed profile" if t else "none", "record": which, "file": "profiles/pmc_latest.json",
+                                     "why": (live_pmc or {}).get("error", "--no-pmc" if args.no_pmc else "not a single-GPU screen run")}
     for rl in (rl_screen, rl_acc):
-        if rl:   # HBM bytes per launch from the committed PMC passes, and their ratio to the same launches' algorithmic bytes
-            rl["traffic"], rl["traffic_over_algorithmic"], rl["traffic_source"] = pmc_traffic(rl["kernel"], n_local, K, p2, args.start)
+        if rl:   # (by_kernel: the committed passes' figures for the window's kernels, each marked as such)
+            t, ratio, which = pmc_traffic(rl["kernel"], n_local, K, p2, args.start)
+            rl["traffic"], rl["traffic_over_algorithmic"] = t, ratio
+            rl["traffic_source"] = {"source": "committed profile" if t else "none", "record": which, "file": "profiles/pmc_latest.json"}
     # the timed WINDOW's launches (plain, hinted and list forms mixed): launch-weighted HBM bytes from the committed PMC passes
     for rl in (rl_screen, rl_acc):
         if rl:
@@ -346,11 +403,12 @@ def main():
     # the VALU wall of the screen's formulation: packed f32 add + fma per (stored entry, centroid
     # pair), 4 issue cycles each on 1024 SIMDs, at the clock the part holds under this kernel (profiles/pmc_latest.json:
     # GRBM_GUI_ACTIVE over the traced duration) and at the 2.4 GHz it is specified for
-    if path == 1 and scr_name.startswith("k_screen_quad") and rl_screen["kernel_ms"]:
+    if path == 1 and scr_name.startswith("k_screen_quad") and rl_full["kernel_ms"]:
         pk = (n_local / 16.0) * (K / 32.0) * (((s + 3) // 4) * 4) * 8.0       # wave-instructions of a launch that does ALL the work
         clk = pmc_clock(scr_name, n_local, K, p2) or 1.79
         floor_sust, floor_nom = pk * 4.0 / 1024.0 / (clk * 1e9) * 1e3, pk * 4.0 / 1024.0 / 2.4e9 * 1e3
-        rl_screen["valu_floor"] = {
+        rl_full["frac_of_valu_floor"] = floor_sust / rl_full["kernel_ms"]
+        rl_full["valu_floor"] = {
             "packed_wave_instructions": pk, "issue_cycles_each": 4, "simds": 1024, "sustained_clock_ghz": clk,
             "valu_floor_ms": floor_sust, "valu_floor_ms_at_2.4GHz": floor_nom,
             "frac_of_hbm_roofline_at_the_floor": (b_iter / (floor_sust * 1e-3) / 1e9 / HBM_PEAK_GBS),
@@ -361,9 +419,20 @@ def main():
                     "arithmetic, plus winner selection per step; tools/ubench_quad.hip (profiles/r04_ubench_quad.txt) shows "
                     "its rounds alone take 28-29 ms-equivalent because the part drops to 1.57 GHz under VALU + LDS together "
                     "(1.98 GHz VALU only, 2.2 GHz LDS only): power, not issue slots, is what is left"}
-    roofline = dict(top)
-    roofline["by_kernel"] = {scr_name: rl_screen, **({"k_exact_accumulate": rl_acc} if rl_acc else {})}
+    # top level = the section 8(d) quantity: the full-work launch of the assignment kernel (its frac is reproducible from the
+    # kernel trace alone: B_iter / average duration of k_screen_quad<NR, IR, 0, false> / 8 TB/s); the window's share model
+    # and the accumulation pass hang below it
+    roofline = dict(rl_full)
+    roofline["window"] = {"kernel": scr_name, "kernel_ms_mean": rl_screen["kernel_ms"], "rounds_executed_share": rounds_share,
+                          "steps_entered_share": done, "exact_pass_points_share": acc_share,
+                          "credited_bytes_per_launch": rl_screen["algorithmic_bytes_per_launch"], "achieved": rl_screen["achieved"],
+                          "frac": rl_screen["frac"], "traffic_window_mean": rl_screen.get("traffic_window_mean"),
+                          "traffic_window_over_credited": rl_screen.get("traffic_window_over_algorithmic"),
+                          "note": rl_screen["note"]}
+    roofline["by_kernel"] = {scr_name + " (full-work launch)": rl_full, scr_name + " (window mean)": rl_screen,
+                             **({"k_exact_accumulate": rl_acc} if rl_acc else {})}
     roofline["screen_steps_processed_share"] = done
+    roofline["screen_rounds_executed_share"] = rounds_share
     roofline["exact_pass_points_share"] = acc_share
     free_b, total_b = torch.cuda.mem_get_info()
     ops = 3.0 * nnz_local * K
@@ -395,7 +464,7 @@ def main():
                    "n_total": n_total, "n_per_gpu": n_local, "p2": p2, "K": K, "nnz_per_point": s, "start": args.start,
                    "order": args.order, "tol": TOL, "maxiter": MAXITER,
                    "gamma": gamma, "parallelism": f"dp{world} (1 RCCL all-reduce/iter)" if world > 1 else "single GPU",
-                   "allreduce": allreduce_via,
+                   "allreduce": allreduce_via, "exchange": exchange,
                    "datagen_s": round(t_gen, 1), "final_obj": final_obj,
                    "hbm_resident_GB": round((total_b - free_b) / 1e9, 1), "csc_released": bool(csc_released),
                    "hbm_after_first_call_GB": hbm_after_first_call_GB, "dataset_layout": "records" if "rec" in data else "csc",
@@ -520,6 +589,60 @@ def pmc_traffic(kern, n_local, K, p2, start):
     except Exception:
         return None, None, None
     return None, None, None
+
+
+def pmc_passes(args):
+    """HBM bytes per launch of the assignment kernel's full-work form, measured now: two child runs of this script (one cold
+    iteration + one more) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the two do not fit one pass; counters only,
+    no trace domain), before this process has generated its dataset.  bytes = FETCH_SIZE x 2 + WRITE_SIZE (KB -> B):
+    MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads, calibrated for this kernel's access pattern in
+    profiles/r01_fetch_calibration.txt.  Returns a dict (with `error` when a pass did not deliver)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--no-pmc", "--no-regimes", "--cpu-sample", "0", "--steps", "2",
+             "--warmup", "1", "--gpus", "1", "--n-total", repr(args.n_total), "--dim", str(args.dim), "--clusters", str(args.clusters),
+             "--sparsity", repr(args.sparsity), "--seed", str(args.seed), "--order", args.order, "--start", args.start,
+             "--noise", repr(args.noise), "--layout", args.layout, "--workload", args.workload, "--gen-chunk", str(args.gen_chunk)]
+    plain = re.compile(r"k_screen_quad<\d+, unsigned (short|int), 0, false>")
+    out, t0 = {}, time.time()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="spkm_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("SPKM_BENCH_DUMP", None)
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-include-regex", "k_screen_quad", "--output-format", "csv", "-d", d,
+                                "-o", "pmc", "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=240)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == ctr and plain.search(row.get("Kernel_Name", "")):
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return {"error": f"{ctr} pass delivered no plain-form k_screen_quad dispatch (rc {r.returncode}): "
+                                 + r.stderr.decode(errors="replace")[-300:]}
+            out[ctr] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:   # a report, never a reason to lose the bench line
+            return {"error": f"{ctr} pass: {e!r}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_kb, write_kb = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return {"hbm_bytes_per_launch": (fetch_kb * 2.0 + write_kb) * 1024.0, "FETCH_SIZE_raw_KB": fetch_kb, "WRITE_SIZE_raw_KB": write_kb,
+            "dispatches": out["FETCH_SIZE"][1], "kernel": "k_screen_quad<NR, IR, 0, false> (plain form)",
+            "correction": "FETCH_SIZE x 2 + WRITE_SIZE (gfx950: 128-B requests tallied at 64 B; MI355X_MICROARCH.md, "
+                          "profiles/r01_fetch_calibration.txt)",
+            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-include-regex k_screen_quad -- python bench.py "
+                       "--steps 2 --warmup 1 --no-regimes --cpu-sample 0 (same workload), two separate passes",
+            "seconds": round(time.time() - t0, 1)}
 
 
 def _pmc_records():

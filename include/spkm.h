@@ -251,7 +251,7 @@ int spkm_last_screen_rounds(spkm_ctx *ctx, int64_t info[2]);
  * steps would leave several times as many points on the screen as failed, so that data in arbitrary order -- where a 16-point
  * step is rarely settled as a whole -- skips as much as cluster-contiguous data does.  (The listed points' entries are
  * then read from the record layout of the exact pass, 512 contiguous bytes per point at s = 51, when the shard has
- * one; SPKM_PTS_NO_REC=1 reads the screen's own step-major copy instead.)
+ * one.)
  * Blocks on the stream. */
 int spkm_last_screen_mode(spkm_ctx *ctx, int64_t info[8]);
 /* How the last fused call moved the per-cluster sums when it did so incrementally (spkm_last_screen_mode info[6] = 2 or 4):
@@ -274,6 +274,13 @@ int spkm_last_events_form(spkm_ctx *ctx, int64_t info[2]);
  * info[0] = running total (this context) of the points the exact pass actually streamed, info[1] = in the last call.
  * Blocks on the stream. */
 int spkm_exact_pass_points(spkm_ctx *ctx, int64_t info[2]);
+/* Work of the fused call's 4-lanes-per-point screen launches, in ROUNDS (4 stored entries of a 16-point step against the
+ * centroids of one 32-centroid tile), running totals over this context: info[0] = rounds executed for all centroids of a
+ * tile (a step skipped on the carried bounds contributes none, a (step, tile) pair that the two-phase forms finish early
+ * only the rounds it ran for all centroids), info[1] = rounds of launches that do ALL the work (every step, every round).
+ * Measurement aid: bench.py credits the timed window's launches with info[0] / info[1] of an iteration's algorithmic
+ * bytes.  Blocks on the stream. */
+int spkm_screen_work_totals(spkm_ctx *ctx, int64_t info[2]);
 
 /* k-means++ seeding on the device (private/Arthur_initialization.m:38-69).  A round evaluates the distances to the NEWEST
  * centre only (spkm_assign_dev with K = 1 -> d_dist_new) and
@@ -324,7 +331,10 @@ int spkm_mix_sample_rec_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, 
                             uint64_t col0, int ir_bits, void *d_rec_out);
 /* A shard over n records of exactly s entries each that the caller holds on the device (and keeps alive): what
  * kmeans_sparsified.m:316-334 produces for one GPU, in the library's own layout.  Everything a CSC shard can do it can do:
- * an entry point that needs CSC arrays re-materialises library-owned ones from the records first. */
+ * an entry point that needs CSC arrays re-materialises library-owned ones from the records first.
+ * The allocation behind d_rec must extend at least 256 BYTES past the last record (n * spkm_record_bytes(s, ir_bits) + 256):
+ * the record kernels read whole 16-byte pieces and fetch a wave's batch ahead of its bounds check (the library gives its
+ * own record buffers the same slack).  1 <= s <= 64. */
 int spkm_shard_create_rec_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t s, int ir_bits, const void *d_rec,
                               spkm_shard **out);
 

@@ -138,6 +138,7 @@ def lib():
     L.spkm_debug_block_times.argtypes = [_vp, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
     L.spkm_debug_shard_bounds.argtypes = [_vp, _vp, _vp, _vp, _vp]
     L.spkm_exact_pass_points.argtypes = [_vp, C.POINTER(C.c_int64)]
+    L.spkm_screen_work_totals.argtypes = [_vp, C.POINTER(C.c_int64)]
     L.spkm_distances_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp]
     L.spkm_distances_stats_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp, _vp]
     L.spkm_shard_set_lazy_stats.argtypes = [_vp, C.c_int]

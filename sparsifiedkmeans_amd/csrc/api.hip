@@ -46,18 +46,13 @@ struct devbuf {
 // inside one process).
 struct spkm_switches {
     bool no_screen = false;       // SPKM_NO_SCREEN: all-exact f64 kernels instead of screen + confirmation
-    bool screen_v1 = false;       // SPKM_SCREEN_V1: the 16-lanes-per-point screen kernel for every shape
-    bool no_fuse = false;         // SPKM_NO_FUSE: a remainder of <= 4 centroids gets a narrow tile of its own
     bool no_prune = false;        // SPKM_NO_PRUNE: never a two-phase form
     bool no_hint = false;         // SPKM_NO_HINT: no hinted two-phase form
     bool no_bounds = false;       // SPKM_NO_BOUNDS: carried bounds are maintained but nothing is skipped on them
-    bool no_sort_reuse = false;   // SPKM_NO_SORT_REUSE: the counting sort is redone in every call
     bool no_rec = false;          // SPKM_NO_REC: no record layout (the exact pass reads the two separate arrays)
     bool no_point_list = false;   // SPKM_NO_POINT_LIST: the carried bounds always settle whole 16-point steps
     bool no_cluster_skip = false; // SPKM_NO_CLUSTER_SKIP: every cluster is planned, placed and streamed in every call
-    bool pts_no_rec = false;      // SPKM_PTS_NO_REC: point lists read the step-major f32 copy, not the records
     bool no_late_split = false;   // SPKM_NO_LATE_SPLIT: the hinted screen always asks after a quarter of the rounds
-    bool no_dist1 = false;        // SPKM_NO_DIST1: K = 1 calls go through the tiled exact kernel
     bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
     bool no_sums_only = false;    // SPKM_NO_SUMS_ONLY: a lazy call's full pass still evaluates every point's distance
@@ -67,24 +62,20 @@ struct spkm_switches {
     bool force_pair_events = false; // SPKM_FORCE_PAIR_EVENTS: pair events also when few movers per pair are expected (tests)
     bool no_direct_events = false; // SPKM_NO_DIRECT_EVENTS: a lazy call with few movers still sorts its events (plan, placement, slab kernel)
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
+    bool check_assign = false;    // SPKM_CHECK_ASSIGN: before blocks are skipped, verify the lazy contract on d_assign (debug aid; syncs)
 };
 static spkm_switches read_switches()
 {
     auto on = [](const char* name) { const char* v = getenv(name); return v != nullptr && *v != 0; };
     spkm_switches w;
     w.no_screen = on("SPKM_NO_SCREEN");
-    w.screen_v1 = on("SPKM_SCREEN_V1");
-    w.no_fuse = on("SPKM_NO_FUSE");
     w.no_prune = on("SPKM_NO_PRUNE");
     w.no_hint = on("SPKM_NO_HINT");
     w.no_bounds = on("SPKM_NO_BOUNDS");
-    w.no_sort_reuse = on("SPKM_NO_SORT_REUSE");
     w.no_rec = on("SPKM_NO_REC");
     w.no_point_list = on("SPKM_NO_POINT_LIST");
     w.no_cluster_skip = on("SPKM_NO_CLUSTER_SKIP");
-    w.pts_no_rec = on("SPKM_PTS_NO_REC");
     w.no_late_split = on("SPKM_NO_LATE_SPLIT");
-    w.no_dist1 = on("SPKM_NO_DIST1");
     w.no_incremental = on("SPKM_NO_INCREMENTAL");
     w.no_support_drift = on("SPKM_NO_SUPPORT_DRIFT");
     w.no_teams = on("SPKM_NO_TEAMS");
@@ -94,6 +85,7 @@ static spkm_switches read_switches()
     w.no_direct_events = on("SPKM_NO_DIRECT_EVENTS");
     w.no_pair_events = on("SPKM_NO_PAIR_EVENTS");
     w.force_pair_events = on("SPKM_FORCE_PAIR_EVENTS");
+    w.check_assign = on("SPKM_CHECK_ASSIGN");
     return w;
 }
 
@@ -169,7 +161,7 @@ struct spkm_shard {
     // the screen call's counters for the host policy, written by the call's last kernel (k_call_tail) straight into pinned,
     // device-mapped host memory: 16 counters, then the call's sequence number (system-scope release).  The host looks at
     // them one call later, and only if the number is the one it is waiting for -- no copy, no event, no wait on the hot
-    // path (the copy and its event cost a settled iteration 10 of its 230 us)
+    // path (the copy and its event cost a settled iteration 10 of its 230 us).  SPKM_REPORT_WORDS counters (update.hip).
     unsigned* h_nlist = nullptr;
     unsigned* h_nlist_dev = nullptr; // the same memory as the device addresses it
     unsigned nlist_seq = 0;          // number of the report the host is waiting for (nlist_pending)
@@ -530,6 +522,7 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->cl_stats_valid = false;
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
+    s->sp_clean = false;
     return SPKM_OK;
 }
 
@@ -570,6 +563,7 @@ extern "C" int spkm_shard_set_lazy_stats(spkm_shard* s, int on)
 {
     if (!s) return SPKM_ERR_NULL_ARG;
     s->lazy = on != 0;
+    s->sp_clean = false; // (a host that (re)declares its contract starts with every block visited: its buffer may be a new one at an old address)
     return SPKM_OK;
 }
 
@@ -936,7 +930,7 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
         return SPKM_OK;
     }
     // K = 1 on a fixed-stride shard (the k-means++ rounds): a plain stream over X, no tiles, no partials
-    if (K == 1 && s->fixed_s > 0 && s->nnz > 0 && !ctx->sw.no_dist1) {
+    if (K == 1 && s->fixed_s > 0 && s->nnz > 0) {
         const int threads = 1024, nw = threads / 64;
         const size_t per_pt = (size_t)(s->fixed_s | 1) * 8;
         const size_t fixed_lds = (size_t)p * 8;
@@ -1236,10 +1230,10 @@ extern "C" int spkm_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t 
 // fused iteration front half: assignment + accumulation (everything before the all-reduce)
 // ------------------------------------------------------------------------------------------
 // The 4-lanes-per-point screen keeps a point's entries in registers (up to 64); longer columns use the
-// first-generation 16-lanes-per-point kernel.  SPKM_SCREEN_V1 forces the latter (A/B runs).
+// first-generation 16-lanes-per-point kernel.
 static bool screen_use_quad(const spkm_ctx* ctx, const spkm_shard* s)
 {
-    return s->fixed_s <= 64 && !ctx->sw.screen_v1;
+    return s->fixed_s <= 64;
 }
 
 static bool screen_eligible(const spkm_ctx* ctx, const spkm_shard* s, int K)
@@ -1299,7 +1293,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // narrow tile with 1 or 2 centroid pairs per lane instead of 4.  Gs = tiles that have workgroups / result slots.
     const int k_last = K - (G - 1) * SCREEN_KT;
     int pl_last = !quad ? 4 : (k_last <= 8 ? 1 : (k_last <= 16 ? 2 : 4));
-    if (quad && G >= 2 && k_last <= 4 && !ctx->sw.no_fuse &&
+    if (quad && G >= 2 && k_last <= 4 &&
         (size_t)(p + 1) * (SCREEN_KT * 4 + 16) + 16 <= ctx->lds_max)
         pl_last = 5;
     const int Gs = pl_last == 5 ? G - 1 : G;
@@ -1390,13 +1384,16 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // point moves and the events cost what the full pass would have.  Whatever is chosen, the sums are the members' sums.
         // (what an incremental call needs is allocated by the first lazy call, whatever path that one takes: a run's
         //  first call is the one that builds things; 3 x 8 B per point here, and the sort buffers at their event sizes below)
-        ev_possible = sm->lazy && !ctx->sw.no_incremental && !ctx->sw.no_sort_reuse && (size_t)p * 12 <= 64 * 1024;
+        ev_possible = sm->lazy && !ctx->sw.no_incremental && (size_t)p * 12 <= 64 * 1024;
         // (pair events, below: the bar for "few" is higher.  Only while a pair's run is long enough to pay for its slab --
         //  flushed to BOTH clusters, 4 p atomics per work item -- and for the four extra launches of the second sort level:
         //  at least 256 movers per pair expected, from the previous call's count (n / 3 while there is none).  N = 1e8,
         //  K = 100: 3300 per pair in the iterations that matter; config 3, 6e4 points: never -- 0.28 against 0.16 ms there)
         const unsigned long long est_movers = sm->pol.movers_known ? sm->pol.last_movers : (unsigned long long)n / 3ull;
+        // (... and while the second sort level's plan fits this device's LDS: K (K + 1) counters of dynamic LDS beside
+        //  k_plan_segments_wide's 8 KB of static arrays -- 74 KB at K = 128, more than a 64-KB part offers from K = 120 on)
         const bool pair_capable = K <= 128 && !ctx->sw.no_pair_events &&
+                                  (size_t)K * (size_t)(K + 1) * 4 + 8192 <= ctx->lds_max &&
                                   (est_movers >= 256ull * (unsigned long long)K * (unsigned long long)(K + 1) || ctx->sw.force_pair_events);
         ev_path = ev_possible && d_mind == nullptr && kept && sm->cl_valid && sm->pol.few_movers((double)n, pair_capable) &&
                   !sm->pol.refresh_due((double)n);
@@ -1417,6 +1414,12 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // PAIR events (K <= 128): one event per mover, sorted by (new, old) pair -- the accumulation reads every mover's
         // record once (k_accumulate_events<.., PAIR>; two events per mover read it twice).  SPKM_NO_PAIR_EVENTS=1: A/B switch
         pair_ev = ev_path && pair_capable;
+        // (the plan kernel's dynamic-LDS allowance is raised HERE, before a single event is recorded in the pair format: a
+        //  device that refuses it gets two events per mover instead of a failed call)
+        if (pair_ev && allow_lds(ctx, (const void*)k_plan_segments_wide, (size_t)K * (size_t)(K + 1) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            pair_ev = false;
+        }
         if (pair_ev && sm->ev_o_cap < (size_t)n + 4096) {
             if (sm->ev_o) (void)hipFree(sm->ev_o);
             sm->ev_o = nullptr;
@@ -1432,11 +1435,22 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             if ((rc = ensure(ctx, ctx->nk_ev, (size_t)2 * K * 8))) return rc;
             zero_later(ctx->nk_ev.p, (size_t)2 * K * 8);
         }
+        const bool skip_enabled = bounds_ok && !ctx->sw.no_bounds;
+        // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 60 % of the points
+        // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
+        pt_mode = skip_enabled && sm->pol.pt_next && !ctx->sw.no_point_list;
+        // the two-phase forms' compiled splits (policy.h): the step-major copy lists a point's entries by |x| descending and
+        // stops earlier than the point-list kernels, whose entries may come from the records in storage order
+        // (the UNCONDITIONAL two-phase form takes the later of the ordered copy's splits, a quarter of the rounds: it finishes
+        //  every step on its partial sums, and with the single round of the early split -- 4 entries -- their scatter sends
+        //  5 % of a moderately separated shard to the exact list; the hinted form checks before it stops)
+        if (prune_a > 0)
+            prune_a = (!pt_mode && quad_split_late(q_rounds, false) > 0) ? quad_split_late(q_rounds, false) : quad_split(q_rounds, pt_mode);
         // hinted two-phase form: needs the carried bounds (the hints are ub + drift) and a split that saves rounds
-        hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds) < q_rounds;
+        hinted = want_hint && bounds_ok && prune_a == 0 && quad_split(q_rounds, pt_mode) < q_rounds;
         if (hinted) {
-            const bool late = sm->pol.take_hinted_split(q_rounds, ctx->sw.no_late_split);
-            prune_a = late ? quad_split_late(q_rounds) : quad_split(q_rounds);
+            const bool late = sm->pol.take_hinted_split(q_rounds, ctx->sw.no_late_split) && quad_split_late(q_rounds, pt_mode) > quad_split(q_rounds, pt_mode);
+            prune_a = late ? quad_split_late(q_rounds, pt_mode) : quad_split(q_rounds, pt_mode);
             ctx->last_hint_late = late;
             if (sm->hintu_len < npad) {
                 if (sm->hintu) (void)hipFree(sm->hintu);
@@ -1445,10 +1459,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                 sm->hintu_len = npad;
             }
         }
-        const bool skip_enabled = bounds_ok && !ctx->sw.no_bounds;
-        // point-granular list (screen.hip, k_bounds_steps): once the previous call's test passed >= 60 % of the points
-        // (counters read back one call late); SPKM_NO_POINT_LIST=1: always 16-point steps (A/B switch)
-        pt_mode = skip_enabled && sm->pol.pt_next && !ctx->sw.no_point_list;
         if (skip_enabled || hinted) {
             zero_later(sm->hb + 3 * npad + K, 4);
             zero_flush();
@@ -1486,6 +1496,24 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             float* sp_slack = sp_on ? reinterpret_cast<float*>(sm->sp + (size_t)nblk * 16) : nullptr;
             int* sp_valid = sp_on ? reinterpret_cast<int*>(sm->sp + (size_t)nblk * 20) : nullptr;
             const int sp_reset = (sp_on && sm->sp_clean && sm->sp_assign == (const void*)d_assign) ? 0 : 1;
+            if (sp_on && !sp_reset && ctx->sw.check_assign) {
+                // SPKM_CHECK_ASSIGN=1 (debug aid for hosts other than ours): blocks are about to go unvisited on the strength of
+                // the lazy contract (spkm.h: the same buffer, not written to between calls) -- compare the caller's buffer
+                // with the library's copy of the previous call's assignment first and refuse the call if they differ
+                unsigned* cnt = (unsigned*)ctx->nlist.p + 20;
+                HIP_TRY(hipMemsetAsync(cnt, 0, 4, ctx->stream));
+                hipLaunchKernelGGL(k_count_diff_i32, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const int*)d_assign, (const int*)(sm->hb + 2 * npad), n, cnt);
+                unsigned diff = 0;
+                HIP_TRY(hipMemcpyAsync(&diff, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                if (diff) {
+                    snprintf(ctx->errmsg, sizeof(ctx->errmsg), "SPKM_CHECK_ASSIGN: d_assign differs from the library's copy of the previous "
+                             "call's assignment in %u places (lazy statistics: the buffer is the library's to keep between calls)", diff);
+                    sm->sp_clean = false;
+                    return SPKM_ERR_BAD_VALUE;
+                }
+            }
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
                                ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
@@ -1514,6 +1542,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     long long chunk = n / ((long long)(quad ? ctx->bmapq_blocks / 4 : ctx->bmap_streams) * 8);
     chunk = std::max<long long>(sweep, std::min<long long>(chunk, 16 * sweep));
     chunk = (chunk / sweep) * sweep;
+    if (quad) { long long c2 = sweep; while (c2 * 2 <= chunk) c2 *= 2; chunk = c2; } // (a power of two: screen_quad.hip's step arithmetic)
     {
         const size_t lds = (size_t)(p + 1) * (SCREEN_KT * 4 + (pl_last == 5 ? 16 : 0)) + 16;
         const void* kern = quad ? screen_quad_kernel<IR>((s->fixed_s + 3) / 4, prune_a > 0 ? prune_a : (s->fixed_s + 3) / 4, pt_mode) : (const void*)k_screen_tile<IR>;
@@ -1528,8 +1557,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         float* a_m2 = (float*)ctx->scr_m2.p;
         int* a_k = (int*)ctx->scr_k.p;
         int a_extra = G - 1; // buffer / centroid block of the carried remainder (pl 5)
-        // two-phase forms: the split is compiled into the kernel (quad_split, screen.hip)
-        const bool two = quad && prune_a > 0 && prune_a < q_rounds; // (prune_a: quad_split or quad_split_late of q_rounds)
+        // two-phase forms: the split is compiled into the kernel (policy.h)
+        const bool two = quad && prune_a > 0 && prune_a < q_rounds; // (prune_a: quad_split or quad_split_late of (q_rounds, pt_mode))
         const int a_rounds = two ? prune_a : q_rounds;
         ctx->last_rounds_all = quad ? a_rounds : 0;
         ctx->last_rounds = quad ? q_rounds : 0;
@@ -1540,22 +1569,26 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const int* a_todo = skipping ? (const int*)ctx->todo.p : nullptr;
         int a_tp = pt_mode ? 1 : 0;
         // point lists: the listed points' entries come from the record layout of the exact pass when this shard has one
-        // (built in an earlier call: point lists only appear once most points pass the bounds); SPKM_PTS_NO_REC=1: A/B
-        const char* a_rec = (pt_mode && sm->rec && !ctx->sw.pts_no_rec) ? sm->rec : (const char*)nullptr;
+        // (built in an earlier call: point lists only appear once most points pass the bounds)
+        const char* a_rec = (pt_mode && sm->rec) ? sm->rec : (const char*)nullptr;
         int a_recR = sm->rec_R;
+        const int* a_recmap = nullptr;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
-                        &a_hint, &a_hc, &a_cnt, &a_todo, &a_tp, &a_rec, &a_recR};
+                        &a_hint, &a_hc, &a_cnt, &a_todo, &a_tp, &a_rec, &a_recR, &a_recmap};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(timing_end(ctx));
     ctx->last_skipping = skipping;
     ctx->last_pt_mode = pt_mode;
+    // what the launch did, for the running totals of executed rounds (k_call_tail; spkm_screen_work_totals)
+    const unsigned long long work_steps = (unsigned long long)((n + 15) / 16);
+    const int work_tiles = quad ? Gs : 0;
+    const int work_flags = ((quad && ctx->last_rounds_all < ctx->last_rounds && !ctx->last_hinted) ? 1 : 0) | (skipping ? 2 : 0) | (pt_mode ? 4 : 0);
     // 4. counting sort by cluster.  When the context still holds the sort of THIS shard's previous screen call (same
     // K, n, segment length; nothing else has written those buffers since) and no assignment changed -- nlist[5],
     // counted on the device by the combine and list kernels against the library's copy of the previous assignment --
     // the histogram, plan and scatter kernels return at once and the previous permutation is used again.
-    // SPKM_NO_SORT_REUSE=1: A/B switch.
     const int seg = seg_points(n, ctx->num_cus);
     const int max_items = (int)(n / seg) + K + 1;
     // (ev_possible: at the sizes the sort of the EVENTS needs -- 2 per point, 2 K keys, 256-event segments -- from the
@@ -1611,11 +1644,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     int* cl_icnt = cl_on ? sm->cl_flags + 4 * K : nullptr;
     // (ctx->sort_owner still set: none of the sort buffers was replaced by the ensure() calls above)
     const bool reuse = kept && ctx->sort_owner == (const void*)sm && ctx->sort_perm_valid && ctx->sort_seg == seg &&
-                       !ctx->sort_partial && !ctx->sw.no_sort_reuse;
+                       !ctx->sort_partial;
     const unsigned* gate = reuse ? (const unsigned*)ctx->nlist.p + 5 : (const unsigned*)nullptr;
     // cluster sizes: updated by the points that moved (k_combine_screen / k_assign_list see every change against the
-    // library's copy of the previous assignment) instead of a histogram over all points; SPKM_NO_SORT_REUSE=1 recounts
-    const bool nk_incr = kept && !ctx->sw.no_sort_reuse;
+    // library's copy of the previous assignment) instead of a histogram over all points
+    const bool nk_incr = kept;
     // 2. certification, 3. exact evaluation of the uncertified points.  Both kernels also keep the library's own copy of
     // the assignment (hb + 2 npad; the caller's buffer may change between calls) up to date IN PLACE -- only they can
     // change an assignment -- and, against the previous call's value, mark the clusters a point left or entered and move
@@ -1720,7 +1753,6 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             hipLaunchKernelGGL(k_pair_hist, dim3(gb), dim3(256), l2, ctx->stream, (const int*)ctx->perm_o.p,
                                (const long long*)ctx->offs.p, (const int4*)ctx->items.p, (const int*)nitems1, K,
                                (unsigned long long*)ctx->hist2.p, gate_ev);
-            HIP_TRY(allow_lds(ctx, (const void*)k_plan_segments_wide, (size_t)128 * 129 * 4)); // (66 KB of dynamic LDS at K = 128)
             hipLaunchKernelGGL(k_plan_segments_wide, dim3(1), dim3(1024), (size_t)Kp * 4, ctx->stream, (const unsigned long long*)ctx->hist2.p, Kp,
                                seg_ev, (long long*)ctx->offs2.p, (unsigned long long*)ctx->cursor2.p, (int4*)ctx->items2.p,
                                nitems_ev, gate_ev);
@@ -1794,7 +1826,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                            0, ctx->stream, (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
                            (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p, 1,
                            cache_s, (const double*)cache_c, pk, sums, counts,
-                           sm->nlist_pending ? (unsigned*)nullptr : sm->h_nlist_dev, sm->nlist_seq + 1u);
+                           sm->nlist_pending ? (unsigned*)nullptr : sm->h_nlist_dev, sm->nlist_seq + 1u,
+                           work_steps, work_tiles, q_rounds, ctx->last_rounds_all, work_flags);
         HIP_TRY(hipGetLastError());
         sm->hb_K = K;
         sm->hb_gamma = gamma;
@@ -1919,7 +1952,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        (const unsigned long long*)ctx->nk.p, K, nk_f, (const double*)ctx->stats.p, obj2, d_stats,
                        (unsigned long long*)d_nk_u64, (const unsigned*)ctx->bstat.p, bstat_n, (unsigned*)ctx->nlist.p,
                        sums_only ? 1 : 0, (double*)nullptr, (const double*)nullptr, (size_t)0, (double*)nullptr, (double*)nullptr,
-                       sm->nlist_pending ? (unsigned*)nullptr : sm->h_nlist_dev, sm->nlist_seq + 1u);
+                       sm->nlist_pending ? (unsigned*)nullptr : sm->h_nlist_dev, sm->nlist_seq + 1u,
+                       work_steps, work_tiles, q_rounds, ctx->last_rounds_all, work_flags);
     HIP_TRY(hipGetLastError());
     if (quad) { // the bounds now describe this call: its centroids are what the next call's drift is measured from
         sm->hb_K = K;
@@ -1950,12 +1984,13 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         memset(sm->h_nlist, 0, 128);
         HIP_TRY(hipHostGetDevicePointer((void**)&sm->h_nlist_dev, sm->h_nlist, 0));
     }
-    if (sm->nlist_pending && __atomic_load_n(sm->h_nlist + 16, __ATOMIC_ACQUIRE) == sm->nlist_seq) {
+    if (sm->nlist_pending && __atomic_load_n(sm->h_nlist + SPKM_REPORT_WORDS, __ATOMIC_ACQUIRE) == sm->nlist_seq) {
         sm->nlist_pending = false;
         ctx->last_listed = sm->h_nlist[0];
         spkm_policy_counters c;
         c.listed = sm->h_nlist[0]; c.ambig = sm->h_nlist[1]; c.early = sm->h_nlist[2]; c.skipped = sm->h_nlist[3];
         c.kept = sm->h_nlist[12]; c.movers = sm->h_nlist[14];
+        c.full_opened = sm->h_nlist[19] != 0u;
         sm->pol.observe(c, (double)s->n, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT), (s->fixed_s + 3) / 4);
     }
     const spkm_policy::choice ch = sm->pol.next(ctx->sw.no_prune, ctx->sw.no_hint, screen_use_quad(ctx, s));
@@ -1975,7 +2010,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             sm->nlist_seq++;
             sm->nlist_pending = true;
             sm->pol.launched(ctx->last_rounds_all, ctx->last_rounds, ctx->last_hinted, ctx->last_hint_late, ctx->last_skipping,
-                             ctx->last_lib_valid);
+                             ctx->last_lib_valid, ctx->last_incremental, ctx->last_dual);
         }
         return SPKM_OK; // (statistics and cluster sizes were handed over by run_screen's last kernel)
     }
@@ -2135,6 +2170,21 @@ extern "C" int spkm_exact_pass_points(spkm_ctx* ctx, int64_t info[2])
         HIP_TRY(hipMemcpy(v, ctx->nlist.p, sizeof(v), hipMemcpyDeviceToHost));
         info[0] = (int64_t)(((unsigned long long)v[33] << 32) | v[32]);
         info[1] = v[13];
+    }
+    return SPKM_OK;
+}
+
+extern "C" int spkm_screen_work_totals(spkm_ctx* ctx, int64_t info[2])
+{
+    if (!ctx || !info) return SPKM_ERR_NULL_ARG;
+    info[0] = info[1] = 0;
+    if (ctx->nlist.p) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned long long v[2] = {0ull, 0ull};
+        HIP_TRY(hipMemcpy(v, (const unsigned*)ctx->nlist.p + 34, sizeof(v), hipMemcpyDeviceToHost));
+        info[0] = (int64_t)v[0];
+        info[1] = (int64_t)v[1];
     }
     return SPKM_OK;
 }

@@ -22,19 +22,33 @@
 #define SPKM_HD
 #endif
 
-// Two-phase forms of the 4-lanes-per-point screen (screen_quad.hip, TWO): the first A = quad_split(NR) rounds for all
-// centroids, the rest only for each tile's leader (or, hinted, for all again when a step's points do not clear their
-// hints).  The split is a compile-time constant: with a run-time split every round sits behind its own branch and the
-// finish's LDS reads are waited for one by one.
-// Late split of the HINTED form (columns of >= 37 entries): half of the rounds.  In the first iterations of a run the
-// hints are loose (the own centroid has just moved a long way) and the competition's partial sums clear them only after
-// about half of the rounds; measured on the headline run (s = 51, 13 rounds) a split at 7 is best in iterations 2-4
-// (28.4 / 27.9 / 26.9 ms against 33.9 / 32.6 / 29.7 at 3), the early one from the fifth on.
-SPKM_HD constexpr int quad_split_late(int nr) { return nr >= 10 ? (nr + 1) / 2 : 0; } // 0: none
-SPKM_HD constexpr int quad_split(int nr) { return nr >= 3 ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : nr; }
+// Two-phase forms of the 4-lanes-per-point screen (screen_quad.hip, TWO): the first A rounds for all centroids, the rest
+// only for each tile's leader (or, hinted, for all again when a step's points do not clear their hints).  The split is a
+// compile-time constant: with a run-time split every round sits behind its own branch and the finish's LDS reads are
+// waited for one by one.  Two splits are compiled per round count, an EARLY one, A = quad_split(NR), and a LATE one,
+// A = quad_split_late(NR) (0: none) for the first hinted calls of a run, when the hints are loose (the own centroid has
+// just moved a long way) and the competition's partial sums clear them later.
+// Round 5: the screen's step-major copy lists a point's entries by |x| DESCENDING (k_screen_reorder), so that the partial
+// sums over the first 4 A entries -- lower bounds of the full sums whatever the order -- grow as fast as they can: a far
+// centroid's term (x_j - c_j)^2 is x_j^2 + c_j^2 on average, and the 4 largest of 51 Gaussian |x| carry 38 % of sum x^2,
+// the 12 largest 70 %.  Measured on the headline run (tools/exp_bounds_r5.py, share of the (16-point step, tile) pairs whose
+// points all clear 1.5 x hint^2): iterations 2-4, 3 rounds in |x| order 0.53 / 0.57 / 0.59 against 7 rounds in storage
+// order 0.57 / 0.57 / 0.59; iterations 5-9, ONE round in |x| order 0.61 / 0.64 / 0.79 / 0.86 / 0.90 against 3 rounds in
+// storage order 0.62 / 0.65 / 0.81 / 0.87 / 0.91.  So for the ordered copy: early = an eighth of the rounds (s = 51: 1 of
+// 13), late = a quarter (3 of 13).  pts = the point-list kernels, whose entries may come from the records in STORAGE
+// order: they keep round 4's splits (a quarter / half of the rounds: 3 and 7 of 13).
+SPKM_HD constexpr int quad_split_late(int nr, bool pts = false)
+{
+    return pts ? (nr >= 10 ? (nr + 1) / 2 : 0) : (nr >= 6 ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : 0); // 0: none
+}
+SPKM_HD constexpr int quad_split(int nr, bool pts = false)
+{
+    return nr < 3 ? nr : (pts ? ((nr + 2) / 4 > 2 ? (nr + 2) / 4 : 2) : (nr / 8 > 1 ? nr / 8 : 1));
+}
 
 struct spkm_policy_counters {
     double listed = 0, ambig = 0, early = 0, skipped = 0, kept = 0, movers = 0;
+    bool full_opened = false; // a call that queued both accumulation forms: the device opened the full pass (k_pick_form)
 };
 
 struct spkm_policy {
@@ -44,6 +58,9 @@ struct spkm_policy {
     bool hint_late_pending = false; // ... with the late split
     bool skip_pending = false;      // it ran the carried-bounds test
     bool mov_pending_valid = false; // it counted the movers
+    bool ev_latched = false;        // it updated the sums by events (latched WITH the other pending facts: ev_pending below
+                                    // describes the latest call issued, which is a later one when a report lags)
+    bool dual_latched = false;      // ... and had queued the full pass as well (the device chose)
     // --- what the next call should do ---
     int exact_cooldown = 0;         // calls left on the all-exact kernels after a poorly certifying screen
     int prune_next_a = 0;           // unconditional two-phase form with this many rounds for all centroids (0: no)
@@ -63,7 +80,7 @@ struct spkm_policy {
     // ever held, so a full pass starts them afresh once the points that moved since the last one add up to the whole shard
     // eight times over (or after 256 incremental calls; a headline run moves its points once over in its first six
     // iterations -- a refresh there would cost a full pass, 8 ms at N = 1e8, for rounding noise of 1e-13)
-    bool ev_pending = false;        // the call whose counters are pending updated the sums by events
+    bool ev_pending = false;        // the latest call issued updated the sums by events
     int ev_calls = 0;               // incremental calls since the last full accumulation pass
     unsigned long long ev_cum_movers = 0; // movers counted over those calls
 
@@ -84,7 +101,8 @@ struct spkm_policy {
     {
         if (mov_pending_valid) { last_movers = (unsigned long long)c.movers; movers_known = true; }
         if (!hint_pending && prune_pending_a == 0 && !skip_pending) crowded = c.ambig >= 0.9 * n; // (a plain call that screened every point)
-        if (ev_pending && mov_pending_valid) ev_cum_movers += (unsigned long long)c.movers;
+        if (ev_latched && dual_latched && c.full_opened) { ev_calls = 0; ev_cum_movers = 0; } // (the sums are fresh after all)
+        else if (ev_latched && mov_pending_valid) ev_cum_movers += (unsigned long long)c.movers;
         // more than 5 % of the points on the exact list: the screen pays K-fold exact work for each; 8 calls all-exact
         if (c.listed > 0.05 * n) exact_cooldown = 8;
         // point-granular list for the next bounds test: worth its 16-B fetches only while few points are listed (in
@@ -110,7 +128,7 @@ struct spkm_policy {
         // -- judged by how the failing points lie, not by the list form: the steps left on the screen are at least an eighth
         // full of them (scattered failures, a few per cent of the points, leave a quarter of all steps)
         blocks_next = skip_pending && c.kept >= 0.9 * n && (std::ceil(n / 16.0) - c.skipped) * 16.0 <= 8.0 * (n - c.kept);
-        const int a_prune = quad_split(nr); // a quarter of the rounds (s = 51: 3 of 13): a runner-up 2.25x away clears it
+        const int a_prune = quad_split(nr); // the early split (api.hip takes the point-list kernels' value where it applies): a runner-up 2.25x away clears it
         const int t = std::max(1, tiles);
         if (hint_pending) {
             // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only while the
@@ -174,13 +192,16 @@ struct spkm_policy {
         return late;
     }
     // A screen call has been queued and its counters' read-back started: remember what it was.
-    void launched(int rounds_all, int rounds, bool hinted, bool hinted_late, bool skipping, bool movers_counted)
+    void launched(int rounds_all, int rounds, bool hinted, bool hinted_late, bool skipping, bool movers_counted,
+                  bool by_events = false, bool both_forms = false)
     {
         prune_pending_a = rounds_all < rounds ? rounds_all : 0;
         hint_pending = hinted;
         hint_late_pending = hinted && hinted_late;
         skip_pending = skipping;
         mov_pending_valid = movers_counted;
+        ev_latched = by_events;
+        dual_latched = by_events && both_forms;
     }
     // Incremental sums (events) instead of a full accumulation pass: while not too many points move -- at most a third
     // in the previous counted call (an event pair reads the point twice, through a gather: 0.2 ms per million movers at

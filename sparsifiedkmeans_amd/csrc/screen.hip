@@ -143,77 +143,105 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
 
 // The screen's own copy of a fixed-stride shard, laid out the way the 4-lanes-per-point kernel consumes it.
 //  * values as f32;
-//  * per point, the entries PARTITIONED BY ROW PARITY -- points with an even index list their even rows first,
-//    odd points their odd rows first.  The sum of squares the screen estimates does not depend on the order;
-//    the order decides which LDS banks the kernel hits: the two points that read the same half-row in one
-//    16-lane phase then touch rows of opposite parity (= different 128-B halves of the 64 banks) for all but the
-//    few steps around the middle of the column, where one of them has already switched class;
+//  * per point, the entries ordered BY |x| DESCENDING in three segments -- the first 4 A1, the next 4 (A2 - A1), the rest;
+//    A1 = quad_split(NR), A2 = quad_split_late(NR): the rounds the two-phase forms evaluate for all centroids (policy.h).
+//    The sum of squares the screen estimates does not depend on the order, and a partial sum of its non-negative terms is
+//    a lower bound of the full sum whatever the order; the order decides how LARGE the partial sums are when the
+//    two-phase forms look at them: a far centroid's term (x_j - c_j)^2 is x_j^2 + c_j^2 on average, so the largest |x_j|
+//    first makes the competition clear a point's hint after a quarter of the rounds that storage order needs;
+//  * inside a segment, PARTITIONED BY ROW PARITY -- points with an even index list their even rows first, odd points
+//    their odd rows first: the order inside a segment is free, and it decides which LDS banks the kernel hits: the two
+//    points that read the same half-row in one 16-lane phase then touch rows of opposite parity (= different 128-B
+//    halves of the 64 banks) for all but the few rounds in which one of them has already switched class;
 //  * STEP-MAJOR: a step is 16 consecutive points, a round 4 entries of each.  Element (step t, round r, lane L)
 //    sits at (t * NR + r) * 64 + L, where lane L = 4 * (point - 16 t) + l4 holds entry 4 r + l4 of its point:
-//    every load of a wave is one contiguous 256-B (values) / 128-B (16-bit row ids) piece.  Slots past the
+//    every load of a wave is one contiguous 256-B (values) / 128-B (16-bit row ids) piece, and a step that the hinted
+//    form settles on its first rounds fetches only those pieces.  Slots past the
 //    column (4 NR > fixed_s) and past the last point hold x = 0 on the all-zero row p;
 //  * row ids are stored as row * 8 ^ ((row >> 1) & 3): shifted left by 4 that is the row's LDS offset (128-B
 //    rows) with the tile's piece swizzle in bits 4..5 (k_prep_tiles_f32, swz), so the kernel's address
 //    arithmetic stays one XOR per broadcast entry.  Needs 8 (p + 1) <= 65536 for 16-bit ids (LDS: p <= 1279).
+//  map != nullptr (a regrouped shard, api.hip): step-major slot i holds the point map[i] of the records.
 template <typename IR>
 __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ ir, const double* __restrict__ x,
                                                         long long n, int fixed_s, int p, float* __restrict__ xfs,
                                                         IR* __restrict__ irs, float* __restrict__ xnr,
                                                         const char* __restrict__ rec = nullptr,
-                                                        int rec_R = 0)
+                                                        int rec_R = 0, const int* __restrict__ map = nullptr)
 {
     // rec != nullptr: the entries are read from the record layout (a shard that never had CSC arrays, or has let them go)
     // one step per workgroup pass: 16 lanes per point, up to 4 passes of 16 entries (fixed_s <= 64) held in
-    // registers; the partitioned columns are staged in LDS, then written out in lane order
+    // registers; the ordered columns are staged in LDS, then written out in lane order
     __shared__ float s_x[16][64];
     __shared__ IR s_r[16][64];
+    __shared__ int s_a[16][64];            // |x| of the point's entries as f32 BITS (monotone for non-negative floats, NaN above
+                                           // everything: a total order whatever the data; -1: no entry), then the sort keys
     const int sub = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
-    const int lane = threadIdx.x & 63;
-    const int gsh = lane & 48; // first lane of this 16-lane group
     const int NR = (fixed_s + 3) >> 2;
+    const int e1 = 4 * quad_split(NR), e2 = 4 * (quad_split_late(NR) > quad_split(NR) ? quad_split_late(NR) : quad_split(NR));
     const long long nsteps = (n + 15) >> 4;
-    const unsigned below = (1u << sub) - 1u;
     for (long long st = blockIdx.x; st < nsteps; st += gridDim.x) {
         const long long i = st * 16 + grp;
         const bool live = i < n;
-        const long long j0 = (live ? i : 0) * fixed_s;
+        const long long src = live ? (map != nullptr ? (long long)map[i] : i) : 0;
+        const long long j0 = src * fixed_s;
         const unsigned want = (unsigned)(i & 1);
         double xv[4];
         IR rv[4];
-        unsigned mf[4], mg[4];
-        int nfirst = 0;
         double nb = 0.0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
             const bool ok = live && e < fixed_s;
             if (rec != nullptr) {
-                const char* rb = rec + (size_t)(live ? i : 0) * (size_t)rec_R;
+                const char* rb = rec + (size_t)src * (size_t)rec_R;
                 xv[u] = ok ? reinterpret_cast<const double*>(rb)[e] : 0.0;
                 rv[u] = ok ? reinterpret_cast<const IR*>(rb + (size_t)fixed_s * 8)[e] : (IR)0;
             } else {
                 xv[u] = ok ? x[j0 + e] : 0.0;
                 rv[u] = ok ? ir[j0 + e] : (IR)0;
             }
-            const bool f = ok && ((unsigned)rv[u] & 1u) == want;
-            mf[u] = (unsigned)((__ballot(f) >> gsh) & 0xffffull);
-            mg[u] = (unsigned)((__ballot(ok && !f) >> gsh) & 0xffffull);
-            nfirst += __builtin_popcount(mf[u]);
             nb += xv[u] * xv[u];
+            s_a[grp][e] = ok ? (__builtin_bit_cast(int, (float)xv[u]) & 0x7fffffff) : -1;
         }
-        int cf = 0, cs = 0;
+        __syncthreads();
+        // rank of each entry by (|x| descending, index ascending): a strict total order, all pairs (64 x 64 per point)
+        int rank[4] = {0, 0, 0, 0};
+        int mine[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) mine[u] = s_a[grp][u * 16 + sub];
+        for (int j = 0; j < 64; j++) {
+            const int o = s_a[grp][j];
+#pragma unroll
+            for (int u = 0; u < 4; u++) rank[u] += (o > mine[u] || (o == mine[u] && j < u * 16 + sub)) ? 1 : 0;
+        }
+        __syncthreads();
+        // key = segment | parity class | rank (unique per entry); slots without an entry stay behind everything, in index order
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
             const bool ok = live && e < fixed_s;
-            const bool f = (mf[u] >> sub) & 1u;
-            const int pos = ok ? (f ? cf + __builtin_popcount(mf[u] & below) : nfirst + cs + __builtin_popcount(mg[u] & below)) : e;
-            s_x[grp][pos] = ok ? (float)xv[u] : 0.f;   // slots past the column / past the last point: x = 0, row p
+            const int seg = rank[u] < e1 ? 0 : (rank[u] < e2 ? 1 : 2);
+            const int cls = (((unsigned)rv[u] & 1u) == want) ? 0 : 1;
+            const int key = ok ? ((seg << 7) | (cls << 6) | rank[u]) : ((3 << 7) | e);
+            s_a[grp][e] = key;
+            rank[u] = key;
+        }
+        __syncthreads();
+        int pos[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 64; j++) {
+            const int o = s_a[grp][j];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pos[u] += (o < rank[u]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = u * 16 + sub;
+            const bool ok = live && e < fixed_s;
+            s_x[grp][pos[u]] = ok ? (float)xv[u] : 0.f;   // slots past the column / past the last point: x = 0, row p
             const unsigned row = ok ? (unsigned)rv[u] : (unsigned)p;
-            s_r[grp][pos] = (IR)((row << 3) ^ ((row >> 1) & 3u)); // LDS row offset / 16 with the tile swizzle folded in
-            cf += __builtin_popcount(mf[u]);
-            cs += __builtin_popcount(mg[u]);
+            s_r[grp][pos[u]] = (IR)((row << 3) ^ ((row >> 1) & 3u)); // LDS row offset / 16 with the tile swizzle folded in
         }
         __syncthreads();
         float* xo = xfs + (size_t)st * NR * 64;

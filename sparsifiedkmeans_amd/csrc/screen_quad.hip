@@ -73,8 +73,10 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int extra_k0,
                                                  const float* __restrict__ hint, float hint_c,
                                                  unsigned* __restrict__ counters, const int* __restrict__ todo,
-                                                 int todo_pts, const char* __restrict__ rec, int rec_R)
+                                                 int todo_pts, const char* __restrict__ rec, int rec_R,
+                                                 const int* __restrict__ recmap)
 {
+    // recmap != nullptr (a regrouped shard, api.hip): point q of this shard's order is record recmap[q]
     // PTS (its own kernel instantiation): the list names POINTS; rec != nullptr: their entries are read from the record
     // layout of the exact pass (k_build_records: one point = R contiguous bytes, f64 values then row ids) instead of the
     // step-major f32 copy, where the entries of ONE point are 13 pieces of 16 + 8 B in 26 different cache lines
@@ -138,7 +140,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                 const int qc = q < n ? q : n - 1;
                 i = q;
                 if (rec != nullptr) {
-                    const char* rb = rec + (size_t)qc * (size_t)rec_R;
+                    const char* rb = rec + (size_t)(recmap != nullptr ? recmap[qc] : qc) * (size_t)rec_R;
                     xd = reinterpret_cast<const double*>(rb) + l4;
                     rd = reinterpret_cast<const IR*>(rb + (size_t)fixed_s * 8) + l4;
                 } else {
@@ -346,14 +348,15 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
     if (counters != nullptr && lane == 0 && npruned) atomicAdd(ticket + 1, npruned);
 }
 
-template <int NR, typename IR, int TWO, bool PTS> // TWO: 0 all rounds for all centroids, 1 split at quad_split, 2 at quad_split_late; PTS: the list names points
+template <int NR, typename IR, int TWO, bool PTS> // TWO: 0 all rounds for all centroids, 1 split at quad_split(NR, PTS), 2 at quad_split_late(NR, PTS); PTS: the list names points
 __global__ __launch_bounds__(1024) void k_screen_quad(
     const IR* __restrict__ ir, const float* __restrict__ xval, const float* __restrict__ T32, int p, int n, int fixed_s,
     int K, const spkm_blockmap* __restrict__ bmap, int chunk_points, float* __restrict__ scr_m1,
     float* __restrict__ scr_m2, int* __restrict__ scr_k, int extra_tile,
     const float* __restrict__ hint, float hint_c, unsigned* __restrict__ counters, const int* __restrict__ todo,
     int todo_points, // todo_points != 0 (the PTS instantiation): the list holds point ids (counters[4] of them), not 16-point steps
-    const char* __restrict__ rec, int rec_R) // record layout for the listed points (PTS; may be null)
+    const char* __restrict__ rec, int rec_R, // record layout for the listed points (PTS; may be null)
+    const int* __restrict__ recmap)          // ... and which record a point of this shard's order is (null: its own)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spkm_blockmap bm = bmap[blockIdx.x];
@@ -380,17 +383,17 @@ __global__ __launch_bounds__(1024) void k_screen_quad(
     float* m2o = scr_m2 + (size_t)bm.tile * n;
     int* ko = scr_k + (size_t)bm.tile * n;
     const int eb = (int)tile_bytes, ek = extra_tile * SCREEN_KT;
-    constexpr int A = TWO == 0 ? NR : (TWO == 2 && quad_split_late(NR) > 0 ? quad_split_late(NR) : quad_split(NR));
+    constexpr int A = TWO == 0 ? NR : (TWO == 2 && quad_split_late(NR, PTS) > 0 ? quad_split_late(NR, PTS) : quad_split(NR, PTS));
     int nv = n, chunk_v = chunk_points, tp = 0;
     if (todo != nullptr) { // counters[4] = length of the list; chunks small enough that every workgroup gets several
         if (PTS) { tp = (int)counters[4]; nv = (tp + 15) & ~15; }
         else nv = (int)counters[4] * 16;
         chunk_v = max(256, min(chunk_points, (nv / (int)(gridDim.x * 2)) & ~255));
     }
-    if (pl == 4) screen_quad_body<NR, IR, 4, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
-    else if (pl == 5) screen_quad_body<NR, IR, 5, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
-    else if (pl == 2) screen_quad_body<NR, IR, 2, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
-    else screen_quad_body<NR, IR, 1, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R);
+    if (pl == 4) screen_quad_body<NR, IR, 4, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R, recmap);
+    else if (pl == 5) screen_quad_body<NR, IR, 5, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R, recmap);
+    else if (pl == 2) screen_quad_body<NR, IR, 2, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R, recmap);
+    else screen_quad_body<NR, IR, 1, A, PTS>(ir, xval, p, n, nv, fixed_s, K, bm, chunk_v, m1o, m2o, ko, smem, ticket, eb, ek, hint, hint_c, counters, todo, tp, rec, rec_R, recmap);
     if (counters != nullptr) {
         __syncthreads();
         if (tid == 0 && ticket[1]) atomicAdd(counters + 2, ticket[1]);
@@ -412,13 +415,13 @@ const void* SPKM_SQ_CAT(spkm_sq_kernel_, SPKM_SQ_IRBITS, SPKM_SQ_PTS)(int rounds
 {
     constexpr bool PTS = SPKM_SQ_PTS != 0;
     typedef sq_ir_t IR;
-    const bool late = a_rounds < rounds && quad_split_late(rounds) > 0 && a_rounds == quad_split_late(rounds);
+    const bool late = a_rounds < rounds && quad_split_late(rounds, PTS) > 0 && a_rounds == quad_split_late(rounds, PTS);
     const bool two = a_rounds < rounds;
     switch (rounds) {
 #define SPKM_QUAD_CASE(N)                                                                                   \
     case N:                                                                                                 \
-        if (late) return (const void*)k_screen_quad<N, IR, (quad_split_late(N) > 0 ? 2 : 0), PTS>;          \
-        return two && quad_split(N) < N ? (const void*)k_screen_quad<N, IR, (quad_split(N) < N ? 1 : 0), PTS> : (const void*)k_screen_quad<N, IR, 0, PTS>;
+        if (late) return (const void*)k_screen_quad<N, IR, (quad_split_late(N, PTS) > 0 ? 2 : 0), PTS>;     \
+        return two && quad_split(N, PTS) < N ? (const void*)k_screen_quad<N, IR, (quad_split(N, PTS) < N ? 1 : 0), PTS> : (const void*)k_screen_quad<N, IR, 0, PTS>;
         SPKM_QUAD_CASE(1) SPKM_QUAD_CASE(2) SPKM_QUAD_CASE(3) SPKM_QUAD_CASE(4) SPKM_QUAD_CASE(5) SPKM_QUAD_CASE(6)
         SPKM_QUAD_CASE(7) SPKM_QUAD_CASE(8) SPKM_QUAD_CASE(9) SPKM_QUAD_CASE(10) SPKM_QUAD_CASE(11) SPKM_QUAD_CASE(12)
         SPKM_QUAD_CASE(13) SPKM_QUAD_CASE(14) SPKM_QUAD_CASE(15) SPKM_QUAD_CASE(16)

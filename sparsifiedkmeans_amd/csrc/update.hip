@@ -853,14 +853,34 @@ __global__ void k_nk_to_f64(const unsigned long long* __restrict__ nk, int K, do
 
 // ... together with the other small hand-overs at the end of the fused call (each was a launch of its own): obj^2 into
 // the reduce buffer, the statistics and cluster sizes into the caller's buffers (either may be null)
+#define SPKM_REPORT_WORDS 24 // counters a fused call reports to the host ([19]: the device opened the full pass, k_pick_form)
 __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, double* __restrict__ nk_f,
                             const double* __restrict__ stats, double* __restrict__ obj2, double* __restrict__ d_stats,
                             unsigned long long* __restrict__ d_nk, const unsigned* __restrict__ bstat, int bstat_n,
                             unsigned* __restrict__ counters, int lazy = 0, double* __restrict__ cache_s = nullptr,
                             const double* __restrict__ cache_c = nullptr, size_t pk = 0, double* __restrict__ sums = nullptr,
-                            double* __restrict__ counts = nullptr, unsigned* __restrict__ host_out = nullptr, unsigned seq = 0u)
+                            double* __restrict__ counts = nullptr, unsigned* __restrict__ host_out = nullptr, unsigned seq = 0u,
+                            unsigned long long work_steps = 0ull, int work_tiles = 0, int work_nr = 0, int work_a = 0,
+                            int work_flags = 0)
 {
-    // host_out != nullptr: pinned host memory, device-mapped -- the call's 16 counters for the host policy go there, then
+    // work_*: what this call's 4-lanes-per-point screen launch did, in ROUNDS (4 stored entries of 16 points against the
+    // centroids of one tile) -- counters[34..35] += rounds executed for all centroids of a tile, counters[36..37] += rounds of
+    // a launch that does all the work (work_steps = ceil(n / 16) steps x work_tiles x work_nr); running totals, read by
+    // spkm_screen_work_totals (bench.py weights the window's algorithmic bytes by their ratio).  work_flags: 1 = the
+    // unconditional two-phase form (every step stops after work_a rounds), 2 = the launch ran over a list (counters[4]
+    // entries), 4 = of points; the hinted form's early-finished (step, tile) pairs are counters[2].
+    if (work_tiles > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long steps = work_steps;
+        if (work_flags & 2) steps = (work_flags & 4) ? ((unsigned long long)counters[4] + 15ull) / 16ull : (unsigned long long)counters[4];
+        unsigned long long r = steps * (unsigned long long)work_tiles * (unsigned long long)((work_flags & 1) ? work_a : work_nr);
+        if (!(work_flags & 1) && work_a < work_nr) {
+            const unsigned long long saved = (unsigned long long)counters[2] * (unsigned long long)(work_nr - work_a);
+            r -= saved < r ? saved : r;
+        }
+        *reinterpret_cast<unsigned long long*>(counters + 34) += r;
+        *reinterpret_cast<unsigned long long*>(counters + 36) += work_steps * (unsigned long long)work_tiles * (unsigned long long)work_nr;
+    }
+    // host_out != nullptr: pinned host memory, device-mapped -- the call's first SPKM_REPORT_WORDS counters for the host policy go there, then
     // the report's number `seq` with a system-scope release (api.hip reads them one call later, if the number is there)
     // cache_s != nullptr (incremental calls): the call's sums and counts ARE the cache.  One repair on the way: a row of a
     // cluster that no member stores any more (count 0) must have the sum EXACTLY 0 -- a fresh summation gives that, an
@@ -895,8 +915,8 @@ __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, do
         }
     }
     if (host_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { // (thread 0 made the last changes to the counters itself)
-        for (int j = 0; j < 16; j++) host_out[j] = counters[j];
-        __hip_atomic_store(host_out + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int j = 0; j < SPKM_REPORT_WORDS; j++) host_out[j] = counters[j];
+        __hip_atomic_store(host_out + SPKM_REPORT_WORDS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) {

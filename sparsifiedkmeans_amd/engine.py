@@ -66,7 +66,9 @@ class Shard:
         s row ids, in ``record_bytes(s, ir_bits)`` bytes) -- the layout the fused call reads; the separate CSC arrays never
         exist (spkm_shard_create_rec_dev)."""
         assert rec.is_cuda and rec.dtype == torch.uint8 and rec.is_contiguous()
-        assert rec.numel() >= n * record_bytes(s, ir_bits)
+        # (n records + 256 bytes: the record kernels fetch whole 16-byte pieces and a wave's batch of records ahead of its
+        #  bounds check -- spkm.h, spkm_shard_create_rec_dev)
+        assert rec.numel() >= n * record_bytes(s, ir_bits) + 256, "the record buffer needs 256 bytes of slack behind its last record"
         h = C.c_void_p()
         _lib.check(_lib.lib().spkm_shard_create_rec_dev(ctx.handle, p, n, s, ir_bits, _p(rec), C.byref(h)),
                    "spkm_shard_create_rec_dev")
@@ -144,6 +146,13 @@ def comm_size(ctx: Context) -> int:
     n, r = C.c_int(), C.c_int()
     _lib.check(_lib.lib().spkm_comm_info(ctx.handle, C.byref(n), C.byref(r)))
     return n.value
+
+
+def comm_info(ctx: Context) -> tuple[int, int]:
+    """(ranks, this rank) of the RCCL communicator attached to ``ctx`` inside libspkm.so ((0, 0) = none): spkm_comm_info."""
+    n, r = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().spkm_comm_info(ctx.handle, C.byref(n), C.byref(r)))
+    return n.value, r.value
 
 
 def attach_rccl(ctx: Context, group=None) -> int:
@@ -297,6 +306,13 @@ class LloydEngine:
         fewer than n once clusters are settled (spkm_exact_pass_points)."""
         a = (C.c_int64 * 2)()
         _lib.check(_lib.lib().spkm_exact_pass_points(self.ctx.handle, a))
+        return int(a[0]), int(a[1])
+
+    def screen_work_totals(self) -> tuple[int, int]:
+        """(rounds the screen launches on this context executed for all centroids of a tile, rounds of launches doing all the
+        work) -- running totals (spkm_screen_work_totals); a round = 4 stored entries of a 16-point step against one tile."""
+        a = (C.c_int64 * 2)()
+        _lib.check(_lib.lib().spkm_screen_work_totals(self.ctx.handle, a))
         return int(a[0]), int(a[1])
 
     def last_screen_rounds(self) -> tuple[int, int]:

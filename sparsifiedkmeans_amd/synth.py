@@ -105,7 +105,7 @@ def sparsified_gmm_device(ctx, p: int, n_local: int, n_total: int, first: int, K
     sign[sign == 0] = 1.0
     ir_dtype = torch.int16 if p2 <= 65536 else torch.int32   # int16 storage is read as uint16 row ids
     # 48 entries of slack: the fixed-stride kernels read (and ignore) up to 33 entries past a column
-    records = layout == "records"
+    records = layout == "records" and s <= 64      # (the record layout holds columns of at most 64 entries: CSC beyond, as StreamingSparsifier)
     R = record_bytes(s, 16 if p2 <= 65536 else 32) if records else 0
     if records:
         rec = torch.empty(n_local * R + 256, dtype=torch.uint8, device=dev)

@@ -20,9 +20,17 @@ void pol_next(void* p, int no_prune, int no_hint, int quad, int* out)
     out[0] = ch.exact; out[1] = ch.prune_a; out[2] = ch.want_hint;
 }
 int pol_take_hinted_split(void* p, int nr, int no_late) { return ((spkm_policy*)p)->take_hinted_split(nr, no_late != 0); }
-void pol_launched(void* p, int rounds_all, int rounds, int hinted, int late, int skipping, int movers_counted)
+void pol_launched(void* p, int rounds_all, int rounds, int hinted, int late, int skipping, int movers_counted, int by_events,
+                  int both_forms)
 {
-    ((spkm_policy*)p)->launched(rounds_all, rounds, hinted != 0, late != 0, skipping != 0, movers_counted != 0);
+    ((spkm_policy*)p)->launched(rounds_all, rounds, hinted != 0, late != 0, skipping != 0, movers_counted != 0, by_events != 0,
+                                both_forms != 0);
+}
+void pol_observe_full_opened(void* p, double movers, double n, int tiles, int nr)
+{
+    spkm_policy_counters c;
+    c.movers = movers; c.full_opened = true;
+    ((spkm_policy*)p)->observe(c, n, tiles, nr);
 }
 int pol_blocks_next(void* p) { return ((spkm_policy*)p)->blocks_next; }
 int pol_pt_next(void* p) { return ((spkm_policy*)p)->pt_next; }
@@ -37,4 +45,6 @@ unsigned long long pol_event_cap(unsigned long long n) { return spkm_policy::eve
 unsigned long long pol_event_cap_pair(unsigned long long n) { return spkm_policy::event_cap(n, true); }
 int pol_quad_split(int nr) { return quad_split(nr); }
 int pol_quad_split_late(int nr) { return quad_split_late(nr); }
+int pol_quad_split_pts(int nr) { return quad_split(nr, true); }
+int pol_quad_split_late_pts(int nr) { return quad_split_late(nr, true); }
 }

@@ -73,11 +73,9 @@ def test_screen_kernel_variants_equal_oracle(gpu_ctx, oracle, p, n, K, s):
     _check(eng, oracle, X, Cm, s / p)
 
 
-@pytest.mark.parametrize("p,n,K,s", [(1024, 6000, 100, 51), (512, 5000, 37, 26), (256, 3000, 64, 80)])
-def test_sixteen_lane_screen_kernel_equals_oracle(gpu_ctx, oracle, p, n, K, s, monkeypatch):
-    """The first-generation screen kernel (16 lanes per point; what columns longer than 64 entries use),
-    forced for ordinary shapes too."""
-    set_switch(monkeypatch, gpu_ctx, "SPKM_SCREEN_V1")
+@pytest.mark.parametrize("p,n,K,s", [(1024, 6000, 100, 70), (512, 5000, 37, 66), (256, 3000, 64, 80)])
+def test_sixteen_lane_screen_kernel_equals_oracle(gpu_ctx, oracle, p, n, K, s):
+    """The first-generation screen kernel (16 lanes per point): what columns longer than 64 entries use."""
     X = random_csc(p, n, s, seed=p + K + 1)
     Cm = np.random.default_rng(K + 1).standard_normal((p, K)) * 0.2
     eng, path, listed = _run(gpu_ctx, X, Cm, s / p)
@@ -338,7 +336,8 @@ def test_carried_bounds_skip_steps_and_stay_exact(gpu_ctx, oracle):
     with SPKM_NO_BOUNDS-like behaviour after reset_policy (bounds forgotten)."""
     from sparsifiedkmeans_amd import synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
-    K, n = 40, 8000
+    K, n = 48, 9600       # (the jump of call 3 leaves two clusters of 200 points to the exact list: 4 %, under the 5 % at which
+                          #  the library would answer with eight calls on the all-exact kernels -- no bounds carried there)
     data = synth.sparsified_gmm_host(p=256, n=n, K=K, gamma=0.2, seed=13, fwht=oracle.fwht)
     Y, p2, gam = data["Y"], data["p2"], data["gamma"]
     cen = np.zeros((p2, K))
@@ -567,9 +566,10 @@ def test_unchanged_clusters_are_not_streamed_again_and_outputs_stay_exact(gpu_ct
 
 
 def test_hinted_screen_early_and_late_split_give_the_oracles_answers(gpu_ctx, oracle, monkeypatch):
-    """Columns of 51 entries (13 rounds): a run's first hinted calls ask after 7 rounds (spkm_last_screen_rounds reports
-    (7, 13)), later ones after 3; SPKM_NO_LATE_SPLIT=1 keeps to 3.  Which split runs changes the work, never an output:
-    assignments and distances are the oracle's in every call of both runs."""
+    """Columns of 51 entries (13 rounds), listed by |x| descending in the screen's copy: a run's first hinted calls ask after
+    3 rounds (spkm_last_screen_rounds reports (3, 13)), later ones after 1 -- the point-list kernels, whose entries may be
+    in storage order, after 7 and 3; SPKM_NO_LATE_SPLIT=1 keeps to the early split.  Which split runs changes the work,
+    never an output: assignments and distances are the oracle's in every call of both runs."""
     from sparsifiedkmeans_amd import synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard
 
@@ -595,14 +595,18 @@ def test_hinted_screen_early_and_late_split_give_the_oracles_answers(gpu_ctx, or
             used = c.cpu().numpy().T.copy()
             eng.iterate(c)
             torch.cuda.synchronize()                                 # (lets the library's asynchronous counters land)
-            rounds.append(eng.last_screen_rounds())
+            md = eng.last_screen_mode()
+            rounds.append(eng.last_screen_rounds() + (md[7] == 2, md[0] == 2))   # (.., the list named points, hinted form)
             assert eng.last_path_info()[0] == 1
             ra, rd = oracle.assign(p, n, *parts(Y), used, gam)
             assert np.array_equal(eng.assign.cpu().numpy(), ra), (nolate, it)
             assert np.array_equal(eng.mind.cpu().numpy(), rd), (nolate, it)
         seen[nolate] = rounds
-    assert (7, 13) in seen[False], seen                              # the late split ran ...
-    assert (7, 13) not in seen[True], seen                           # ... and not when switched off
+    late = {(3, 13, False, True), (7, 13, True, True)}               # hinted calls over 16-point steps / point lists
+    assert late & set(seen[False]), seen                             # the late split ran ...
+    assert not (late & set(seen[True])), seen                        # ... and not when switched off (the UNCONDITIONAL two-phase
+    #                                                                  form asks after a quarter of the rounds either way)
+    assert {(1, 13, False, True), (3, 13, True, True)} & set(seen[True]), seen   # (the early one did)
     assert all(r[1] == 13 for r in seen[False] + seen[True]), seen
 
 

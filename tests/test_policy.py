@@ -24,7 +24,8 @@ def pol(tmp_path_factory):
     L.pol_observe.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_int]
     L.pol_next.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.pol_take_hinted_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    L.pol_launched.argtypes = [C.c_void_p] + [C.c_int] * 6
+    L.pol_launched.argtypes = [C.c_void_p] + [C.c_int] * 8
+    L.pol_observe_full_opened.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int]
     L.pol_pt_next.argtypes = [C.c_void_p]
     L.pol_blocks_next.argtypes = [C.c_void_p]
     L.pol_few_movers.argtypes = [C.c_void_p, C.c_double]
@@ -49,7 +50,9 @@ class Walk:
         self.sw = (no_prune, no_hint, no_late)
         self.bounds = False                  # the library holds bounds from a previous screen call
 
-    def call(self):
+    def call(self, sums=None, both=False):
+        """one fused call: the policy's choice, then -- in the library's order -- how the call gets its sums ("events" /
+        "full" / None: not said), then what was launched"""
         out = (C.c_int * 3)()
         self.L.pol_next(self.p, self.sw[0], self.sw[1], 1, out)
         exact, prune_a, want_hint = out[0], out[1], out[2]
@@ -59,7 +62,12 @@ class Walk:
         hinted = bool(want_hint and self.bounds and prune_a == 0)
         late = bool(self.L.pol_take_hinted_split(self.p, NR, self.sw[2])) if hinted else False
         rounds_all = (self.L.pol_quad_split_late(NR) if late else self.L.pol_quad_split(NR)) if hinted else (prune_a or NR)
-        self.L.pol_launched(self.p, rounds_all, NR, int(hinted), int(late), int(self.bounds), int(self.bounds))
+        if sums == "events":
+            self.L.pol_sums_by_events(self.p)
+        elif sums == "full":
+            self.L.pol_sums_by_full_pass(self.p)
+        self.L.pol_launched(self.p, rounds_all, NR, int(hinted), int(late), int(self.bounds), int(self.bounds),
+                            int(sums == "events"), int(both))
         self.bounds = True
         if hinted:
             return "hinted-late" if late else "hinted-early"
@@ -70,8 +78,15 @@ class Walk:
 
 
 def test_compiled_splits(pol):
-    assert [pol.pol_quad_split(nr) for nr in (1, 2, 3, 8, 13, 16)] == [1, 2, 2, 2, 3, 4]
-    assert [pol.pol_quad_split_late(nr) for nr in (9, 10, 13, 16)] == [0, 5, 7, 8]
+    # the step-major copy lists a point's entries by |x| descending: an eighth / a quarter of the rounds
+    assert [pol.pol_quad_split(nr) for nr in (1, 2, 3, 8, 13, 16)] == [1, 2, 1, 1, 1, 2]
+    assert [pol.pol_quad_split_late(nr) for nr in (5, 6, 10, 13, 16)] == [0, 2, 3, 3, 4]
+    # the point-list kernels (entries possibly in storage order): a quarter / half of the rounds, as in round 4
+    assert [pol.pol_quad_split_pts(nr) for nr in (1, 2, 3, 8, 13, 16)] == [1, 2, 2, 2, 3, 4]
+    assert [pol.pol_quad_split_late_pts(nr) for nr in (9, 10, 13, 16)] == [0, 5, 7, 8]
+    for nr in range(1, 17):                                   # a late split, where there is one, comes after the early one
+        for f, g in ((pol.pol_quad_split, pol.pol_quad_split_late), (pol.pol_quad_split_pts, pol.pol_quad_split_late_pts)):
+            assert g(nr) == 0 or f(nr) < g(nr) < nr
 
 
 def test_first_call_is_plain_and_well_separated_data_goes_two_phase(pol):
@@ -276,17 +291,39 @@ def test_incremental_sums_are_refreshed_by_a_full_pass(pol):
     """Sums moved by events accumulate rounding relative to everything an entry ever held: once the movers counted since
     the last full pass add up to eight times the shard (or after 256 incremental calls) the next call runs the full pass again."""
     w = Walk(pol)
-    w.call(); pol.pol_sums_by_full_pass(w.p); w.seen()
+    w.call(sums="full"); w.seen()
     for _ in range(26):                                      # 0.3 N movers per incremental call: due after the 27th
         assert pol.pol_refresh_due(w.p, N) == 0
-        w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=0.3 * N)
+        w.call(sums="events"); w.seen(movers=0.3 * N)
     assert pol.pol_refresh_due(w.p, N) == 0                  # 7.8 N so far
-    w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=0.3 * N)
+    w.call(sums="events"); w.seen(movers=0.3 * N)
     assert pol.pol_refresh_due(w.p, N) == 1                  # 8.1 N > 8 N
-    w.call(); pol.pol_sums_by_full_pass(w.p); w.seen(movers=0.01 * N)
+    w.call(sums="full"); w.seen(movers=0.01 * N)
     assert pol.pol_refresh_due(w.p, N) == 0                  # the full pass starts the count over (its own movers do not count)
     for _ in range(255):
-        w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=1.0)
+        w.call(sums="events"); w.seen(movers=1.0)
     assert pol.pol_refresh_due(w.p, N) == 0
-    w.call(); pol.pol_sums_by_events(w.p); w.seen(movers=1.0)
+    w.call(sums="events"); w.seen(movers=1.0)
     assert pol.pol_refresh_due(w.p, N) == 1                  # 256 incremental calls in a row
+
+
+def test_movers_are_credited_to_the_call_that_was_observed(pol):
+    """The events flag is latched with the launch it describes: a report that lags (no launched() for the newer call) is
+    credited by what ITS call did, and a call that queued both forms and saw the device open the full pass starts the
+    refresh count over."""
+    w = Walk(pol)
+    w.call(sums="full"); w.seen()
+    w.call(sums="events"); w.seen(movers=0.5 * N)
+    pol.pol_sums_by_full_pass(w.p)                           # a newer call (full pass) was issued while this report was pending:
+    pol.pol_sums_by_events(w.p)                              # ... and another by events -- neither launched(): reports lag
+    w.seen(movers=9.0 * N)                                   # the pending report is the EVENTS call's: its movers count
+    assert pol.pol_refresh_due(w.p, N) == 1
+    w2 = Walk(pol)
+    w2.call(sums="full"); w2.seen()
+    for _ in range(3):
+        w2.call(sums="events"); w2.seen(movers=2.0 * N)
+    w2.call(sums="events", both=True)                        # both forms queued; the device opened the full pass
+    pol.pol_observe_full_opened(w2.p, 3.0 * N, N, TILES, NR)
+    assert pol.pol_refresh_due(w2.p, N) == 0                 # 6 N + a fresh summation: the count starts over
+    w2.call(sums="events"); w2.seen(movers=2.0 * N)
+    assert pol.pol_refresh_due(w2.p, N) == 0
