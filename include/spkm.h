@@ -150,6 +150,17 @@ int spkm_shard_get_column_host(spkm_ctx *ctx, const spkm_shard *s, uint64_t col,
                                double *x_out, uint64_t *count);
 void spkm_shard_destroy(spkm_shard *s);
 int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
+/* Data in arbitrary order.  A 16-point step of the screen is skipped on the carried bounds, or finished early by the hinted
+ * form, only if all its 16 points allow it; with the points of a cluster scattered over the shard that is rare.  When a
+ * fused call over all points of a LAZY shard (spkm_shard_set_lazy_stats) finds fewer than half of its steps holding one
+ * cluster, the next call first REGROUPS the shard: the library's own order of the points -- the order of its screen copy,
+ * bounds, hints and block summaries -- becomes "by cluster, the points that are sure of it first" (one gather of the
+ * records, one write of the 306-B-per-point screen copy: once per spkm_shard_reset_policy at most).  Nothing the caller sees
+ * moves: d_assign, d_mind, spkm_shard_get_column_host and the records keep the caller's order (the library reaches them
+ * through an index map), and no result depends on the order (kmeans_sparsified.m:430-431 sums over find(assignments == k)).
+ * SPKM_NO_REGROUP=1: A/B switch.  info[0] = 1 if the shard's own order differs from the caller's, info[1] = 1 if it was
+ * regrouped since the last spkm_shard_reset_policy. */
+int spkm_shard_order_info(const spkm_shard *s, int64_t info[2]);
 
 /* Length (in doubles) of the per-iteration reduce buffer for (p, K):
  *   [ sums p*K | counts p*K | nk K | obj2 1 ]      -- one SUM all-reduce covers all of it. */

@@ -111,6 +111,7 @@ def lib():
     L.spkm_shard_destroy.argtypes = [_vp]
     L.spkm_shard_destroy.restype = None
     L.spkm_shard_info.argtypes = [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(C.c_int)]
+    L.spkm_shard_order_info.argtypes = [_vp, C.POINTER(C.c_int64)]
     L.spkm_reduce_len.argtypes = [_u64, _u64]
     L.spkm_reduce_len.restype = _u64
     L.spkm_assign_dev.argtypes = [_vp, _vp, _u64, _vp, _dbl, _vp, _vp, _vp, _vp]

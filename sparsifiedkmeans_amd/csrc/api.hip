@@ -62,6 +62,7 @@ struct spkm_switches {
     bool force_pair_events = false; // SPKM_FORCE_PAIR_EVENTS: pair events also when few movers per pair are expected (tests)
     bool no_direct_events = false; // SPKM_NO_DIRECT_EVENTS: a lazy call with few movers still sorts its events (plan, placement, slab kernel)
     bool no_teams = false;        // SPKM_NO_TEAMS: screen workgroups split over the tiles by cost (tiles drift apart) instead of teams
+    bool no_regroup = false;      // SPKM_NO_REGROUP: the library's order of the points stays the caller's whatever their steps look like
     bool check_assign = false;    // SPKM_CHECK_ASSIGN: before blocks are skipped, verify the lazy contract on d_assign (debug aid; syncs)
 };
 static spkm_switches read_switches()
@@ -86,6 +87,7 @@ static spkm_switches read_switches()
     w.no_pair_events = on("SPKM_NO_PAIR_EVENTS");
     w.force_pair_events = on("SPKM_FORCE_PAIR_EVENTS");
     w.check_assign = on("SPKM_CHECK_ASSIGN");
+    w.no_regroup = on("SPKM_NO_REGROUP");
     return w;
 }
 
@@ -202,6 +204,12 @@ struct spkm_shard {
     bool cl_stats_valid = false; // cl_cache's obj2 / max / argmax describe the previous call (false after an incremental call)
     int* ev_pt = nullptr;        // events of the current call: point | key (K + old cluster, or new cluster); 2 n each
     int* ev_k = nullptr;
+    // the library's own order of the points (regroup_shard): point i of the screen copy / of every per-point array the
+    // library keeps is the caller's point map[i] (null: the caller's order).  The records stay in the caller's order.
+    int* map = nullptr;
+    bool regroup_wanted = false;   // the last call over all points found most 16-point steps mixing clusters
+    bool regroup_done = false;     // ... and it has been acted on since the last spkm_shard_reset_policy
+    bool pend_full = false;        // the call whose counters are pending screened every point in plain order (its step statistics count)
     int* ev_o = nullptr;         // pair events (K <= 128): the mover's old cluster (-1: none); n + 4096 of them
     size_t ev_o_cap = 0;
     size_t ev_cap = 0;
@@ -504,6 +512,7 @@ extern "C" void spkm_shard_destroy(spkm_shard* s)
     if (s->ev_pt) (void)hipFree(s->ev_pt);
     if (s->ev_k) (void)hipFree(s->ev_k);
     if (s->ev_o) (void)hipFree(s->ev_o);
+    if (s->map) (void)hipFree(s->map);
     if (s->hb_centers) (void)hipFree(s->hb_centers);
     if (s->h_nlist) (void)hipHostFree(s->h_nlist);
     if (s->owned && s->jc) (void)hipFree(s->jc);
@@ -523,6 +532,9 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
     s->sp_clean = false;
+    s->regroup_wanted = false;
+    s->regroup_done = false; // (the order a previous run left stays; a new run may ask once more)
+    s->pend_full = false;
     return SPKM_OK;
 }
 
@@ -564,6 +576,14 @@ extern "C" int spkm_shard_set_lazy_stats(spkm_shard* s, int on)
     if (!s) return SPKM_ERR_NULL_ARG;
     s->lazy = on != 0;
     s->sp_clean = false; // (a host that (re)declares its contract starts with every block visited: its buffer may be a new one at an old address)
+    return SPKM_OK;
+}
+
+extern "C" int spkm_shard_order_info(const spkm_shard* s, int64_t info[2])
+{
+    if (!s || !info) return SPKM_ERR_NULL_ARG;
+    info[0] = s->map != nullptr ? 1 : 0;
+    info[1] = s->regroup_done ? 1 : 0;
     return SPKM_OK;
 }
 
@@ -660,8 +680,76 @@ static int build_screen_copy(spkm_ctx* ctx, spkm_shard* sm)
     hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256),
                        0, ctx->stream, (const IR*)sm->ir, (const double*)sm->x, n, sm->fixed_s, p, sm->xfs, (IR*)sm->irs,
                        sm->norms_done ? (float*)nullptr : sm->xnr,
-                       sm->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R);
+                       sm->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R, (const int*)nullptr);
     sm->norms_done = true;
+    return SPKM_OK;
+}
+
+// Regroup a lazy shard by cluster (screen.hip, k_regroup_keys): called at the start of a fused call whose predecessor -- a
+// call over every point -- found most 16-point steps mixing clusters.  Counting sort of the library's points by (cluster,
+// unsure) from the bounds that call left; the bounds and the library's copy of the assignment move with the points, the
+// screen copy and the certificate's norms are rebuilt from the records in the new order (one gather of the records, one
+// write of the copy), the block summaries start over.  Scratch of its own: the context's kept counting sort is untouched.
+template <typename IR>
+static int regroup_shard(spkm_ctx* ctx, spkm_shard* sm, int K)
+{
+    const long long n = (long long)sm->n, npad = sm->hb_npad;
+    const int K2 = 2 * K;
+    int *keys = nullptr, *perm = nullptr, *newmap = nullptr;
+    float* hb_new = nullptr;
+    auto fail = [&](hipError_t e) {
+        (void)hipGetLastError();
+        if (keys) (void)hipFree(keys);
+        if (perm) (void)hipFree(perm);
+        if (newmap) (void)hipFree(newmap);
+        if (hb_new) (void)hipFree(hb_new);
+        return e == hipErrorOutOfMemory ? SPKM_OK : (int)e; // (no room: the shard simply stays as it is)
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&keys, (size_t)n * 4 + 64)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&perm, (size_t)n * 4 + 64)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&newmap, (size_t)n * 4 + 64)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&hb_new, ((size_t)3 * npad + HB_TAIL) * 4)) != hipSuccess) return fail(e);
+    int rc;
+    if ((rc = ensure(ctx, ctx->hist2, (size_t)K2 * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->offs2, (size_t)(K2 + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->cursor2, (size_t)K2 * 8))) return rc;
+    constexpr int RG_SEG = 2048; // (the plan's items are not used: only its offsets and cursors)
+    if ((rc = ensure(ctx, ctx->items2, (size_t)((n / RG_SEG) + K2 + 1) * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->nitems, 64))) return rc;
+    const unsigned g1 = (unsigned)std::min<long long>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(k_regroup_keys, dim3(g1), dim3(256), 0, ctx->stream, (const float*)sm->hb, npad, n, K,
+                       (const double*)(sm->hb_cum + sm->cum_par), keys);
+    HIP_TRY(hipMemsetAsync(ctx->hist2.p, 0, (size_t)K2 * 8, ctx->stream));
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)std::min<long long>(1024, (n + 1023) / 1024)), dim3(256), (size_t)K2 * 4, ctx->stream,
+                       (const int*)keys, n, K2, (unsigned long long*)ctx->hist2.p, (const unsigned*)nullptr);
+    hipLaunchKernelGGL(k_plan_segments, dim3(1), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->hist2.p, K2, RG_SEG,
+                       (long long*)ctx->offs2.p, (unsigned long long*)ctx->cursor2.p, (int4*)ctx->items2.p, (int*)ctx->nitems.p + 4,
+                       (const unsigned*)nullptr);
+    {
+        const int sb = (int)std::max<long long>(std::min<long long>(1024, (n + 1023) / 1024), std::min<long long>(8192, n / 4096));
+        const size_t sc = (size_t)((K2 + 1) & ~1) * 4 + (size_t)K2 * 12;
+        if (sc > 48 * 1024) (void)allow_lds(ctx, (const void*)k_scatter_by_cluster<true>, sc);
+        hipLaunchKernelGGL(k_scatter_by_cluster<true>, dim3(sb), dim3(256), sc, ctx->stream, (const int*)keys, n, K2,
+                           (unsigned long long*)ctx->cursor2.p, perm, (const unsigned*)nullptr, (const int*)nullptr);
+    }
+    hipLaunchKernelGGL(k_regroup_apply, dim3(g1), dim3(256), 0, ctx->stream, (const int*)perm, (const int*)sm->map, newmap,
+                       (const float*)sm->hb, hb_new, npad, n);
+    HIP_TRY(hipMemcpyAsync(hb_new + 3 * npad, sm->hb + 3 * npad, (size_t)HB_TAIL * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipGetLastError());
+    // the screen copy and the norms in the new order, over the old ones (their source is the records)
+    hipLaunchKernelGGL((k_screen_reorder<IR>), dim3((unsigned)std::min<long long>((n + 15) / 16, 16384)), dim3(256), 0, ctx->stream,
+                       (const IR*)nullptr, (const double*)nullptr, n, sm->fixed_s, (int)sm->p, sm->xfs, (IR*)sm->irs, sm->xnr,
+                       (const char*)sm->rec, sm->rec_R, (const int*)newmap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // (once per shard and run: the old arrays go back now)
+    (void)hipFree(keys);
+    (void)hipFree(perm);
+    (void)hipFree(sm->hb);
+    if (sm->map) (void)hipFree(sm->map);
+    sm->hb = hb_new;
+    sm->map = newmap;
+    sm->sp_clean = false;
     return SPKM_OK;
 }
 
@@ -1340,6 +1428,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     bool drift_ran = false; // k_center_drift compared this call's centroids with the previous call's (same[] is current)
     bool skipping = false, hinted = false, pt_mode = false, bounds_ok = false, kept = false, ev_path = false, ev_possible = false, pair_ev = false;
     bool sp_maintained = false; // this call's bounds test kept the block summaries
+    bool trusted = false;       // the caller's assignment buffer holds the library's copy (lazy contract): changes only are stored
     // bounds_ok: hb describes this shard's previous screen call (same K, gamma)
     if (quad) {
         if (!sm->hb || sm->hb_npad != npad) {
@@ -1358,6 +1447,16 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         }
         bounds_ok = sm->hb_valid && sm->hb_K == K && sm->hb_gamma == gamma;
         if (!sm->hb_cum) HIP_TRY(hipMalloc((void**)&sm->hb_cum, 16));
+        // data in arbitrary order: the previous call (over every point) found most 16-point steps mixing clusters -- the
+        // library's order of the points becomes "by cluster" now (regroup_shard; SPKM_NO_REGROUP=1: A/B switch).  Lazy shards
+        // only: with the library's order its own, the caller's buffers are reached through a map, which pays while they are
+        // written for the points that move and not for all of them.
+        if (sm->regroup_wanted && !sm->regroup_done && bounds_ok && sm->lazy && d_mind == nullptr && sm->rec != nullptr && sm->xfs != nullptr &&
+            !ctx->sw.no_regroup) {
+            if ((rc = regroup_shard<IR>(ctx, sm, K))) return rc;
+            sm->regroup_done = true;
+        }
+        sm->regroup_wanted = false;
         if (!bounds_ok) { // every lower bound is written afresh by this call: the accumulated drift starts over
             HIP_TRY(hipMemsetAsync(sm->hb_cum, 0, 16, ctx->stream));
             sm->cum_par = 0;
@@ -1496,6 +1595,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
             float* sp_slack = sp_on ? reinterpret_cast<float*>(sm->sp + (size_t)nblk * 16) : nullptr;
             int* sp_valid = sp_on ? reinterpret_cast<int*>(sm->sp + (size_t)nblk * 20) : nullptr;
             const int sp_reset = (sp_on && sm->sp_clean && sm->sp_assign == (const void*)d_assign) ? 0 : 1;
+            // (lazy statistics, the buffer of the previous call: it holds the library's copy -- spkm.h -- and is neither read
+            //  nor restored by the bounds test, and written by the certification only where a point moves)
+            //  -- used for a REGROUPED shard, where every access to the caller's buffer is a scattered one through the map; in
+            //  the caller's own order the test keeps repairing a buffer that differs, as it always did)
+            trusted = sm->map != nullptr && sm->lazy && d_mind == nullptr && sm->sp_assign == (const void*)d_assign;
             if (sp_on && !sp_reset && ctx->sw.check_assign) {
                 // SPKM_CHECK_ASSIGN=1 (debug aid for hosts other than ours): blocks are about to go unvisited on the strength of
                 // the lazy contract (spkm.h: the same buffer, not written to between calls) -- compare the caller's buffer
@@ -1503,7 +1607,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                 unsigned* cnt = (unsigned*)ctx->nlist.p + 20;
                 HIP_TRY(hipMemsetAsync(cnt, 0, 4, ctx->stream));
                 hipLaunchKernelGGL(k_count_diff_i32, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const int*)d_assign, (const int*)(sm->hb + 2 * npad), n, cnt);
+                                   (const int*)d_assign, (const int*)(sm->hb + 2 * npad), n, cnt, (const int*)sm->map);
                 unsigned diff = 0;
                 HIP_TRY(hipMemcpyAsync(&diff, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1515,11 +1619,11 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                 }
             }
             hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
-                               ctx->stream, sm->hb, npad, n, K, (int*)d_assign, (int*)ctx->todo.p,
+                               ctx->stream, sm->hb, npad, n, K, trusted ? (int*)nullptr : (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
                                pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1),
                                (int)span, (unsigned*)ctx->bstat.p, erode ? 1 : 0, sp_slack, sp_mask, sp_valid, sp_reset,
-                               (const int*)(sm->cl_flags + 2 * K));
+                               (const int*)(sm->cl_flags + 2 * K), (const int*)sm->map);
             sp_maintained = sp_on;
             bstat_n = (int)std::min<long long>((npad + span - 1) / span, bgrid);
             if (skip_enabled) sm->cum_par ^= 1; // the drift has been added
@@ -1572,7 +1676,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         // (built in an earlier call: point lists only appear once most points pass the bounds)
         const char* a_rec = (pt_mode && sm->rec) ? sm->rec : (const char*)nullptr;
         int a_recR = sm->rec_R;
-        const int* a_recmap = nullptr;
+        const int* a_recmap = sm->map;
         void* args[] = {&a_ir, &a_xf, &a_t, &a_p, &a_n, &a_s, &a_K, &a_bm, &a_chunk, &a_m1, &a_m2, &a_k, &a_extra,
                         &a_hint, &a_hc, &a_cnt, &a_todo, &a_tp, &a_rec, &a_recR, &a_recmap};
         HIP_TRY(hipLaunchKernel(kern, dim3(quad ? ctx->bmapq_blocks : ctx->bmap_blocks), dim3(1024), args, lds, ctx->stream));
@@ -1626,7 +1730,9 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // centroid reads, the squared terms and the per-point sums out (k_exact_accumulate_rec<..., DIST = false>); upper bounds
     // come from the screen's certificate as in an incremental call, objective and largest distance are NaN.
     const bool sums_only = cl_on && sm->lazy && d_mind == nullptr && !ev_path && !cl_skip && !ctx->sw.no_sums_only;
-    const bool lazy_ub = ev_path || sums_only; // the certificate writes the upper bounds (k_combine_screen, k_assign_list)
+    // the certificate writes the upper bounds (k_combine_screen, k_assign_list) -- also for a regrouped shard, whose exact
+    // pass walks the records in the caller's order and does not know the library's index of a point
+    const bool lazy_ub = ev_path || sums_only || sm->map != nullptr;
     ctx->last_sums_only = sums_only;
     // Form chosen on the device (SPKM_NO_DUAL=1: A/B switch): an incremental call issued WITHOUT a mover count -- a run's
     // second call: the counters come back one call late, and from a random start nearly every point moves -- queues the
@@ -1654,7 +1760,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
     // change an assignment -- and, against the previous call's value, mark the clusters a point left or entered and move
     // the cluster sizes (a separate pass comparing the two arrays used to do that: 0.16 ms per call at N = 1e8)
     int* a_lib = quad ? (int*)(sm->hb + 2 * npad) : (int*)nullptr;
-    if ((rc = ensure(ctx, ctx->wgstat, (size_t)3 * 4096 * 4))) return rc; // k_combine_screen's per-workgroup statistics
+    if ((rc = ensure(ctx, ctx->wgstat, (size_t)4 * 4096 * 4))) return rc; // k_combine_screen's per-workgroup statistics
     const int cb = (int)std::min<long long>(4096, (n + 255) / 256); // (8192+: the cold pass gains 6 %, the short lists of a converged run lose 70 %)
     hipLaunchKernelGGL(k_combine_screen, dim3(cb), dim3(256), ((nk_incr ? (size_t)K : 0) + (ev_path ? (size_t)2 * K : 0)) * 4, ctx->stream, (const float*)ctx->scr_m1.p,
                        (const float*)ctx->scr_m2.p, (const int*)ctx->scr_k.p, n, Gs, (const float*)s->xnr,
@@ -1666,7 +1772,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        nk_incr ? (unsigned long long*)ctx->nk.p : (unsigned long long*)nullptr,
                        lazy_ub ? 1 : 0, ev_path ? sm->ev_pt : (int*)nullptr, ev_path ? sm->ev_k : (int*)nullptr,
                        ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap,
-                       (unsigned*)ctx->wgstat.p, pair_ev ? sm->ev_o : (int*)nullptr);
+                       (unsigned*)ctx->wgstat.p, pair_ev ? sm->ev_o : (int*)nullptr, (const int*)sm->map,
+                       (trusted && bounds_ok) ? 1 : 0);
     hipLaunchKernelGGL((k_assign_list<IR>), dim3(std::max(1, ctx->num_cus) * 8), dim3(256), 0, ctx->stream,
                        (const long long*)s->jc, (const IR*)s->ir, (const double*)s->x, (const double*)ctx->ct.p, K,
                        s->fixed_s, (const int*)ctx->list.p, (const unsigned int*)ctx->nlist.p, (int*)d_assign,
@@ -1676,7 +1783,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                        ev_path ? sm->ev_k : (int*)nullptr, (unsigned*)ctx->nlist.p,
                        s->x == nullptr ? (const char*)sm->rec : (const char*)nullptr, sm->rec_R,
                        ev_path ? (unsigned long long*)ctx->nk_ev.p : (unsigned long long*)nullptr, ev_cap,
-                       (const unsigned*)ctx->wgstat.p, cb, pair_ev ? sm->ev_o : (int*)nullptr);
+                       (const unsigned*)ctx->wgstat.p, cb, pair_ev ? sm->ev_o : (int*)nullptr, (const int*)sm->map);
     ctx->sort_owner = nullptr; // until this call's sort (or its confirmation) has been queued
     ctx->last_lib_valid = bounds_ok;
     ctx->last_incremental = ev_path;
@@ -1896,7 +2003,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const double* a_C = d_centers;
         double a_gamma = gamma;
         double* a_mind = d_mind;
-        float* a_ub = quad ? sm->hb : (float*)nullptr;
+        float* a_ub = (quad && sm->map == nullptr) ? sm->hb : (float*)nullptr; // (a regrouped shard: the certificate wrote them)
         double *a_sums = sums, *a_counts = counts, *a_bo = (double*)ctx->blk_obj.p, *a_bm = (double*)ctx->blk_max.p;
         long long* a_bi = (long long*)ctx->blk_imax.p;
         void* args[] = {&a_rec, &a_R, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s,
@@ -1914,7 +2021,7 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
         const double* a_C = d_centers;
         double a_gamma = gamma;
         double* a_mind = d_mind;
-        float* a_ub = quad ? sm->hb : (float*)nullptr;
+        float* a_ub = (quad && sm->map == nullptr) ? sm->hb : (float*)nullptr; // (a regrouped shard: the certificate wrote them)
         double *a_sums = sums, *a_counts = counts, *a_bo = (double*)ctx->blk_obj.p, *a_bm = (double*)ctx->blk_max.p;
         long long* a_bi = (long long*)ctx->blk_imax.p;
         void* args[] = {&a_rec, &a_R, &a_ir, &a_x, &a_perm, &a_offs, &a_items, &a_nitems, &a_C, &a_gamma, &a_p, &a_s, &a_pts,
@@ -1991,6 +2098,13 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         c.listed = sm->h_nlist[0]; c.ambig = sm->h_nlist[1]; c.early = sm->h_nlist[2]; c.skipped = sm->h_nlist[3];
         c.kept = sm->h_nlist[12]; c.movers = sm->h_nlist[14];
         c.full_opened = sm->h_nlist[19] != 0u;
+        // data in arbitrary order: the call looked at every point in the library's order and fewer than half of its 16-point
+        // steps held one cluster -- the next call regroups the shard first (run_screen)
+        // (not while clusters overlap -- nine points in ten with a runner-up within 2.25x, what the policy calls crowded: their steps are mixed whatever the order,
+        //  and stay on the screen whatever their neighbours do)
+        if (sm->pend_full && sm->lazy && !sm->regroup_done && s->n >= 4096 &&
+            (double)sm->h_nlist[21] < 0.5 * (double)((s->n + 15) / 16) && (double)sm->h_nlist[1] < 0.9 * (double)s->n)
+            sm->regroup_wanted = true;
         sm->pol.observe(c, (double)s->n, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT), (s->fixed_s + 3) / 4);
     }
     const spkm_policy::choice ch = sm->pol.next(ctx->sw.no_prune, ctx->sw.no_hint, screen_use_quad(ctx, s));
@@ -2011,6 +2125,7 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
             sm->nlist_pending = true;
             sm->pol.launched(ctx->last_rounds_all, ctx->last_rounds, ctx->last_hinted, ctx->last_hint_late, ctx->last_skipping,
                              ctx->last_lib_valid, ctx->last_incremental, ctx->last_dual);
+            sm->pend_full = !ctx->last_skipping && screen_use_quad(ctx, s);
         }
         return SPKM_OK; // (statistics and cluster sizes were handed over by run_screen's last kernel)
     }
@@ -2053,7 +2168,7 @@ static int run_distances(spkm_ctx* ctx, const spkm_shard* s, int K, const double
             unsigned* cnt = (unsigned*)ctx->nlist.p + 20;
             HIP_TRY(hipMemsetAsync(cnt, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_count_diff_i32, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const int*)d_assign, (const int*)(s->hb + 2 * npad), n, cnt);
+                               (const int*)d_assign, (const int*)(s->hb + 2 * npad), n, cnt, (const int*)s->map);
             unsigned diff = 1;
             HIP_TRY(hipMemcpyAsync(&diff, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream)); // an end-of-run call, not the hot path
@@ -2242,14 +2357,28 @@ extern "C" int spkm_debug_shard_bounds(spkm_ctx* ctx, const spkm_shard* s, float
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t n = (size_t)s->n, npad = (size_t)s->hb_npad;
-    if (ub) HIP_TRY(hipMemcpy(ub, s->hb, n * 4, hipMemcpyDeviceToHost));
-    if (lib_assign) HIP_TRY(hipMemcpy(lib_assign, s->hb + 2 * npad, n * 4, hipMemcpyDeviceToHost));
+    // (a regrouped shard keeps its bounds in its own order: handed out in the caller's, point map[i] <- entry i)
+    std::vector<int> map;
+    if (s->map) {
+        map.resize(n);
+        HIP_TRY(hipMemcpy(map.data(), s->map, n * 4, hipMemcpyDeviceToHost));
+    }
+    auto at = [&](size_t i) { return s->map ? (size_t)map[i] : i; };
+    std::vector<float> tmp(n);
+    if (ub) {
+        HIP_TRY(hipMemcpy(tmp.data(), s->hb, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) ub[at(i)] = tmp[i];
+    }
+    if (lib_assign) {
+        std::vector<int32_t> ta(n);
+        HIP_TRY(hipMemcpy(ta.data(), s->hb + 2 * npad, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) lib_assign[at(i)] = ta[i];
+    }
     if (lb) {
-        std::vector<float> rel(n);
         double cum = 0.0;
-        HIP_TRY(hipMemcpy(rel.data(), s->hb + npad, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tmp.data(), s->hb + npad, n * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(&cum, s->hb_cum + s->cum_par, 8, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; i++) lb[i] = (double)rel[i] - cum;
+        for (size_t i = 0; i < n; i++) lb[at(i)] = (double)tmp[i] - cum;
     }
     return SPKM_OK;
 }

@@ -174,13 +174,14 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
     // registers; the ordered columns are staged in LDS, then written out in lane order
     __shared__ float s_x[16][64];
     __shared__ IR s_r[16][64];
-    __shared__ int s_a[16][64];            // |x| of the point's entries as f32 BITS (monotone for non-negative floats, NaN above
-                                           // everything: a total order whatever the data; -1: no entry), then the sort keys
     const int sub = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
+    const int lane = threadIdx.x & 63;
+    const int gsh = lane & 48; // first lane of this 16-lane group
     const int NR = (fixed_s + 3) >> 2;
     const int e1 = 4 * quad_split(NR), e2 = 4 * (quad_split_late(NR) > quad_split(NR) ? quad_split_late(NR) : quad_split(NR));
     const long long nsteps = (n + 15) >> 4;
+    const unsigned below = (1u << sub) - 1u;
     for (long long st = blockIdx.x; st < nsteps; st += gridDim.x) {
         const long long i = st * 16 + grp;
         const bool live = i < n;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
         const unsigned want = (unsigned)(i & 1);
         double xv[4];
         IR rv[4];
+        int key[4], seg[4];
         double nb = 0.0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -203,45 +205,54 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
                 rv[u] = ok ? ir[j0 + e] : (IR)0;
             }
             nb += xv[u] * xv[u];
-            s_a[grp][e] = ok ? (__builtin_bit_cast(int, (float)xv[u]) & 0x7fffffff) : -1;
+            // |x| as f32 bits (monotone for non-negative floats, NaN above everything) with the low 6 bits replaced by the
+            // entry's index: unique per entry, a total order whatever the data (the 2^-17 it moves a value by decides nothing
+            // but the order of near-equal entries); -1: no entry
+            key[u] = ok ? (((__builtin_bit_cast(int, (float)xv[u]) & 0x7fffffff) & ~63) | (63 - e)) : -1;
+            seg[u] = 2;
         }
-        __syncthreads();
-        // rank of each entry by (|x| descending, index ascending): a strict total order, all pairs (64 x 64 per point)
-        int rank[4] = {0, 0, 0, 0};
-        int mine[4];
+        // the e2 largest |x| of the point, one per pass: the group's maximum (keys are unique), its owner takes rank t
+        // (e2 <= 16 passes of ~25 instructions; a full ranking -- 64 x 64 comparisons per point -- made this kernel 4x slower)
+        for (int t = 0; t < e2; t++) {
+            int m = max(max(key[0], key[1]), max(key[2], key[3]));
+            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xf, 0xf, false));  // quad_perm:[1,0,3,2]
+            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xf, 0xf, false));  // quad_perm:[2,3,0,1]
+            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x141, 0xf, 0xf, false)); // row_half_mirror
+            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x140, 0xf, 0xf, false)); // row_mirror
 #pragma unroll
-        for (int u = 0; u < 4; u++) mine[u] = s_a[grp][u * 16 + sub];
-        for (int j = 0; j < 64; j++) {
-            const int o = s_a[grp][j];
-#pragma unroll
-            for (int u = 0; u < 4; u++) rank[u] += (o > mine[u] || (o == mine[u] && j < u * 16 + sub)) ? 1 : 0;
+            for (int u = 0; u < 4; u++)
+                if (key[u] == m && m >= 0) { seg[u] = t < e1 ? 0 : 1; key[u] = -1; }
         }
-        __syncthreads();
-        // key = segment | parity class | rank (unique per entry); slots without an entry stay behind everything, in index order
+        // place: by segment, inside a segment by row parity class (first class = the point's own parity), inside a class in
+        // index order -- counted with ballots over the 16 lanes of the point
+        int base = 0;
+#pragma unroll
+        for (int sg = 0; sg < 3; sg++) {
+#pragma unroll
+            for (int cl = 0; cl < 2; cl++) {
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = u * 16 + sub;
+                    const bool ok = live && e < fixed_s;
+                    const bool in = ok && seg[u] == sg && ((((unsigned)rv[u] & 1u) == want) ? 0 : 1) == cl;
+                    const unsigned mk = (unsigned)((__ballot(in) >> gsh) & 0xffffull);
+                    if (in) {
+                        const int pos = base + cnt + __builtin_popcount(mk & below);
+                        s_x[grp][pos] = (float)xv[u];
+                        const unsigned row = (unsigned)rv[u];
+                        s_r[grp][pos] = (IR)((row << 3) ^ ((row >> 1) & 3u)); // LDS row offset / 16 with the tile swizzle folded in
+                    }
+                    cnt += __builtin_popcount(mk);
+                }
+                base += cnt;
+            }
+        }
+        // slots past the column / past the last point: x = 0 on the all-zero row p
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
-            const bool ok = live && e < fixed_s;
-            const int seg = rank[u] < e1 ? 0 : (rank[u] < e2 ? 1 : 2);
-            const int cls = (((unsigned)rv[u] & 1u) == want) ? 0 : 1;
-            const int key = ok ? ((seg << 7) | (cls << 6) | rank[u]) : ((3 << 7) | e);
-            s_a[grp][e] = key;
-            rank[u] = key;
-        }
-        __syncthreads();
-        int pos[4] = {0, 0, 0, 0};
-        for (int j = 0; j < 64; j++) {
-            const int o = s_a[grp][j];
-#pragma unroll
-            for (int u = 0; u < 4; u++) pos[u] += (o < rank[u]) ? 1 : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = u * 16 + sub;
-            const bool ok = live && e < fixed_s;
-            s_x[grp][pos[u]] = ok ? (float)xv[u] : 0.f;   // slots past the column / past the last point: x = 0, row p
-            const unsigned row = ok ? (unsigned)rv[u] : (unsigned)p;
-            s_r[grp][pos[u]] = (IR)((row << 3) ^ ((row >> 1) & 3u)); // LDS row offset / 16 with the tile swizzle folded in
+            if (e >= base) { s_x[grp][e] = 0.f; s_r[grp][e] = (IR)(((unsigned)p << 3) ^ (((unsigned)p >> 1) & 3u)); }
         }
         __syncthreads();
         float* xo = xfs + (size_t)st * NR * 64;
@@ -625,8 +636,12 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                                                       unsigned* __restrict__ blkstat, int erode,
                                                       float* __restrict__ sp_slack = nullptr, unsigned* __restrict__ sp_mask = nullptr,
                                                       int* __restrict__ sp_valid = nullptr, int sp_reset = 0,
-                                                      const int* __restrict__ same = nullptr)
+                                                      const int* __restrict__ same = nullptr,
+                                                      const int* __restrict__ map = nullptr)
 {
+    // assign == nullptr: the caller's buffer is known to hold the library's copy already (lazy statistics, the same buffer as
+    // in the previous call: spkm.h) -- it is neither read nor restored.  map != nullptr (a regrouped shard, api.hip): point i of
+    // the library's order is the caller's point map[i].
     // BLOCK SUMMARIES (sp_slack != nullptr; lazy calls with K <= 128 only, api.hip): per 1024 consecutive points
     //   sp_slack = min_i [ lb_i (1 - 1e-6) - ub_i (1 + 1e-6) ]   (lb as stored: relative to the accumulated drift `cum`)
     //   sp_mask  = the clusters its points belong to (K bits)
@@ -756,7 +771,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             apv[u] = in ? reinterpret_cast<const int*>(bnd)[2 * npad + i] : 0;
             // what the caller's buffer holds now, fetched with the rest (behind the test it would be a second memory
             // round trip per group): a point that keeps its assignment is stored only if the buffer differs
-            curv[u] = (in && skip_enabled) ? assign[i] : 0;
+            curv[u] = (in && skip_enabled && assign != nullptr) ? assign[map != nullptr ? map[i] : i] : apv[u];
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) dav[u] = bnd[3 * npad + apv[u]];
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                 bm0 |= w == 0 ? bit : 0u; bm1 |= w == 1 ? bit : 0u; bm2 |= w == 2 ? bit : 0u; bm3 |= w == 3 ? bit : 0u;
             }
             if (pt_mode) {
-                if (keep && i < n && curv[u] != apv[u]) assign[i] = apv[u]; // (see the step mode below)
+                if (keep && i < n && curv[u] != apv[u]) assign[map != nullptr ? map[i] : i] = apv[u]; // (see the step mode below)
                 if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
                 const unsigned long long lm = ~b; // (lanes past n count as kept)
                 if (lm) {
@@ -804,7 +819,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
             // a caller that passes the same buffer call after call already holds this value: a 4-B read instead of a
             // 4-B store (a gigabyte of stores costs as much as several of loads here)
-            if (skip && i < n && curv[u] != apv[u]) assign[i] = apv[u];
+            if (skip && i < n && curv[u] != apv[u]) assign[map != nullptr ? map[i] : i] = apv[u];
             if (!skip && i < n && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
             const bool lead = (lane & 15) == 0 && live_step && !skip;
             const unsigned long long lm = __ballot(lead);
@@ -969,6 +984,43 @@ __global__ void k_pick_form(unsigned* __restrict__ counters, unsigned ev_cap, in
     nitems[2] = 0; // (pair events: the first-level plan's chunk list)
 }
 
+// REGROUPING a shard whose 16-point steps mix clusters (data in arbitrary order; api.hip, regroup_shard): the library's own
+// order of the points -- the order of the screen copy and of everything it keeps per point -- becomes "by cluster, and inside
+// a cluster the points that are sure of it first", so that a step's 16 points share their centroid and their prospects: a
+// step is skipped on the carried bounds, or finished early by the hinted form, only if all 16 points allow it.  The records
+// (and with them every per-point array of the caller) stay where they are; map[i] = the caller's index of the library's
+// point i.  kmeans_sparsified.m:430-431 adds up find(assignments == k): no order of the points enters any result.
+//   key = 2 * cluster + (1 if the runner-up bound is within 1.5x of the upper bound: the point may well move)
+__global__ __launch_bounds__(256) void k_regroup_keys(const float* __restrict__ bnd, long long npad, long long n, int K,
+                                                      const double* __restrict__ cum, int* __restrict__ keys)
+{
+    const double cum_now = *cum;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float ub = bnd[i];
+        const double lb = (double)bnd[npad + i] - cum_now;
+        int a = reinterpret_cast<const int*>(bnd)[2 * npad + i];
+        if ((unsigned)a >= (unsigned)K) a = 0;
+        keys[i] = 2 * a + ((lb >= 1.5 * (double)ub) ? 0 : 1); // (NaN: unsure)
+    }
+}
+// the per-point state in the new order: new point j was point perm[j]; newmap[j] = oldmap[perm[j]] (oldmap null: identity)
+__global__ __launch_bounds__(256) void k_regroup_apply(const int* __restrict__ perm, const int* __restrict__ oldmap,
+                                                       int* __restrict__ newmap, const float* __restrict__ bnd_old,
+                                                       float* __restrict__ bnd_new, long long npad, long long n)
+{
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < npad; j += (long long)gridDim.x * blockDim.x) {
+        if (j < n) {
+            const int o = perm[j];
+            newmap[j] = oldmap != nullptr ? oldmap[o] : o;
+            bnd_new[j] = bnd_old[o];
+            bnd_new[npad + j] = bnd_old[npad + o];
+            bnd_new[2 * npad + j] = bnd_old[2 * npad + o];
+        } else {
+            bnd_new[j] = 0.f; bnd_new[npad + j] = 0.f; bnd_new[2 * npad + j] = 0.f;
+        }
+    }
+}
+
 // jc of a fixed-stride shard that was created from records: jc[i] = i * s
 __global__ void k_fill_jc(long long* __restrict__ jc, long long n, long long s)
 {
@@ -1015,8 +1067,15 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         unsigned long long* __restrict__ nk,
                                                         int lazy, int* __restrict__ ev_pt, int* __restrict__ ev_k,
                                                         unsigned long long* __restrict__ nk_ev, unsigned ev_cap,
-                                                        unsigned* __restrict__ wgstat, int* __restrict__ ev_o = nullptr)
+                                                        unsigned* __restrict__ wgstat, int* __restrict__ ev_o = nullptr,
+                                                        const int* __restrict__ map = nullptr, int trusted = 0)
 {
+    // map != nullptr (a regrouped shard, api.hip): point i of the library's order is the caller's point map[i] -- what is
+    // written to the caller's assignment buffer and into the events (the records are in the caller's order) goes through it;
+    // trusted: the caller's buffer already holds the library's copy (lazy statistics, same buffer as last call), so only
+    // CHANGES are stored -- through a map every store is a scattered 4-byte write.
+    // wgstat[4 b + 3] (calls over all points): 16-point steps whose points share one cluster -> nlist[21]; the host regroups a
+    // shard whose steps are mixed (data in arbitrary order).
     // ev_o != nullptr: PAIR events -- ONE event per mover, (point, new cluster in ev_k, old cluster or -1 in ev_o), and the
     // histogram nk_ev over the K new clusters only: the events are then sorted by (new, old) pair and every mover's record
     // is read once, into its new cluster's sums and out of its old one's (api.hip, k_accumulate_events<.., PAIR>); else
@@ -1065,16 +1124,16 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     unsigned nambig = 0;
     // skipping: k_bounds_steps has settled the skipped steps; only the listed ones (nlist[4] of them) are looked at
     const long long total = skipping ? (pt_mode ? (long long)nlist[4] : (long long)nlist[4] * 16) : n;
-    __shared__ unsigned s_amb, s_chg;
+    __shared__ unsigned s_amb, s_chg, s_hom;
     if ((long long)blockIdx.x * blockDim.x >= total) { // (whole workgroup)
-        if (threadIdx.x == 0) { wgstat[3 * blockIdx.x] = 0u; wgstat[3 * blockIdx.x + 1] = 0u; wgstat[3 * blockIdx.x + 2] = 0u; }
+        if (threadIdx.x == 0) { wgstat[4 * blockIdx.x] = 0u; wgstat[4 * blockIdx.x + 1] = 0u; wgstat[4 * blockIdx.x + 2] = 0u; wgstat[4 * blockIdx.x + 3] = 0u; }
         return;
     }
-    if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; s_over = 0u; }
+    if (threadIdx.x == 0) { s_amb = 0u; s_chg = 0u; s_evn = 0u; s_mov = 0u; s_over = 0u; s_hom = 0u; }
     if (nk) for (int k = threadIdx.x; k < K; k += blockDim.x) delta[k] = 0;
     if (ev_pt) for (int k = threadIdx.x; k < (pair ? K : 2 * K); k += blockDim.x) evc[k] = 0u;
     __syncthreads();
-    unsigned nmov = 0;
+    unsigned nmov = 0, nhomog = 0;
     auto flush_events = [&]() { // (whole workgroup)
         if (threadIdx.x == 0) { s_evbase = atomicAdd(nlist + 16, s_evn); if (s_evbase > ev_cap) s_over = 1u; }
         __syncthreads();
@@ -1092,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     for (long long q0 = (long long)blockIdx.x * blockDim.x; q0 < total; q0 += (long long)gridDim.x * blockDim.x) {
       const long long q = q0 + threadIdx.x;
       bool mover = false;
-      int mv_old = -1, mv_new = 0;
+      int mv_old = -1, mv_new = 0, mine_k = -1;
       long long i = n;
       if (q < total) i = skipping ? (pt_mode ? (long long)todo[q] : (long long)todo[q >> 4] * 16 + (q & 15)) : q;
       if (i < n) {
@@ -1115,9 +1174,11 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         const double e1 = E + gacc * r1 + 1e-20, e2 = E + gacc * r2 + 1e-20;
         const bool certified = (bk >= 0) && ((r1 + e1) * (1.0 + nu) < (r2 - e2) * (1.0 - nu));
         const int newk = bk >= 0 ? bk : 0;
-        assign[i] = newk; // (the caller's buffer; tentative for an uncertified point)
+        const long long ic = map != nullptr ? (long long)map[i] : i; // the caller's index of this point
+        const int old = (alib && lib_valid) ? alib[i] : -1;
+        if (!(trusted && lib_valid) || old != newk) assign[ic] = newk; // (the caller's buffer; tentative for an uncertified point)
+        mine_k = newk;
         if (alib && certified) {
-            const int old = lib_valid ? alib[i] : -1;
             if (old != newk) {
                 alib[i] = newk;
                 if (lib_valid) {
@@ -1147,6 +1208,11 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         // could not separate; the host decides from this count whether the next call may use the two-phase screen
         if (!(r2 >= 2.25 * r1)) nambig++;
       }
+      if (!skipping) { // (q = i: the wave's lanes are four whole 16-point steps)
+          const int kf = __shfl(mine_k, threadIdx.x & 48);
+          const unsigned long long eq = __ballot(mine_k == kf && i < n);
+          if ((threadIdx.x & 15) == 0 && i < n && (unsigned)((eq >> (threadIdx.x & 48)) & 0xffffull) == 0xffffu) nhomog++;
+      }
       // (s_over: the full pass will run whatever else moves, k_pick_form -- no event of this workgroup is needed any more;
       //  the flag changes only inside flush_events, between barriers: the same for every thread of a trip)
       if (ev_pt && !s_over && __syncthreads_or(mover ? 1 : 0)) { // (every thread of the workgroup gets here in every trip; no mover: nothing to stage)
@@ -1162,8 +1228,9 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
         }
         if (mover) {
             unsigned at = wbase + (unsigned)(incl - cnt);
-            if (!pair && mv_old >= 0) { s_evp[at] = (int)i; s_evk[at] = K + mv_old; at++; atomicAdd(&evc[K + mv_old], 1u); }
-            s_evp[at] = (int)i; s_evk[at] = pair ? (mv_new | ((mv_old + 1) << 16)) : mv_new;
+            const int ie = map != nullptr ? map[i] : (int)i; // (the records the events are applied from are in the caller's order)
+            if (!pair && mv_old >= 0) { s_evp[at] = ie; s_evk[at] = K + mv_old; at++; atomicAdd(&evc[K + mv_old], 1u); }
+            s_evp[at] = ie; s_evk[at] = pair ? (mv_new | ((mv_old + 1) << 16)) : mv_new;
             atomicAdd(&evc[mv_new], 1u);
         }
         __syncthreads();
@@ -1178,11 +1245,14 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     for (int off = 32; off > 0; off >>= 1) nambig += __shfl_down(nambig, off);
     if ((threadIdx.x & 63) == 0 && nambig) atomicAdd(&s_amb, nambig);
     if (__any(changed) && (threadIdx.x & 63) == 0) s_chg = 1u;
+    for (int off = 32; off > 0; off >>= 1) nhomog += __shfl_down(nhomog, off);
+    if ((threadIdx.x & 63) == 0 && nhomog) atomicAdd(&s_hom, nhomog);
     __syncthreads();
     if (threadIdx.x == 0) {
-        wgstat[3 * blockIdx.x] = s_amb;
-        wgstat[3 * blockIdx.x + 1] = s_chg;
-        wgstat[3 * blockIdx.x + 2] = s_mov;
+        wgstat[4 * blockIdx.x] = s_amb;
+        wgstat[4 * blockIdx.x + 1] = s_chg;
+        wgstat[4 * blockIdx.x + 2] = s_mov;
+        wgstat[4 * blockIdx.x + 3] = s_hom;
     }
     if (nk)
         for (int k = threadIdx.x; k < K; k += blockDim.x)
@@ -1207,20 +1277,23 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                                                      const char* __restrict__ rec, int rec_R,
                                                      unsigned long long* __restrict__ nk_ev, unsigned ev_cap,
                                                      const unsigned* __restrict__ wgstat, int nwg,
-                                                     int* __restrict__ ev_o = nullptr)
+                                                     int* __restrict__ ev_o = nullptr, const int* __restrict__ map = nullptr)
 {
+    // map != nullptr (a regrouped shard): listed point i of the library's order is the caller's point map[i] -- its record,
+    // its place in the caller's assignment buffer, its id in the events
     // ev_o != nullptr: pair events, one per mover (k_combine_screen)
     // wgstat / nwg: k_combine_screen's per-workgroup statistics (ambiguous points, changed flag, movers); the LAST
     // workgroup of this launch adds them into counters[1], *changed (counters[5]) and counters[14] -- nobody reads those
     // before this kernel has finished
     if (blockIdx.x == gridDim.x - 1) {
-        unsigned a = 0u, c = 0u, m = 0u;
-        for (int b = threadIdx.x; b < nwg; b += blockDim.x) { a += wgstat[3 * b]; c += wgstat[3 * b + 1]; m += wgstat[3 * b + 2]; }
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); m += __shfl_down(m, off); }
+        unsigned a = 0u, c = 0u, m = 0u, h = 0u;
+        for (int b = threadIdx.x; b < nwg; b += blockDim.x) { a += wgstat[4 * b]; c += wgstat[4 * b + 1]; m += wgstat[4 * b + 2]; h += wgstat[4 * b + 3]; }
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); m += __shfl_down(m, off); h += __shfl_down(h, off); }
         if ((threadIdx.x & 63) == 0) {
             if (a) atomicAdd(counters + 1, a);
             if (c) atomicAdd(changed, c);
             if (m) atomicAdd(counters + 14, m);
+            if (h) atomicAdd(counters + 21, h);
         }
     }
     // alib / lib_valid / touched / nk: the library's copy of the assignment and what follows from a change, as in
@@ -1235,19 +1308,20 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
     const long long cnt = *nlist;
     for (long long q = wave; q < cnt; q += nwaves) {
         const long long i = list[q];
+        const long long ic = map != nullptr ? (long long)map[i] : i;
         const double* xq;
         const IR* rq;
         int ne;
         if (rec != nullptr) {
-            const char* b = rec + (size_t)i * (size_t)rec_R;
+            const char* b = rec + (size_t)ic * (size_t)rec_R;
             xq = reinterpret_cast<const double*>(b);
             rq = reinterpret_cast<const IR*>(b + (size_t)fixed_s * 8);
             ne = fixed_s;
         } else {
-            const long long j0 = fixed_s > 0 ? i * fixed_s : jc[i];
+            const long long j0 = fixed_s > 0 ? ic * fixed_s : jc[ic];
             xq = xval + j0;
             rq = ir + j0;
-            ne = fixed_s > 0 ? fixed_s : (int)(jc[i + 1] - j0);
+            ne = fixed_s > 0 ? fixed_s : (int)(jc[ic + 1] - j0);
         }
         double best = __builtin_inf();
         int bk = 0x7fffffff;
@@ -1289,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
         }
         if (lane == 0) {
             if ((unsigned)bk >= (unsigned)K) bk = 0; // non-finite distances: MATLAB's min() gives index 1; never an out-of-range cluster
-            assign[i] = bk;
+            assign[ic] = bk;
             if (ubv) ubv[i] = __double2float_ru(best * (1.0 + 1e-12)); // (inf / NaN: the point fails every later test)
             if (alib) {
                 const int old = lib_valid ? alib[i] : -1;
@@ -1303,13 +1377,13 @@ __global__ __launch_bounds__(256) void k_assign_list(const long long* __restrict
                         if (nk) { if (vo) atomicAdd(&nk[old], ~0ull); atomicAdd(&nk[bk], 1ull); }
                         if (ev_pt && ev_o != nullptr) {
                             const unsigned at = atomicAdd(counters + 16, 1u);
-                            if (at <= ev_cap) { ev_pt[at] = (int)i; ev_k[at] = bk; ev_o[at] = vo ? old : -1; }
+                            if (at <= ev_cap) { ev_pt[at] = (int)ic; ev_k[at] = bk; ev_o[at] = vo ? old : -1; }
                             atomicAdd(&nk_ev[bk], 1ull);
                         } else if (ev_pt) {
                             const unsigned at = atomicAdd(counters + 16, vo ? 2u : 1u);
                             if (at <= ev_cap) { // (k_combine_screen: past the cap the events are only counted)
-                                if (vo) { ev_pt[at] = (int)i; ev_k[at] = K + old; }
-                                ev_pt[at + (vo ? 1u : 0u)] = (int)i; ev_k[at + (vo ? 1u : 0u)] = bk;
+                                if (vo) { ev_pt[at] = (int)ic; ev_k[at] = K + old; }
+                                ev_pt[at + (vo ? 1u : 0u)] = (int)ic; ev_k[at + (vo ? 1u : 0u)] = bk;
                             }
                             if (vo) atomicAdd(&nk_ev[K + old], 1ull);
                             atomicAdd(&nk_ev[bk], 1ull);
@@ -1440,12 +1514,13 @@ __global__ __launch_bounds__(256) void k_point_distances(const long long* __rest
     }
 }
 
+// (map != nullptr: b is in a regrouped shard's own order, b[i] belongs to a[map[i]])
 __global__ __launch_bounds__(256) void k_count_diff_i32(const int* __restrict__ a, const int* __restrict__ b, long long n,
-                                                        unsigned* __restrict__ out)
+                                                        unsigned* __restrict__ out, const int* __restrict__ map = nullptr)
 {
     unsigned c = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        c += a[i] != b[i];
+        c += a[map != nullptr ? map[i] : i] != b[i];
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
@@ -1812,12 +1887,7 @@ template __global__ void k_screen_tile<unsigned short>(const unsigned short*, co
     int, int, const spkm_blockmap*, int, float*, float*, int*);
 template __global__ void k_screen_tile<unsigned int>(const unsigned int*, const float*, const float*, int, int, int,
     int, const spkm_blockmap*, int, float*, float*, int*);
-template __global__ void k_assign_list<unsigned short>(const long long*, const unsigned short*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int, int*);
-template __global__ void k_assign_list<unsigned int>(const long long*, const unsigned int*, const double*,
-    const double*, int, int, const int*, const unsigned int*, int*, int*, int, unsigned*, int*, unsigned long long*,
-    float*, int*, int*, unsigned*, const char*, int, unsigned long long*, unsigned, const unsigned*, int, int*);
+
 
 // ============================================================================================
 // K = 1: the distance of every point to ONE centre (the k-means++ rounds, Arthur_initialization.m:39 through

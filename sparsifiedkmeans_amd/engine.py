@@ -116,6 +116,13 @@ class Shard:
                                                       a.ctypes.data), "spkm_debug_shard_bounds")
         return ub, lb, a
 
+    def order_info(self) -> tuple[bool, bool]:
+        """(the library keeps this shard's points in an order of its own, it regrouped them since the last reset_policy) --
+        spkm_shard_order_info: data in arbitrary order is regrouped by cluster inside the library; nothing the caller sees moves."""
+        a = (C.c_int64 * 2)()
+        _lib.check(_lib.lib().spkm_shard_order_info(self.handle, a), "spkm_shard_order_info")
+        return bool(a[0]), bool(a[1])
+
     def reset_policy(self):
         """New start / new replicate: drop the adaptive state of the fused call (spkm_shard_reset_policy)."""
         _lib.check(_lib.lib().spkm_shard_reset_policy(self.handle), "spkm_shard_reset_policy")

@@ -856,6 +856,60 @@ def test_carried_bounds_stay_bounds_through_every_kind_of_lazy_call(gpu_ctx, ora
         assert bad_lb.size == 0, (it, what, forms, bad_lb[:5], lb[bad_lb[:5]], other[bad_lb[:5]])
     shard.set_lazy_stats(False)
     assert 2 in forms and 3 in forms[1:], forms                        # events, and a sums-only pass on valid bounds, both ran
+    # (data in arbitrary order may have been regrouped inside the library on the way: the bounds above were handed out in the
+    #  caller's order through its map)
+    assert not shard.order_info()[0] or shuffled, shard.order_info()   # cluster-contiguous data is left as it lies
+
+
+@pytest.mark.parametrize("regroup", [True, False])
+def test_data_in_arbitrary_order_is_regrouped_inside_the_library_and_nothing_the_caller_sees_moves(gpu_ctx, oracle, monkeypatch, regroup):
+    """A lazy run on shuffled data: after its first call the library regroups ITS order of the points by cluster
+    (spkm_shard_order_info; SPKM_NO_REGROUP=1: not).  Every iteration: assignments the oracle's bit for bit in the CALLER's
+    order, centres the members' means; at the end the distances on demand and their statistics are the oracle's, a column
+    read back is the caller's column, and a second run after reset_policy (a new start) is exact as well."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+    import scipy.sparse as sp
+
+    p, n, K, gopt = 256, 24000, 20, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=77, noise=0.1)   # (separated clusters: overlapping ones are not regrouped)
+    X = X[:, np.random.default_rng(4).permutation(n)]
+    rng = np.random.default_rng(6)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    s = synth.small_p_of(gopt, p)
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    Yones = Y.copy(); Yones.data[:] = 1.0
+    gam = s / p
+    if not regroup:
+        set_switch(monkeypatch, gpu_ctx, "SPKM_NO_REGROUP")
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    shard.set_lazy_stats(True)
+    jc, ir, x = parts(Y)
+    for run in range(2):
+        shard.reset_policy()
+        eng = LloydEngine(shard, K, gam)
+        C0 = oracle.mix(X[:, np.random.default_rng(10 + run).choice(n, K, replace=False)], d, p)
+        c = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
+        for it in range(10):
+            used = c.cpu().numpy().T.copy()
+            eng.iterate(c, want_mind=False)
+            torch.cuda.synchronize()
+            ra, rd = oracle.assign(p, n, jc, ir, x, used, gam)
+            assert np.array_equal(eng.assign.cpu().numpy(), ra), (run, it)
+            ind = sp.csr_matrix((np.ones(n), (ra, np.arange(n))), shape=(K, n))
+            S, Cnt = (Y @ ind.T).toarray(), (Yones @ ind.T).toarray()
+            refc = np.where(np.bincount(ra, minlength=K)[None, :] > 0, gam * S / (Cnt + 1e-16), used)
+            assert np.abs(c.cpu().numpy().T - refc).max() <= 1e-9 * np.abs(refc).max(), (run, it)
+        assert shard.order_info()[0] == regroup, shard.order_info()
+        eng.distances(torch.tensor(np.ascontiguousarray(used.T), device="cuda"))
+        assert np.array_equal(eng.mind.cpu().numpy(), rd)
+        st = eng.stats.cpu().numpy()
+        assert abs(st[0] - np.sum(rd * rd)) <= 1e-9 * np.sum(rd * rd) and st[1] == rd.max() and int(st[2]) == int(np.argmax(rd))
+    shard.release_csc()
+    for col in (0, 1, n // 3, n - 1):
+        rows, vals = shard.column(col)
+        assert np.array_equal(rows, Y.indices[Y.indptr[col]:Y.indptr[col + 1]]) and np.array_equal(vals, Y.data[Y.indptr[col]:Y.indptr[col + 1]])
+    shard.set_lazy_stats(False)
 
 
 @pytest.mark.parametrize("direct", [True, False])

@@ -31,7 +31,7 @@ while time.time() < t_end:
     iters = int(rng.integers(6, 26))
     # the library's A/B switches (none may change an output): each on in about one case of six
     switches = ["SPKM_NO_REC", "SPKM_NO_CLUSTER_SKIP", "SPKM_NO_POINT_LIST", "SPKM_NO_LATE_SPLIT", "SPKM_NO_INCREMENTAL",
-                "SPKM_NO_HINT", "SPKM_NO_PRUNE", "SPKM_NO_BOUNDS", "SPKM_CHECK_ASSIGN",
+                "SPKM_NO_HINT", "SPKM_NO_PRUNE", "SPKM_NO_BOUNDS", "SPKM_CHECK_ASSIGN", "SPKM_NO_REGROUP",
                 "SPKM_NO_SUPPORT_DRIFT", "SPKM_NO_TEAMS", "SPKM_NO_DUAL", "SPKM_NO_SUMS_ONLY", "SPKM_NO_BLOCK_SKIP",
                 "SPKM_NO_DIRECT_EVENTS", "SPKM_NO_PAIR_EVENTS", "SPKM_FORCE_PAIR_EVENTS", "SPKM_FORCE_PAIR_EVENTS"]
     on = [w for w in switches if rng.random() < 1 / 6]
