@@ -6,6 +6,7 @@ quad_round_block / own_round_block) with parts left out or rearranged, for tools
   own_full / own_noreads / own_nomath               every lane keeps all entries of its point: no DPP broadcast
   own_pipe_*                                        the same, the next round's reads in flight during this round's arithmetic
   bc_mix16                                          f16 tile of 64 centroids, v_fma_mix_f32 + v_fma_f32 per centroid
+  bc_pk16                                           f16 tile of 32 centroids in 64-B rows, v_pk_add_f16 + v_pk_fma_f16 (round 5)
 Run from the repo root:  python tools/gen_ubench_quad_variants.py"""
 import os
 import sys
@@ -111,6 +112,26 @@ def mix_block():
     return SEP.join(L)
 
 
+def pk16_block():
+    """packed-f16 round (round 5's capped experiment): tile rows of 32 f16 centroids = 64 B, ONE ds_read_b128 per entry and lane
+    (8 centroids), v_pk_add_f16 + v_pk_fma_f16 on packed halves, f16 accumulators"""
+    L = ["s_nop 1"]
+    for m in range(4):
+        T = QT + 4 * m
+        L += [f"v_xor_b32_dpp %[a{m}], %[ro], %[off0] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf",
+              f"ds_read_b128 v[{T}:{T+3}], %[a{m}]"]
+    for m in range(4):
+        L.append(f"v_mov_b32_dpp v{QX + m}, %[xi] quad_perm:[{m},{m},{m},{m}] row_mask:0xf bank_mask:0xf")
+    for m in range(4):
+        T = QT + 4 * m
+        L.append(f"s_waitcnt lgkmcnt({3 - m})")
+        for w in range(4):
+            L.append(f"v_pk_add_f16 v{T + w}, v{T + w}, v{QX + m}")
+        for w in range(4):
+            L.append(f"v_pk_fma_f16 %[c{w}], v{T + w}, v{T + w}, %[c{w}]")
+    return SEP.join(L)
+
+
 def main():
     b, o = G.quad_round_block(4, 4), G.own_round_block(4, 4)
     noaddr = variant(b, ["v_xor_b32_dpp", "v_add_u32", "v_mov_b32_dpp"])
@@ -129,6 +150,10 @@ def main():
                f'{{ int a0, a1, a2, a3, b0, b1, b2, b3; asm volatile("{mix_block()}" : {accs}, [a0] "=&v"(a0), [a1] "=&v"(a1), '
                f'[a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3) : [xi] "v"(xi), '
                f'[ro] "v"(ro), [off0] "v"(off0), [delta] "v"(delta) : {clob}); }}\n')
+    clob16 = ", ".join(f'"v{r}"' for r in range(QX, QT + 16))
+    out.append(f"__device__ __forceinline__ void bc_pk16(int xi, int ro, int off0, int& c0, int& c1, int& c2, int& c3)\n"
+               f'{{ int a0, a1, a2, a3; asm volatile("{pk16_block()}" : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), '
+               f'[a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3) : [xi] "v"(xi), [ro] "v"(ro), [off0] "v"(off0) : {clob16}); }}\n')
     with open(os.path.join(ROOT, "tools", "ubench_quad_variants.inc"), "w") as f:
         f.write("".join(out))
 

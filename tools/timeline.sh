@@ -9,7 +9,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
 raw=/tmp/timeline_$tag; rm -rf $raw; mkdir -p $raw $root/gpurun_out/timeline_$tag
 cd /tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $raw -o t -- python $root/${TIMELINE_SCRIPT:-bench.py} "$@" > $root/gpurun_out/timeline_$tag/bench.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $raw -o t -- python $root/${TIMELINE_SCRIPT:-bench.py} "$@" > $root/gpurun_out/timeline_$tag/bench.log 2>&1
 f=$(find $raw -name "*kernel_trace.csv" | head -1)
 m=$(find $raw -name "*memory_copy_trace.csv" | head -1)
 python - "$f" "$m" > $root/gpurun_out/timeline_$tag/timeline.txt <<'PY'

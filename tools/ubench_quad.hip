@@ -46,6 +46,15 @@ __global__ __launch_bounds__(THREADS) void k(float* out, int iters, unsigned lon
 #pragma unroll
             for (int j = 0; j < 16; j++) acc4 += c[j];
             acc0 = (double)acc4;
+        } else if (VAR == 5) {   // packed f16: 32 centroids in 64-B rows, one ds_read_b128 per entry, v_pk_add_f16 + v_pk_fma_f16
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            const int off16 = l4 * 16;
+            for (int it = 0; it < iters; it++) {
+#pragma unroll
+                for (int r = 0; r < NR; r++) bc_pk16((int)(0x3c003c00u ^ (hash(q + r) & 0x00ff00ffu)), (o[r] >> 1) & ~63, off16, c0, c1, c2, c3);
+                c0 &= 0x3bff3bff; c1 &= 0x3bff3bff; c2 &= 0x3bff3bff; c3 &= 0x3bff3bff; // (keep the f16 sums finite)
+            }
+            acc0 = (double)(c0 ^ c1 ^ c2 ^ c3);
         } else
         for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -119,6 +128,8 @@ int main()
     run<0, 1024, 2>("broadcast, no packed math", d_out, iters);
     run<0, 1024, 3>("broadcast math + reads, no addr ops", d_out, iters);
     run<0, 1024, 4>("f16 tile, 64 centroids (x0.5 steps)", d_out, iters);
+    run<0, 1024, 5>("packed f16, 32 centroids, 64-B rows", d_out, iters);
+    run<0, 768, 5>("packed f16, 32 centroids, 64-B rows", d_out, iters);
     run<0, 768>("broadcast form (quad_round)", d_out, iters);
     run<0, 768, 1>("broadcast, no LDS reads", d_out, iters);
     run<0, 768, 2>("broadcast, no packed math", d_out, iters);
