@@ -286,7 +286,9 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload != "config5":
         cpu_data = cpu_sample_arrays(data, centers0, s, min(max(args.cpu_sample, 4_000_000), n_local))
     loop = Loop(shard, centers0)
-    loop.steps(max(args.warmup, 1))                 # (at least one call: it builds the shard's record layout and screen copy)
+    # (at least two calls: the first builds the shard's record layout and screen copy, the second is where a shard in
+    #  arbitrary order is regrouped inside the library -- one-off layout work, like the sparsifier: never in the timed window)
+    loop.steps(max(args.warmup, 2))
     torch.cuda.synchronize()
     free_pk, total_pk = torch.cuda.mem_get_info()   # the moment everything exists at once: dataset + the library's layouts + state
     hbm_after_first_call_GB = round((total_pk - free_pk) / 1e9, 1)
@@ -468,6 +470,7 @@ def main():
                    "datagen_s": round(t_gen, 1), "final_obj": final_obj,
                    "hbm_resident_GB": round((total_b - free_b) / 1e9, 1), "csc_released": bool(csc_released),
                    "hbm_after_first_call_GB": hbm_after_first_call_GB, "dataset_layout": "records" if "rec" in data else "csc",
+                   "library_order": dict(zip(("own_order", "regrouped_in_last_run"), shard.order_info())),
                    "runs_completed_in_timed_region": loop.runs_completed, "run_lengths": loop.run_lengths,
                    "assign_path": "f32 screen certified by a rigorous bound + exact f64 confirmation (outputs "
                                   "bit-identical to the all-exact kernels)" if path == 1 else "exact f64 tiles",
@@ -719,6 +722,9 @@ def traced_run(loop, L, ctx, _lib, read_tlog, world, dist, torch, b_iter, b_acc,
          # for comparison across rounds only: round 1 timed iterations W+1 .. W+K of ONE run (its --warmup 5 --steps 20 window)
          "r01_window_iters_6_to_25_per_s": (20.0 / (float(ms[5:25].sum()) * 1e-3)) if its >= 25 else None,
          "per_iter_ms": [round(float(v), 2) for v in ms],
+         # (own order: the library keeps this shard's points in an order of its own -- data in arbitrary order is regrouped by
+         #  cluster inside the library once, spkm_shard_order_info; this run: whether that happened during THIS run)
+         "library_order": dict(zip(("own_order", "regrouped_in_this_run"), loop.shard.order_info())) if hasattr(loop, "shard") else None,
          "kernels_ms": {scr_name: [round(float(v), 2) for v in scr], "k_exact_accumulate": [round(float(v), 2) for v in acc]}}
     if scr.size:
         # one kernel per regime, one byte model each: the cold iteration is the assignment kernel over every step,

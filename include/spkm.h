@@ -152,7 +152,7 @@ void spkm_shard_destroy(spkm_shard *s);
 int spkm_shard_info(const spkm_shard *s, uint64_t *p, uint64_t *n, uint64_t *nnz, int *ir_bits);
 /* Data in arbitrary order.  A 16-point step of the screen is skipped on the carried bounds, or finished early by the hinted
  * form, only if all its 16 points allow it; with the points of a cluster scattered over the shard that is rare.  When a
- * fused call over all points of a LAZY shard (spkm_shard_set_lazy_stats) finds fewer than half of its steps holding one
+ * fused call over all points of a LAZY shard (spkm_shard_set_lazy_stats) finds fewer than one in eight of its steps holding one
  * cluster, the next call first REGROUPS the shard: the library's own order of the points -- the order of its screen copy,
  * bounds, hints and block summaries -- becomes "by cluster, the points that are sure of it first" (one gather of the
  * records, one write of the 306-B-per-point screen copy: once per spkm_shard_reset_policy at most).  Nothing the caller sees

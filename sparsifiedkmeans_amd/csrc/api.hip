@@ -10,7 +10,7 @@
 
 static spkm_switches read_switches()
 {
-    auto on = [](const char* name) { const char* v = getenv(name); return v != nullptr && *v != 0; };
+    auto on = [](const char* name) { const char* v = getenv(name); return v != nullptr && *v != 0 && !(v[0] == '0' && v[1] == 0); }; // (unset, empty or "0": off)
     spkm_switches w;
     w.no_screen = on("SPKM_NO_SCREEN");
     w.no_prune = on("SPKM_NO_PRUNE");

@@ -1002,8 +1002,8 @@ static int run_screen(spkm_ctx* ctx, const spkm_shard* s, int K, const double* d
                     return SPKM_ERR_BAD_VALUE;
                 }
             }
-            hipLaunchKernelGGL(k_bounds_steps, dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0,
-                               ctx->stream, sm->hb, npad, n, K, trusted ? (int*)nullptr : (int*)d_assign, (int*)ctx->todo.p,
+            hipLaunchKernelGGL(sm->map != nullptr ? k_bounds_steps<true> : k_bounds_steps<false>,
+                               dim3((unsigned)std::min<long long>((npad + span - 1) / span, bgrid)), dim3(256), 0, ctx->stream, sm->hb, npad, n, K, trusted ? (int*)nullptr : (int*)d_assign, (int*)ctx->todo.p,
                                (unsigned*)ctx->nlist.p, hinted ? sm->hintu : (float*)nullptr, skip_enabled ? 1 : 0,
                                pt_mode ? 1 : 0, (const double*)(sm->hb_cum + sm->cum_par), sm->hb_cum + (sm->cum_par ^ 1),
                                (int)span, (unsigned*)ctx->bstat.p, erode ? 1 : 0, sp_slack, sp_mask, sp_valid, sp_reset,
@@ -1482,12 +1482,15 @@ extern "C" int spkm_assign_accumulate_dev(spkm_ctx* ctx, const spkm_shard* s, ui
         c.listed = sm->h_nlist[0]; c.ambig = sm->h_nlist[1]; c.early = sm->h_nlist[2]; c.skipped = sm->h_nlist[3];
         c.kept = sm->h_nlist[12]; c.movers = sm->h_nlist[14];
         c.full_opened = sm->h_nlist[19] != 0u;
-        // data in arbitrary order: the call looked at every point in the library's order and fewer than half of its 16-point
-        // steps held one cluster -- the next call regroups the shard first (run_screen)
+        // data in arbitrary order: the call looked at every point in the library's order and fewer than one in eight of its
+        // 16-point steps held one cluster -- the next call regroups the shard first (run_screen).  (Cluster-contiguous data
+        // whose first cells cut across its clusters still has a third or more of its steps in one cell; regrouping it by
+        // those cells was measured: 37 ms spent, nothing gained in the cold iterations, and settled blocks that hold several
+        // clusters pass their summaries less often -- 0.53 against 0.32 ms per converged iteration at N = 1e8.)
         // (not while clusters overlap -- nine points in ten with a runner-up within 2.25x, what the policy calls crowded: their steps are mixed whatever the order,
         //  and stay on the screen whatever their neighbours do)
         if (sm->pend_full && sm->lazy && !sm->regroup_done && s->n >= 4096 &&
-            (double)sm->h_nlist[21] < 0.5 * (double)((s->n + 15) / 16) && (double)sm->h_nlist[1] < 0.9 * (double)s->n)
+            (double)sm->h_nlist[21] < 0.125 * (double)((s->n + 15) / 16) && (double)sm->h_nlist[1] < 0.9 * (double)s->n)
             sm->regroup_wanted = true;
         sm->pol.observe(c, (double)s->n, (int)((K64 + SCREEN_KT - 1) / SCREEN_KT), (s->fixed_s + 3) / 4);
     }

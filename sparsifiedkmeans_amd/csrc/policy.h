@@ -1,5 +1,5 @@
 // Which form the next fused call takes -- the host-side policy of the screen path, on its own so that it can be read,
-// and tested (tests/test_policy.py drives it through tables on the CPU), apart from the launch code in api.hip.
+// and tested (tests/test_policy.py drives it through tables on the CPU), apart from the launch code in api_lloyd.hip.
 //
 // Nothing here can change an output: every form computes the reference's assignment; the policy only chooses how much
 // work the next call does.  It sees the counters of a screen call ONE CALL LATE (copied back asynchronously: no host
@@ -128,7 +128,7 @@ struct spkm_policy {
         // -- judged by how the failing points lie, not by the list form: the steps left on the screen are at least an eighth
         // full of them (scattered failures, a few per cent of the points, leave a quarter of all steps)
         blocks_next = skip_pending && c.kept >= 0.9 * n && (std::ceil(n / 16.0) - c.skipped) * 16.0 <= 8.0 * (n - c.kept);
-        const int a_prune = quad_split(nr); // the early split (api.hip takes the point-list kernels' value where it applies): a runner-up 2.25x away clears it
+        const int a_prune = quad_split(nr); // the early split (api_lloyd.hip takes the point-list kernels' value where it applies): a runner-up 2.25x away clears it
         const int t = std::max(1, tiles);
         if (hint_pending) {
             // hinted call: worth it only if a fair share of the (step, tile) pairs was finished early, and only while the
@@ -206,7 +206,7 @@ struct spkm_policy {
     // Incremental sums (events) instead of a full accumulation pass: while not too many points move -- at most a third
     // in the previous counted call (an event pair reads the point twice, through a gather: 0.2 ms per million movers at
     // s = 51 against 10.4 ms for a full pass over 1e8 points); no count yet (a run's second call): taken as few.
-    // pair_events (api.hip: K <= 128): one event per mover, its record read once -- 12.9 ms per 1e8 movers, sort included,
+    // pair_events (api_lloyd.hip: K <= 128): one event per mover, its record read once -- 12.9 ms per 1e8 movers, sort included,
     // against 8.8 ms for the full pass with its own sort at N = 1e8: events pay up to two thirds of the points; taken up to half.
     bool few_movers(double n, bool pair_events = false) const
     {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
 //  * row ids are stored as row * 8 ^ ((row >> 1) & 3): shifted left by 4 that is the row's LDS offset (128-B
 //    rows) with the tile's piece swizzle in bits 4..5 (k_prep_tiles_f32, swz), so the kernel's address
 //    arithmetic stays one XOR per broadcast entry.  Needs 8 (p + 1) <= 65536 for 16-bit ids (LDS: p <= 1279).
-//  map != nullptr (a regrouped shard, api.hip): step-major slot i holds the point map[i] of the records.
+//  map != nullptr (a regrouped shard, api_lloyd.hip): step-major slot i holds the point map[i] of the records.
 template <typename IR>
 __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ ir, const double* __restrict__ x,
                                                         long long n, int fixed_s, int p, float* __restrict__ xfs,
@@ -627,6 +627,8 @@ __global__ __launch_bounds__(256) void k_center_drift(const double* __restrict__
 // passed, counters[12], and the steps whose 16 points all passed, counters[3]): >= 90 % of the points passed and the
 // steps left over hold several times as many points as failed (entered at 4x, left below 2.5x).  The screen then fetches 16 B per quad instead of
 // 256 B per wave, which only pays while few points are listed.
+template <bool MAPPED> // MAPPED: a regrouped shard (map != nullptr) -- a compile-time flag: with the choice made at run time the
+// compiler puts the caller-buffer load behind a branch, apart from the other loads of its group (44 -> 113 us per settled call)
 __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, long long npad, long long n, int K,
                                                       int* __restrict__ assign,
                                                       int* __restrict__ todo, unsigned* __restrict__ counters,
@@ -640,9 +642,9 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                                                       const int* __restrict__ map = nullptr)
 {
     // assign == nullptr: the caller's buffer is known to hold the library's copy already (lazy statistics, the same buffer as
-    // in the previous call: spkm.h) -- it is neither read nor restored.  map != nullptr (a regrouped shard, api.hip): point i of
+    // in the previous call: spkm.h) -- it is neither read nor restored.  map != nullptr (a regrouped shard, api_lloyd.hip): point i of
     // the library's order is the caller's point map[i].
-    // BLOCK SUMMARIES (sp_slack != nullptr; lazy calls with K <= 128 only, api.hip): per 1024 consecutive points
+    // BLOCK SUMMARIES (sp_slack != nullptr; lazy calls with K <= 128 only, api_lloyd.hip): per 1024 consecutive points
     //   sp_slack = min_i [ lb_i (1 - 1e-6) - ub_i (1 + 1e-6) ]   (lb as stored: relative to the accumulated drift `cum`)
     //   sp_mask  = the clusters its points belong to (K bits)
     //   sp_valid = every point passed the test of the call that wrote the summary
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
     // (Measured and dropped: letting a block whose clusters moved a little pass too, against a per-block lag that its
     //  points' upper bounds take later -- no block more was skipped in iterations 10-40 of the headline run, where nearly
     //  every cluster still exchanges a few points per call and the slack of a block's worst point is small.)
-    // erode != 0 (a call whose exact pass will not run: spkm_shard_set_lazy_stats, api.hip): a point that passes keeps
+    // erode != 0 (a call whose exact pass will not run: spkm_shard_set_lazy_stats, api_lloyd.hip): a point that passes keeps
     // its centroid but gets no fresh upper bound from anybody, so the bound is moved by its centroid's drift here,
     // ub <- ub + delta_a rounded up (Hamerly's update).  A store only where the centroid moved at all: the members of
     // settled clusters (delta_a = 0) are not written.
@@ -771,7 +773,8 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             apv[u] = in ? reinterpret_cast<const int*>(bnd)[2 * npad + i] : 0;
             // what the caller's buffer holds now, fetched with the rest (behind the test it would be a second memory
             // round trip per group): a point that keeps its assignment is stored only if the buffer differs
-            curv[u] = (in && skip_enabled && assign != nullptr) ? assign[map != nullptr ? map[i] : i] : apv[u];
+            if (MAPPED) curv[u] = (in && skip_enabled && assign != nullptr) ? assign[map[i]] : apv[u];
+            else curv[u] = (in && skip_enabled) ? assign[i] : 0;
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) dav[u] = bnd[3 * npad + apv[u]];
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
                 bm0 |= w == 0 ? bit : 0u; bm1 |= w == 1 ? bit : 0u; bm2 |= w == 2 ? bit : 0u; bm3 |= w == 3 ? bit : 0u;
             }
             if (pt_mode) {
-                if (keep && i < n && curv[u] != apv[u]) assign[map != nullptr ? map[i] : i] = apv[u]; // (see the step mode below)
+                if (keep && i < n && curv[u] != apv[u]) assign[MAPPED ? (long long)map[i] : i] = apv[u]; // (see the step mode below)
                 if (!keep && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
                 const unsigned long long lm = ~b; // (lanes past n count as kept)
                 if (lm) {
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(256) void k_bounds_steps(float* __restrict__ bnd, l
             const bool live_step = (i - (lane & 15)) < n; // the step has at least one point
             // a caller that passes the same buffer call after call already holds this value: a 4-B read instead of a
             // 4-B store (a gigabyte of stores costs as much as several of loads here)
-            if (skip && i < n && curv[u] != apv[u]) assign[map != nullptr ? map[i] : i] = apv[u];
+            if (skip && i < n && curv[u] != apv[u]) assign[MAPPED ? (long long)map[i] : i] = apv[u];
             if (!skip && i < n && hintu != nullptr) hintu[i] = sqrtf(ubv[u] * ubv[u] + bnd[3 * npad + HB_HTERM + apv[u]]);
             const bool lead = (lane & 15) == 0 && live_step && !skip;
             const unsigned long long lm = __ballot(lead);
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(256) void k_cluster_stats(const int* __restrict__ n
     }
     if (tid == 0) { stats[0] = s_o[0]; stats[1] = s_m[0]; stats[2] = (double)s_i[0]; }
 }
-// The accumulation form of a lazy call, chosen ON THE DEVICE (api.hip, `dual`): a call whose mover count the host cannot
+// The accumulation form of a lazy call, chosen ON THE DEVICE (api_lloyd.hip, `dual`): a call whose mover count the host cannot
 // know yet -- a run's second call; the counters come back one call late -- queues BOTH forms, the incremental one
 // (k_plan_segments / k_scatter_by_cluster / k_accumulate_events over the events) and the full sums-only pass
 // (k_cluster_need / plan / scatter / k_exact_accumulate_rec<DIST = false> / k_cluster_restore over all points), and this
@@ -984,7 +987,7 @@ __global__ void k_pick_form(unsigned* __restrict__ counters, unsigned ev_cap, in
     nitems[2] = 0; // (pair events: the first-level plan's chunk list)
 }
 
-// REGROUPING a shard whose 16-point steps mix clusters (data in arbitrary order; api.hip, regroup_shard): the library's own
+// REGROUPING a shard whose 16-point steps mix clusters (data in arbitrary order; api_lloyd.hip, regroup_shard): the library's own
 // order of the points -- the order of the screen copy and of everything it keeps per point -- becomes "by cluster, and inside
 // a cluster the points that are sure of it first", so that a step's 16 points share their centroid and their prospects: a
 // step is skipped on the carried bounds, or finished early by the hinted form, only if all 16 points allow it.  The records
@@ -1070,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
                                                         unsigned* __restrict__ wgstat, int* __restrict__ ev_o = nullptr,
                                                         const int* __restrict__ map = nullptr, int trusted = 0)
 {
-    // map != nullptr (a regrouped shard, api.hip): point i of the library's order is the caller's point map[i] -- what is
+    // map != nullptr (a regrouped shard, api_lloyd.hip): point i of the library's order is the caller's point map[i] -- what is
     // written to the caller's assignment buffer and into the events (the records are in the caller's order) goes through it;
     // trusted: the caller's buffer already holds the library's copy (lazy statistics, same buffer as last call), so only
     // CHANGES are stored -- through a map every store is a scattered 4-byte write.
@@ -1078,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     // shard whose steps are mixed (data in arbitrary order).
     // ev_o != nullptr: PAIR events -- ONE event per mover, (point, new cluster in ev_k, old cluster or -1 in ev_o), and the
     // histogram nk_ev over the K new clusters only: the events are then sorted by (new, old) pair and every mover's record
-    // is read once, into its new cluster's sums and out of its old one's (api.hip, k_accumulate_events<.., PAIR>); else
+    // is read once, into its new cluster's sums and out of its old one's (api_lloyd.hip, k_accumulate_events<.., PAIR>); else
     // two events per mover, (point, K + old) and (point, new), over 2 K keys, each applied on its own.
     // wgstat[3 b .. 3 b + 2]: workgroup b's ambiguous points, "some assignment changed" flag and movers, as plain stores;
     // k_assign_list (the next launch) adds them up into nlist[1], nlist[5], nlist[14].  One atomic per workgroup and counter
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_combine_screen(const float* __restrict_
     // them), so once the running count has passed the cap the stores (16 B per mover) would be wasted
     // nk_ev (with ev_pt): the histogram of the events over their 2 K keys, collected per workgroup next to the cluster-size
     // deltas -- the counting sort of the events then needs no histogram pass of its own
-    // lazy != 0 (the exact pass will not run in this call, api.hip): a certified point's upper bound is written here,
+    // lazy != 0 (the exact pass will not run in this call, api_lloyd.hip): a certified point's upper bound is written here,
     // (r1 + eps1) rounded up -- rigorous, if a few 1e-6 looser than the exact distance the pass would have stored -- and
     // every point that changes cluster is recorded as two EVENTS, (point, K + old cluster) and (point, new cluster), for
     // the incremental update of the per-cluster sums (k_accumulate_events).  Events are staged in LDS and appended with
@@ -1458,7 +1461,7 @@ __global__ __launch_bounds__(256) void k_build_records(const IR* __restrict__ ir
 }
 
 // The inverse of k_build_records: the CSC value / row-id arrays of a fixed-stride shard from its record layout (entry points
-// that read CSC after spkm_shard_release_csc re-materialise them first: api.hip, ensure_csc).
+// that read CSC after spkm_shard_release_csc re-materialise them first: api_lloyd.hip, ensure_csc).
 template <typename IR>
 __global__ __launch_bounds__(256) void k_unpack_records(const char* __restrict__ rec, long long n, int s, int R,
                                                         IR* __restrict__ ir, double* __restrict__ x)

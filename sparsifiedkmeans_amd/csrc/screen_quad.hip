@@ -76,7 +76,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
                                                  int todo_pts, const char* __restrict__ rec, int rec_R,
                                                  const int* __restrict__ recmap)
 {
-    // recmap != nullptr (a regrouped shard, api.hip): point q of this shard's order is record recmap[q]
+    // recmap != nullptr (a regrouped shard, api_lloyd.hip): point q of this shard's order is record recmap[q]
     // PTS (its own kernel instantiation): the list names POINTS; rec != nullptr: their entries are read from the record
     // layout of the exact pass (k_build_records: one point = R contiguous bytes, f64 values then row ids) instead of the
     // step-major f32 copy, where the entries of ONE point are 13 pieces of 16 + 8 B in 26 different cache lines
@@ -277,7 +277,7 @@ __device__ __forceinline__ void screen_quad_body(const IR* __restrict__ ir, cons
             if (A < NR && hint != nullptr) {
                 const float hv = hraw;
                 // (stale hints -- the first iterations of a run, a reused buffer -- send steps to the exact list; the host
-                // sees the count one call later and pauses the hints, api.hip)
+                // sees the count one call later and pauses the hints, api_lloyd.hip)
                 const bool fine = !(i < n) || m2 >= hint_c * hv * hv; // false for NaN
                 if (!__all(fine)) {
                     SPKM_QUAD_ROUNDS(SPKM_GUARD_B)

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_pair_scatter(const int* __restrict__ pt
     }
 }
 
-// FEW events (a settled run moves some hundred points per call; api.hip takes this form when the previous call counted
+// FEW events (a settled run moves some hundred points per call; api_lloyd.hip takes this form when the previous call counted
 // fewer than spkm_policy::direct_events_below movers): no counting sort, no slab -- a wave per event adds the point's
 // entries to (key < K) or takes them out of (key >= K) its cluster's rows of the table, one f64 atomic per entry and
 // table.  Three launches (plan, placement, k_accumulate_events: 27 us of latency for 200 events) become one of 6 us.
@@ -881,7 +881,7 @@ __global__ void k_call_tail(const unsigned long long* __restrict__ nk, int K, do
         *reinterpret_cast<unsigned long long*>(counters + 36) += work_steps * (unsigned long long)work_tiles * (unsigned long long)work_nr;
     }
     // host_out != nullptr: pinned host memory, device-mapped -- the call's first SPKM_REPORT_WORDS counters for the host policy go there, then
-    // the report's number `seq` with a system-scope release (api.hip reads them one call later, if the number is there)
+    // the report's number `seq` with a system-scope release (api_lloyd.hip reads them one call later, if the number is there)
     // cache_s != nullptr (incremental calls): the call's sums and counts ARE the cache.  One repair on the way: a row of a
     // cluster that no member stores any more (count 0) must have the sum EXACTLY 0 -- a fresh summation gives that, an
     // add-and-subtract history leaves a residual of rounding noise, and kmeans_sparsified.m:448 divides it by 1e-16.

@@ -244,7 +244,7 @@ def test_incremental_sums_while_at_most_a_third_of_the_points_move(pol):
 
 
 def test_a_call_without_a_mover_count_lets_the_device_choose_the_form(pol):
-    """Table for the accumulation form of a lazy call (api.hip `dual`, screen.hip k_pick_form): while no mover count has
+    """Table for the accumulation form of a lazy call (api_lloyd.hip `dual`, screen.hip k_pick_form): while no mover count has
     come back -- a run's second call, or any call whose predecessor's counters are still in flight -- both forms are
     queued and the device opens the events iff there are at most event_cap(n) of them (two per mover: a third of the
     points, the same bar few_movers applies to a known count); once a count is known the host decides alone."""

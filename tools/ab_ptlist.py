@@ -4,22 +4,8 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from sparsifiedkmeans_amd import _lib
-if os.environ.get("SPKM_AB_LIB"):
-    _lib._SO = os.environ["SPKM_AB_LIB"]
-    import ctypes as _C
-    _orig = _C.CDLL.__getattr__
-    def _tolerant(self, name):                      # an older build lacks newer symbols: give a stub that raises when called
-        try:
-            return _orig(self, name)
-        except AttributeError:
-            if name.startswith("spkm_"):
-                class _Stub:
-                    argtypes = None; restype = None
-                    def __call__(self, *a): raise RuntimeError(name + " is not in this build")
-                return _Stub()
-            raise
-    _C.CDLL.__getattr__ = _tolerant
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ab_lib  # noqa: F401
 from oracle import oracle as O
 from sparsifiedkmeans_amd import synth
 from sparsifiedkmeans_amd.engine import LloydEngine, Shard, torch_context

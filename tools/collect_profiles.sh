@@ -2,7 +2,7 @@
 # usage: tools/collect_profiles.sh r04 -- copies the measurement set of tools/gpu_final.sh from gpurun_out/ (scratch) into profiles/ (tracked) and rebuilds
 # profiles/pmc_latest.json from the PMC passes of tools/prof.sh (FETCH_SIZE x 2 + WRITE_SIZE: MI355X_MICROARCH.md's HBM recipe)
 cd "$(dirname "$0")/.."
-R=${1:-r04}
+R=${1:-r05}
 export R
 for f in headline headline_100steps headline_shuffled headline_eager_stats config5 config3 k10_n2e7 config2_n1e7 shard_1.25e7 shard_1.25e7_100steps shard_2.5e7 shard_5e7; do
   [ -f gpurun_out/${R}final/bench_$f.json ] && cp gpurun_out/${R}final/bench_$f.json profiles/${R}_bench_$f.json

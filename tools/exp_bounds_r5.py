@@ -143,4 +143,13 @@ for it in range(1, iters + 1):
                     row.append(f"{nm}/{hn} {torch.stack(fin, 1).float().mean().item():.3f}")
             out.append(" ".join(row))
         print("      early-finished (step, tile) pairs  " + "  |  ".join(out), flush=True)
+        # (3) what a partial sum is worth as a carried LOWER bound: sqrt(min over the other centroids) -- median / 1 % quantile over
+        # the points, and the median over 16-point steps of the step's smallest (a block summary keeps the minimum of 1024)
+        out = []
+        own = torch.zeros((m, K), dtype=torch.bool, device="cuda"); own[ar, a_true] = True
+        for A in ROUNDS:
+            for nm, P in (("storage", Pst[A]), ("sorted", Psr[A])):
+                lbp = torch.where(own, torch.full_like(P, float("inf")), P).min(1).values.sqrt()
+                out.append(f"A={A} {nm} {lbp.median().item():.1f}/{lbp.quantile(0.01).item():.1f}/{lbp.view(-1, 16).min(1).values.median().item():.1f}")
+        print(f"      partial sums as lower bounds (median / 1 pct / median of step minima; ub median {D[ar, a_true].median().item():.1f}): " + "  ".join(out), flush=True)
     D_prev, a_prev, prev_c = D, a_true, cur

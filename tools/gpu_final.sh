@@ -1,7 +1,7 @@
 #!/bin/bash
 # Measurement set of a round (usage: tools/gpu_final.sh r04): bench lines for the headline and the other configs, rocprofv3 kernel traces + PMC passes, the
 # shard timeline.  Everything lands under gpurun_out/<round>final (tools/collect_profiles.sh <round> copies the summaries to profiles/).
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/${R}final; mkdir -p $out
@@ -21,7 +21,7 @@ bash tools/prof.sh ${R}_headline --steps 20 --warmup 5 --cpu-sample 0 --no-regim
 PROF_TRACE_ONLY=1 bash tools/prof.sh ${R}_k10 --n-total 2e7 --clusters 10 --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_k10.log 2>&1
 PROF_TRACE_ONLY=1 bash tools/prof.sh ${R}_shuffled --order shuffled --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_shuffled.log 2>&1
 PROF_TRACE_ONLY=1 bash tools/prof.sh ${R}_config5 --workload config5 --steps 20 --warmup 5 --cpu-sample 0 --no-regimes > $out/prof_config5.log 2>&1
-for seed in 1 2 3; do timeout 900 python tools/stress_parity.py 300 $seed 2>&1 | tail -1 | sed "s/^/seed $seed: /"; done > $out/stress_parity.txt
+for seed in 21 22 23 24; do timeout 900 python tools/stress_parity.py 240 $seed 2>&1 | tail -1 | sed "s/^/seed $seed: /"; done > $out/stress_parity.txt
 ./tools/ubench_quad > $out/ubench_quad.txt 2>&1
 bash tools/timeline.sh ${R}_shard --n-total 1.25e7 --steps 30 --warmup 2 --cpu-sample 0 --no-regimes > /dev/null 2>&1
 TIMELINE_SHOW=60,90 bash tools/timeline.sh ${R}_shard100 --n-total 1.25e7 --steps 100 --warmup 2 --cpu-sample 0 --no-regimes > /dev/null 2>&1

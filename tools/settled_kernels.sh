@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
 raw=/tmp/sk_$tag; rm -rf $raw; mkdir -p $raw
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $raw -o t -- python $root/tools/settled_probe.py "$@" > $raw/probe.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $raw -o t -- python $root/tools/settled_probe.py "$@" > $raw/probe.log 2>&1
 f=$(find $raw -name "*kernel_trace.csv" | head -1)
 echo "== $tag"
 tail -4 $raw/probe.log

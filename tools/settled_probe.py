@@ -9,6 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ab_lib  # noqa: E402,F401  (SPKM_AB_LIB: another build of the library)
 from sparsifiedkmeans_amd import synth                                   # noqa: E402
 from sparsifiedkmeans_amd.engine import Context, LloydEngine, Shard, mix_device  # noqa: E402
 
@@ -32,8 +34,12 @@ print("iter   ms     form listed ambig early skipped16 sums ptmode | streamed")
 for it in range(iters):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    c_before = c.clone() if os.environ.get("SPKM_PROBE_CHANGED") else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     eng.iterate(c, want_mind=False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
+    changed = int((c_before != c).any(dim=0 if c.shape[0] != K else 1).sum().item()) if c_before is not None else -1
     m = eng.last_screen_mode()
-    print(f"{it:3d} {ms:8.3f}  {m[0]:2d} {m[1]:8d} {m[2]:8d} {m[3]:8d} {m[4]:9d} {m[6]:2d} {m[7]:2d} | {eng.exact_pass_points()[1]}")
+    print(f"{it:3d} {ms:8.3f} r{eng.last_screen_rounds()[0]:<2d} {m[0]:2d} {m[1]:8d} {m[2]:8d} {m[3]:8d} {m[4]:9d} {m[6]:2d} {m[7]:2d} | {eng.exact_pass_points()[1]}" + (f" changed centroids {changed}" if changed >= 0 else ""))
