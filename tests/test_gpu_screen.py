@@ -861,10 +861,10 @@ def test_carried_bounds_stay_bounds_through_every_kind_of_lazy_call(gpu_ctx, ora
     assert not shard.order_info()[0] or shuffled, shard.order_info()   # cluster-contiguous data is left as it lies
 
 
-@pytest.mark.parametrize("regroup", [True, False])
+@pytest.mark.parametrize("regroup", [True, False, "0"])
 def test_data_in_arbitrary_order_is_regrouped_inside_the_library_and_nothing_the_caller_sees_moves(gpu_ctx, oracle, monkeypatch, regroup):
     """A lazy run on shuffled data: after its first call the library regroups ITS order of the points by cluster
-    (spkm_shard_order_info; SPKM_NO_REGROUP=1: not).  Every iteration: assignments the oracle's bit for bit in the CALLER's
+    (spkm_shard_order_info; SPKM_NO_REGROUP=1: not; =0: as if unset).  Every iteration: assignments the oracle's bit for bit in the CALLER's
     order, centres the members' means; at the end the distances on demand and their statistics are the oracle's, a column
     read back is the caller's column, and a second run after reset_policy (a new start) is exact as well."""
     from sparsifiedkmeans_amd import synth
@@ -882,6 +882,10 @@ def test_data_in_arbitrary_order_is_regrouped_inside_the_library_and_nothing_the
     gam = s / p
     if not regroup:
         set_switch(monkeypatch, gpu_ctx, "SPKM_NO_REGROUP")
+    elif regroup == "0":   # a switch set to 0 is off, like one that is not set
+        monkeypatch.setenv("SPKM_NO_REGROUP", "0")
+        gpu_ctx.reload_switches()
+        regroup = True
     shard = Shard.from_scipy(gpu_ctx, Y)
     shard.set_lazy_stats(True)
     jc, ir, x = parts(Y)
