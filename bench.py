@@ -200,6 +200,8 @@ def main():
               "fused_mix_sample_columns_per_s": mcols / t_fused}
         del xd, irt, xt
 
+    READBACK = bool(os.environ.get("SPKM_BENCH_READBACK"))
+
     class Loop:
         """kmeans_sparsified's iteration loop on the engine: iterate, read dff (one small D2H per iteration, as the
         driver does), restart from the start centres when dff < Tol or MaxIter is reached."""
@@ -226,7 +228,12 @@ def main():
         def step(self):
             """one Lloyd iteration; returns (dff, obj, converged_or_capped)"""
             self.prev.copy_(self.centers)
-            out = self.eng.iterate(self.centers, want_mind=False).cpu().numpy()   # host sync: the driver needs dff to decide
+            # (the driver needs dff to decide whether to go on: spkm_lloyd_iter_host hands it over through pinned host memory
+            #  the device maps -- no copy kernel, no stream synchronisation; SPKM_BENCH_READBACK=1: iterate + a device-to-host read)
+            if READBACK:
+                out = self.eng.iterate(self.centers, want_mind=False).cpu().numpy()
+            else:
+                out = self.eng.iterate_host(self.centers, want_mind=False)
             self.it += 1
             if self.it == 1:
                 self.cold_calls.append(self.calls)

@@ -406,6 +406,17 @@ int spkm_allreduce_f64_dev(spkm_ctx *ctx, double *d_buf, uint64_t count);
 int spkm_lloyd_iter(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, double *d_centers, double gamma, int unbiased,
                     int32_t *d_assign, double *d_mind, double *d_stats, uint64_t *d_nk_u64, double *d_reduce,
                     double *d_out);
+/* The same iteration for a host that decides after every one of them, as the reference's driver does (kmeans_sparsified.m:
+ * 432 "ind = find(~counts)", 470-487 "dff = norm(...); if dff < Tol, break"): besides everything spkm_lloyd_iter does, the
+ * call WAITS until the iteration's results are in host memory and returns them in host_out[2 + K] =
+ * { ||old-new||_F^2, obj2, nk[0..K-1] } (cluster sizes as doubles; all global).  No device-to-host copy and no stream
+ * synchronisation is involved: the finalisation's last workgroup stores the values into pinned host memory that the device
+ * maps, followed by a sequence number, and the call returns when the number has arrived (a stream that runs dry without it --
+ * a platform without coherent host mappings -- is noticed after 0.25 s and the values are copied the ordinary way).
+ * d_out receives the same two values on the device, as with spkm_lloyd_iter. */
+int spkm_lloyd_iter_host(spkm_ctx *ctx, const spkm_shard *s, uint64_t K, double *d_centers, double gamma, int unbiased,
+                         int32_t *d_assign, double *d_mind, double *d_stats, uint64_t *d_nk_u64, double *d_reduce,
+                         double *d_out, double *host_out);
 /* Text of the last HIP / RCCL failure recorded on this context ("" if none). */
 const char *spkm_ctx_last_error(spkm_ctx *ctx);
 

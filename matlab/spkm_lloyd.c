@@ -325,6 +325,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     const int unbiased = nrhs >= 4 ? (mxGetScalar(prhs[3]) != 0.0) : 1;
     const int lazy = nrhs >= 5 ? (mxGetScalar(prhs[4]) != 0.0) : 0;
     const size_t pk = p * K;
+    int have_hres = 0;             /* the dense-centre call brought dff^2 / obj^2 / nk to the host itself */
+    double hres_out[2] = {0.0, 0.0};
     per_point_buffers(n);
     centre_buffers(p, K);
     check(spkm_shard_set_lazy_stats(g_shard, lazy));
@@ -356,8 +358,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
      * screen with exact f64 confirmation where the data qualifies (every column the same length, as
      * randsample_fixedNumberEntries produces), the exact kernels otherwise -- same outputs either way.  d_mind = NULL:
      * the n distances are not written per iteration ('distances' delivers them once) */
-    check(spkm_lloyd_iter(ctx, g_shard, K, g_dC, gamma, unbiased, g_dassign, NULL, NULL, NULL, g_dred, g_dout));
-    check(spkm_ctx_sync(ctx));
+    {   /* (spkm_lloyd_iter_host: dff^2, obj^2 and the cluster sizes are in host memory when the call returns -- through
+         *  pinned memory the device maps; no copies of them below) */
+        double *hres = (double *)mxMalloc((2 + K) * sizeof(double));
+        check(spkm_lloyd_iter_host(ctx, g_shard, K, g_dC, gamma, unbiased, g_dassign, NULL, NULL, NULL, g_dred, g_dout, hres));
+        have_hres = 1;
+        hres_out[0] = hres[0]; hres_out[1] = hres[1];
+        if (nlhs > 3) { plhs[3] = mxCreateDoubleMatrix(1, K, mxREAL); memcpy(mxGetPr(plhs[3]), hres + 2, K * sizeof(double)); }
+        mxFree(hres);
+    }
     if (g_s && !g_csc_released) {
         /* the first fused call has built the library's own layouts: the gateway's value / row arrays can go
          * (spkm_shard_release_csc; 'columns' keeps working: the library reads the records) */
@@ -369,8 +378,9 @@ outputs:
     plhs[0] = mxCreateDoubleMatrix(p, K, mxREAL);
     hipMemcpy(mxGetPr(plhs[0]), g_dC, pk * 8, hipMemcpyDeviceToHost);
     double out[2];
-    hipMemcpy(out, g_dout, 16, hipMemcpyDeviceToHost);
+    if (have_hres) { out[0] = hres_out[0]; out[1] = hres_out[1]; }
+    else hipMemcpy(out, g_dout, 16, hipMemcpyDeviceToHost);
     if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(sqrt(out[0]));   /* norm(centersOld-centers,'fro') */
     if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(sqrt(out[1]));   /* sqrt(sum(distances.^2)); NaN: not evaluated (lazy) */
-    if (nlhs > 3) { plhs[3] = mxCreateDoubleMatrix(1, K, mxREAL); hipMemcpy(mxGetPr(plhs[3]), g_dred + 2 * pk, K * 8, hipMemcpyDeviceToHost); }
+    if (nlhs > 3 && !have_hres) { plhs[3] = mxCreateDoubleMatrix(1, K, mxREAL); hipMemcpy(mxGetPr(plhs[3]), g_dred + 2 * pk, K * 8, hipMemcpyDeviceToHost); }
 }

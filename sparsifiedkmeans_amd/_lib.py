@@ -155,6 +155,7 @@ def lib():
     L.spkm_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.spkm_allreduce_f64_dev.argtypes = [_vp, _vp, _u64]
     L.spkm_lloyd_iter.argtypes = [_vp, _vp, _u64, _vp, _dbl, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.spkm_lloyd_iter_host.argtypes = [_vp, _vp, _u64, _vp, _dbl, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.spkm_ctx_last_error.argtypes = [_vp]
     L.spkm_ctx_last_error.restype = C.c_char_p
     _lib = L

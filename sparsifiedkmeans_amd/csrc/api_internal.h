@@ -60,6 +60,12 @@ struct spkm_ctx {
     // grow-only device scratch
     devbuf tiles, part_acc, part_k, blk_obj, blk_max, blk_imax, nk, stats, perm, offs, cursor, items, nitems,
         bmap, blk_dff, ct, tmp_assign, tmp_mind, mscr, dbg, t32, scr_m1, scr_m2, scr_k, cmax, list, nlist, dn_x, dn_c, dn_nk, bmapq, todo, bstat, nk_ev, fin_ticket, wgstat, offs2, cursor2, hist2, items2, perm_o;
+    // results of an iteration handed to the host without a copy or a stream synchronisation (spkm_lloyd_iter_host): pinned host
+    // memory the device maps -- [sequence number | dff^2 | obj^2 | cluster sizes], written by k_finalize_centers' last workgroup
+    double* h_res = nullptr;
+    double* h_res_dev = nullptr; // the same memory as the device addresses it
+    size_t h_res_len = 0;        // doubles
+    unsigned long long res_seq = 0ull;
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;
@@ -188,3 +194,7 @@ struct spkm_shard {
 hipError_t allow_lds(spkm_ctx* ctx, const void* kern, size_t bytes);
 int ensure(spkm_ctx* ctx, devbuf& b, size_t bytes);
 void release(devbuf& b);
+
+// (api_lloyd.hip) spkm_finalize_dev, optionally reporting [dff^2, obj^2, cluster sizes] into ctx->h_res under ctx->res_seq
+int spkm_finalize_impl(spkm_ctx* ctx, uint64_t p, uint64_t K, const double* d_reduce, double gamma, double* d_centers,
+                       double* d_out, bool to_host);

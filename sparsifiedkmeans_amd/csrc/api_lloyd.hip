@@ -1790,6 +1790,12 @@ static constexpr int FIN_BLOCKS = 256;
 extern "C" int spkm_finalize_dev(spkm_ctx* ctx, uint64_t p, uint64_t K, const double* d_reduce, double gamma,
                                  double* d_centers, double* d_out)
 {
+    return spkm_finalize_impl(ctx, p, K, d_reduce, gamma, d_centers, d_out, false);
+}
+
+int spkm_finalize_impl(spkm_ctx* ctx, uint64_t p, uint64_t K, const double* d_reduce, double gamma, double* d_centers,
+                       double* d_out, bool to_host)
+{
     if (!ctx || !d_reduce || !d_centers || !d_out) return SPKM_ERR_NULL_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t pk = (size_t)p * K;
@@ -1800,9 +1806,22 @@ extern "C" int spkm_finalize_dev(spkm_ctx* ctx, uint64_t p, uint64_t K, const do
         HIP_TRY(hipMemsetAsync(ctx->fin_ticket.p, 0, 64, ctx->stream)); // (the kernel's last workgroup resets it after every call)
     }
     const int fb = (int)std::min<size_t>(FIN_BLOCKS, (pk + 255) / 256);
+    if (to_host && ctx->h_res_len < 3 + K) { // (pinned host memory the device maps: grown to the largest K seen)
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+        ctx->h_res = nullptr;
+        ctx->h_res_len = 0;
+        const size_t len = 3 + std::max<size_t>(K, 125);
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_res, len * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ctx->h_res, 0, len * 8);
+        HIP_TRY(hipHostGetDevicePointer((void**)&ctx->h_res_dev, ctx->h_res, 0));
+        ctx->h_res_len = len;
+        ctx->res_seq = 0ull;
+    }
     hipLaunchKernelGGL(k_finalize_centers, dim3(fb), dim3(256), 0, ctx->stream, d_reduce, d_reduce + pk,
                        d_reduce + 2 * pk, (int)p, (int)K, gamma, d_centers, (double*)ctx->blk_dff.p,
-                       (unsigned*)ctx->fin_ticket.p, d_out, (const double*)(d_reduce + 2 * pk + K));
+                       (unsigned*)ctx->fin_ticket.p, d_out, (const double*)(d_reduce + 2 * pk + K),
+                       to_host ? ctx->h_res_dev : (double*)nullptr, to_host ? ++ctx->res_seq : 0ull);
     HIP_TRY(hipGetLastError());
     return SPKM_OK;
 }

@@ -803,8 +803,12 @@ __global__ __launch_bounds__(256) void k_finalize_centers(const double* __restri
                                                           const double* __restrict__ nk_f64, int p, int K,
                                                           double gamma, double* __restrict__ centers,
                                                           double* __restrict__ blk_dff2, unsigned* __restrict__ ticket,
-                                                          double* __restrict__ out, const double* __restrict__ obj2)
+                                                          double* __restrict__ out, const double* __restrict__ obj2,
+                                                          double* __restrict__ host_res = nullptr, unsigned long long seq = 0ull)
 {
+    // host_res != nullptr (spkm_lloyd_iter_host): pinned host memory, device-mapped -- [seq | dff^2 | obj^2 | nk[0..K-1]]; the
+    // results go there as well, then the call's sequence number (system-scope release): the host waits for the number and
+    // needs neither a copy nor a stream synchronisation to decide whether to iterate again (kmeans_sparsified.m:470-487).
     // blk_dff2[b] = this workgroup's partial sum of (old - new)^2.  The workgroup that finishes LAST (a ticket counter, reset
     // for the next call) adds the partials up in a fixed order -- lane l takes blocks l, l + 64, ...; then a shuffle tree --
     // and writes out = [dff^2, obj^2] (kmeans_sparsified.m:470-471 before sqrt): what used to be a launch of its own.
@@ -841,6 +845,16 @@ __global__ __launch_bounds__(256) void k_finalize_centers(const double* __restri
         out[0] = o;
         if (obj2) out[1] = *obj2;
         *ticket = 0u;
+    }
+    if (host_res != nullptr) { // (one wave: its stores are complete behind the fence, whichever lane made them)
+        for (int k = threadIdx.x; k < K; k += 64) host_res[3 + k] = nk_f64[k];
+        if (threadIdx.x == 0) {
+            host_res[1] = o;
+            host_res[2] = obj2 ? *obj2 : __longlong_as_double(0x7ff8000000000000LL);
+        }
+        __threadfence_system();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_res), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -239,6 +239,7 @@ class LloydEngine:
         self.nk = torch.zeros(self.K, dtype=torch.int64, device=dev)
         self.reduce = torch.zeros(int(_lib.lib().spkm_reduce_len(self.p, self.K)), dtype=torch.float64, device=dev)
         self.out = torch.zeros(2, dtype=torch.float64, device=dev)
+        self._host_res = None      # iterate_host's [dff^2, obj^2, nk] on the host
         self.group = group
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
 
@@ -363,6 +364,28 @@ class LloydEngine:
                                               _p(self.mind) if want_mind else None, _p(self.stats),
                                               _p(self.nk), _p(self.reduce), _p(self.out)), "spkm_lloyd_iter")
         return self.out
+
+    def iterate_host(self, centers: torch.Tensor, want_mind: bool = True) -> np.ndarray:
+        """One full Lloyd iteration in place on ``centers`` for a host that decides after each of them (the reference's
+        driver: kmeans_sparsified.m:432, 470-487): returns the host array [dff^2, obj^2, nk[0..K-1]] (global values) --
+        spkm_lloyd_iter_host: the results arrive through pinned host memory the device maps, no copy, no stream
+        synchronisation.  Falls back to iterate() + one device-to-host read when the exchange has to go through
+        torch.distributed (a process group without attach_rccl)."""
+        from .distributed import is_distributed
+
+        if is_distributed() and comm_size(self.ctx) == 0:
+            self.iterate(centers, want_mind)
+            pk = self.p * self.K
+            return torch.cat([self.out, self.reduce[2 * pk: 2 * pk + self.K]]).cpu().numpy()
+        assert centers.dtype == torch.float64 and centers.is_contiguous() and tuple(centers.shape) == (self.K, self.p)
+        if self._host_res is None or self._host_res.size != 2 + self.K:
+            self._host_res = np.zeros(2 + self.K, np.float64)
+        _lib.check(_lib.lib().spkm_lloyd_iter_host(self.ctx.handle, self.shard.handle, self.K, _p(centers), self.gamma,
+                                                   1 if self.unbiased else 0, _p(self.assign),
+                                                   _p(self.mind) if want_mind else None, _p(self.stats),
+                                                   _p(self.nk), _p(self.reduce), _p(self.out),
+                                                   self._host_res.ctypes.data), "spkm_lloyd_iter_host")
+        return self._host_res.copy()
 
     # -- helpers -------------------------------------------------------------------------
     def global_nk(self) -> torch.Tensor:

@@ -399,6 +399,7 @@ def kmeans_sparsified(X, K, **options):
         fused_iters = 0
         for its in range(1, int(o["MaxIter"]) + 1):
             # [assignments,distances] = findClusters(X,centers) (:420) and the per-cluster sums of :430-453
+            host_res = None
             if mask_t is not None:
                 eng.assign_sparse_step(centers, mask_t)                          # findClusterAssignments.m:63-75
                 eng.accumulate_step()
@@ -412,7 +413,9 @@ def kmeans_sparsified(X, K, **options):
                 if MLcorrection:
                     # assignment + accumulation + all-reduce + gamma*S./(Cnt+1e-16) + dff + obj: ONE library call
                     # (spkm_lloyd_iter; kmeans_sparsified.m:420-471)
-                    eng.iterate(centers, want_mind=False)
+                    # (the results this loop decides on -- dff^2, obj^2, cluster sizes -- arrive in host memory with the
+                    #  call: spkm_lloyd_iter_host)
+                    host_res = eng.iterate_host(centers, want_mind=False)
                 else:
                     eng.assign_accumulate_step(centers, want_mind=False)
                 fused_iters += 1
@@ -444,8 +447,11 @@ def kmeans_sparsified(X, K, **options):
                 mean_ = eng.reduce[:pk_].view(Kc, p2) / torch.clamp(nk_, min=1.0)[:, None]
                 centers.copy_(torch.where((nk_ > 0)[:, None], mean_, centers))
                 dff2_t = ((old - centers) ** 2).sum().reshape(1)
-            # ONE small device-to-host read per iteration: [dff^2 | obj^2 | cluster sizes]
-            host = torch.cat([dff2_t, eng.reduce[2 * pk_ + Kc: 2 * pk_ + Kc + 1], eng.reduce[2 * pk_: 2 * pk_ + Kc]]).cpu().numpy()
+            # ONE small device-to-host read per iteration: [dff^2 | obj^2 | cluster sizes] (none when the fused call brought them)
+            if host_res is not None:
+                host = host_res
+            else:
+                host = torch.cat([dff2_t, eng.reduce[2 * pk_ + Kc: 2 * pk_ + Kc + 1], eng.reduce[2 * pk_: 2 * pk_ + Kc]]).cpu().numpy()
             dff2, obj2, nk = float(host[0]), float(host[1]), host[2:]
             empty = np.flatnonzero(nk == 0)
             if empty.size and np.isnan(obj2) and mind_pending:

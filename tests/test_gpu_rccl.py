@@ -70,6 +70,36 @@ def test_lloyd_iter_without_a_communicator_equals_the_three_calls(gpu_ctx, oracl
         assert np.array_equal(a.assign.cpu().numpy(), ref["assign"])
 
 
+def test_lloyd_iter_host_hands_the_host_what_it_decides_on_without_a_copy(gpu_ctx, oracle):
+    """spkm_lloyd_iter_host = spkm_lloyd_iter + [dff^2, obj^2, cluster sizes] in host memory when the call returns (pinned
+    memory the device maps, a sequence number behind the values): the same numbers as the device outputs of the same
+    call, the oracle's assignments and objective, and a K that grows between calls (the mapped buffer is re-made)."""
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, s = 128, 9000, 8
+    X = random_csc(p, n, s, seed=3)
+    shard = Shard.from_scipy(gpu_ctx, X)
+    for K in (5, 200):        # (the buffer starts out with room for 125 cluster sizes)
+        C0 = np.random.default_rng(1).standard_normal((K, p))
+        eng = LloydEngine(shard, K, s / p)
+        c = torch.tensor(C0, device="cuda")
+        ref = oracle.lloyd(p, n, *parts(X), C0.T, s / p, maxiter=4, tol=0.0)
+        for it in range(4):
+            used = c.clone()
+            host = eng.iterate_host(c)
+            # (no synchronisation before looking at `host`: the call itself waited for the values)
+            assert host.shape == (2 + K,)
+            torch.cuda.synchronize()
+            out = eng.out.cpu().numpy()
+            pk = p * K
+            assert host[0] == out[0] and (host[1] == out[1] or (np.isnan(host[1]) and np.isnan(out[1])))
+            assert np.array_equal(host[2:], eng.reduce[2 * pk: 2 * pk + K].cpu().numpy())
+            assert np.array_equal(host[2:], np.bincount(eng.assign.cpu().numpy(), minlength=K).astype(np.float64))
+            assert host[0] == float(((used - c) ** 2).sum().item()) or abs(host[0] - float(((used - c) ** 2).sum().item())) <= 1e-12 * host[0]
+            assert abs(np.sqrt(host[1]) - ref["obj"][it]) <= 1e-9 * ref["obj"][it]
+        assert np.array_equal(eng.assign.cpu().numpy(), ref["assign"])
+
+
 def _check_two_ranks(tmp_path, oracle, env_extra, port, timeout=600):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
