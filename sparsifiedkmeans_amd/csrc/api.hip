@@ -318,6 +318,7 @@ extern "C" int spkm_shard_reset_policy(spkm_shard* s)
     s->nlist_pending = false; // counters of the last call before the reset say nothing about what comes next
     s->hb_valid = false;
     s->sp_clean = false;
+    s->assign_synced = false;
     s->regroup_wanted = false;
     s->regroup_done = false; // (the order a previous run left stays; a new run may ask once more)
     s->pend_full = false;
@@ -328,6 +329,7 @@ extern "C" int spkm_shard_set_lazy_stats(spkm_shard* s, int on)
 {
     if (!s) return SPKM_ERR_NULL_ARG;
     s->lazy = on != 0;
+    s->assign_synced = false;
     s->sp_clean = false; // (a host that (re)declares its contract starts with every block visited: its buffer may be a new one at an old address)
     return SPKM_OK;
 }

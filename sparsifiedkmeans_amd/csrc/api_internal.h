@@ -154,6 +154,8 @@ struct spkm_shard {
     long long sp_blocks = 0;
     bool sp_clean = false;            // the last call that wrote bounds maintained the summaries
     const void* sp_assign = nullptr;  // the caller's assignment buffer of that call (a skipped block's part of it is not touched)
+    bool assign_synced = false;       // every point of sp_assign holds the library's copy: the previous fused call on this buffer wrote or
+                                      // repaired all of it and nobody -- set_lazy_stats, reset_policy, another entry point -- has ended the claim since
     double* hb_cum = nullptr;  // [2]: drift accumulated since the lower bounds were stored (screen.hip, k_bounds_steps), by call parity
     int cum_par = 0;
     double* cl_cache = nullptr;

@@ -444,6 +444,7 @@ extern "C" int spkm_assign_dev(spkm_ctx* ctx, const spkm_shard* s, uint64_t K64,
     ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
     const_cast<spkm_shard*>(s)->sp_clean = false; // (this call writes d_assign: the block summaries' claim on that buffer ends)
+    const_cast<spkm_shard*>(s)->assign_synced = false;
     if (int rcc = ensure_csc(ctx, s)) return rcc;
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;
@@ -568,6 +569,7 @@ extern "C" int spkm_assign_sparse_centers_dev(spkm_ctx* ctx, const spkm_shard* s
     ctx->sort_owner = nullptr; // this call overwrites (some of) the buffers a kept counting sort lives in
     HIP_TRY(hipSetDevice(ctx->device));
     const_cast<spkm_shard*>(s)->sp_clean = false; // (this call writes d_assign: the block summaries' claim on that buffer ends)
+    const_cast<spkm_shard*>(s)->assign_synced = false;
     if (int rcc = ensure_csc(ctx, s)) return rcc;
     const int K = (int)K64, p = (int)s->p;
     const long long n = (long long)s->n;

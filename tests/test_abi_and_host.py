@@ -166,3 +166,41 @@ def test_staging_copy_is_exact_and_leaves_the_thread_count_alone(monkeypatch):
     out = torch.empty_like(small)
     engine._parallel_host_copy(out, small)
     assert np.array_equal(out.numpy(), small.numpy())
+
+
+def test_mex_gateways_type_check_against_the_c_abi():
+    """matlab/*.c (the five mex gateways with the reference's file names, and the engine gateway
+    spkm_lloyd.c) go through a compiler -- `gcc -fsyntax-only -Wall -Wextra -Werror` against include/spkm.h and a
+    DECLARATIONS-ONLY list of the documented mx*/mex* functions they call (tests/native/mex_decls.h: a compile check, never
+    linked, never seen by the oracle or by any build).  Every spkm_* call in the gateways is thereby checked for argument
+    count and types against the header the library is built from; the gateway entry point has the reference's signature
+    (SparseMatrixMinusCluster.c:44-45)."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = sorted(glob.glob(os.path.join(root, "matlab", "*.c")))
+    assert {os.path.basename(f) for f in srcs} >= {"SparseMatrixMinusCluster.c", "SparseMatrixInnerProduct.c", "SparseMatrixColumnNormSq.c",
+                                                   "hadamard.c", "hadamard_pthreads.c", "spkm_lloyd.c"}
+    inc = ["-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "matlab"), "-I" + os.path.join(root, "tests", "native", "mexcheck")]
+    hip_inc = "/opt/rocm/include"
+    for f in srcs:
+        text = open(f).read()
+        if "hip/hip_runtime_api.h" in text and not os.path.isdir(os.path.join(hip_inc, "hip")):
+            continue                                                     # (the engine gateway also needs the HIP runtime's header)
+        r = subprocess.run([gcc, "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", *inc, "-isystem", hip_inc, f],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, f"{os.path.basename(f)}:\n{r.stderr[:3000]}"
+        assert re.search(r"void\s+mexFunction\s*\(\s*int\s+nlhs\s*,\s*mxArray\s*\*\s*plhs\[\]\s*,\s*int\s+nrhs\s*,\s*const\s+mxArray\s*\*\s*prhs\[\]\s*\)", text), f
+        # every C-ABI name a gateway uses is one the header declares
+        from sparsifiedkmeans_amd import _lib
+        code = re.sub(r"/\*.*?\*/|//[^\n]*", " ", text, flags=re.S)         # (usage texts in comments name the MATLAB function)
+        code = re.sub(r'"(?:\\.|[^"\\])*"', '""', code)
+        used = set(re.findall(r"\b(spkm_[a-z0-9_]+)\s*\(", code)) - {"spkm_mex_ctx", "spkm_mex_atexit"}
+        local = set(re.findall(r"^static[^\n(]*\b(spkm_[a-z0-9_]+)\s*\(", text, re.M))
+        assert used - local <= set(_lib.declared_symbols()), sorted(used - local - set(_lib.declared_symbols()))

@@ -916,6 +916,58 @@ def test_data_in_arbitrary_order_is_regrouped_inside_the_library_and_nothing_the
     shard.set_lazy_stats(False)
 
 
+def test_a_new_buffer_at_an_old_address_is_written_in_full_on_a_regrouped_shard(gpu_ctx, oracle):
+    """on a regrouped shard the fused call trusts the caller's assignment buffer (stores only moves)
+    while the lazy contract's claim stands.  A host that re-declares the contract (spkm_shard_set_lazy_stats) or builds a
+    new engine may hand over a NEW buffer at the OLD address (torch's caching allocator): simulated here by scribbling
+    over the buffer before re-declaring.  The next call has to leave the oracle's assignment in EVERY place, not only
+    where a point moved."""
+    from sparsifiedkmeans_amd import synth
+    from sparsifiedkmeans_amd.engine import LloydEngine, Shard
+
+    p, n, K, gopt = 256, 24000, 20, 0.1
+    X, centres, labels = synth.gmm_dense(p, n, K, seed=78, noise=0.1)
+    X = X[:, np.random.default_rng(5).permutation(n)]
+    rng = np.random.default_rng(7)
+    d = np.sign(rng.standard_normal(p)); d[d == 0] = 1
+    s = synth.small_p_of(gopt, p)
+    Y = synth.sparsify_dense(oracle.mix(X, d, p), s, rng)
+    gam = s / p
+    shard = Shard.from_scipy(gpu_ctx, Y)
+    shard.reset_policy()
+    shard.set_lazy_stats(True)
+    jc, ir, x = parts(Y)
+    eng = LloydEngine(shard, K, gam)
+    C0 = oracle.mix(X[:, np.random.default_rng(12).choice(n, K, replace=False)], d, p)
+    c = torch.tensor(np.ascontiguousarray(C0.T), device="cuda")
+    for it in range(6):
+        used = c.cpu().numpy().T.copy()
+        eng.iterate(c, want_mind=False)
+        torch.cuda.synchronize()
+    assert shard.order_info()[0], "the shard was expected to be regrouped by now"
+    ra, _ = oracle.assign(p, n, jc, ir, x, used, gam)
+    assert np.array_equal(eng.assign.cpu().numpy(), ra)
+    for how in ("set_lazy_stats", "new engine"):
+        eng.assign.fill_(-7)                        # "a new buffer at the old address": nothing of the old contents survives
+        torch.cuda.synchronize()
+        if how == "set_lazy_stats":
+            shard.set_lazy_stats(True)
+        else:
+            ptr = eng.assign.data_ptr()
+            keep = eng.assign
+            eng = LloydEngine(shard, K, gam)         # (re-declares the contract for its own buffer)
+            eng.assign = keep                        # ... which here IS the old address
+            assert eng.assign.data_ptr() == ptr
+            shard.set_lazy_stats(True)
+        used = c.cpu().numpy().T.copy()
+        eng.iterate(c, want_mind=False)
+        torch.cuda.synchronize()
+        ra, _ = oracle.assign(p, n, jc, ir, x, used, gam)
+        got = eng.assign.cpu().numpy()
+        assert np.array_equal(got, ra), (how, int((got != ra).sum()))
+    shard.set_lazy_stats(False)
+
+
 @pytest.mark.parametrize("direct", [True, False])
 def test_few_movers_are_applied_one_by_one_and_give_the_members_sums(gpu_ctx, oracle, monkeypatch, direct):
     """An incremental call whose predecessor counted fewer than 2048 movers applies its events without sorting them

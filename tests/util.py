@@ -114,3 +114,37 @@ def set_switch(monkeypatch, ctx, name, on=True):
     else:
         os.environ.pop(name, None)
     ctx.reload_switches()
+
+
+def mnist_like_pixels(n=60000, K=10, seed=3):
+    """BASELINE.json config 3 by shape and value type (MNIST itself is not available offline): n x 784 uint8 "digit-like"
+    images -- per class a stroke prototype on the 28 x 28 grid (three thick random strokes), per image a random gain, a
+    +-1-pixel shift and pixel noise on the lit pixels; two thirds of the pixels are exactly 0, the classes overlap
+    (K-means finds ~0.7 of the planted labels).  Returns (X uint8 [n, 784], labels [n])."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:28, 0:28]
+    protos = np.zeros((K, 28, 28))
+    for k in range(K):
+        img = np.zeros((28, 28))
+        for _ in range(3):
+            a, b = rng.uniform(6, 22, 2), rng.uniform(6, 22, 2)
+            for t in np.linspace(0, 1, 40):
+                c = a + t * (b - a)
+                img = np.maximum(img, np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2) / (2 * 1.3 ** 2)))
+        protos[k] = img
+    labels = rng.integers(0, K, n)
+    X = np.empty((n, 784), np.uint8)
+    for c0 in range(0, n, 10000):
+        lab = labels[c0:c0 + 10000]
+        m = lab.size
+        im = protos[lab]
+        dy, dx = rng.integers(-1, 2, m), rng.integers(-1, 2, m)
+        for sh in range(-1, 2):
+            for sw in range(-1, 2):
+                sel = (dy == sh) & (dx == sw)
+                if sel.any():
+                    im[sel] = np.roll(np.roll(im[sel], sh, axis=1), sw, axis=2)
+        gain = rng.uniform(0.6, 1.0, (m, 1, 1))
+        px = 255.0 * gain * im + 12.0 * rng.standard_normal((m, 28, 28)) * (im > 0.05)
+        X[c0:c0 + m] = np.clip(np.round(px), 0, 255).astype(np.uint8).reshape(m, 784)
+    return X, labels
