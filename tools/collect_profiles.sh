@@ -6,6 +6,8 @@ R=${1:-r05}
 export R
 for f in headline headline_100steps headline_shuffled headline_eager_stats config5 config3 k10_n2e7 config2_n1e7 shard_1.25e7 shard_1.25e7_100steps shard_2.5e7 shard_5e7; do
   [ -f gpurun_out/${R}final/bench_$f.json ] && cp gpurun_out/${R}final/bench_$f.json profiles/${R}_bench_$f.json
+  # (round 6: stdout carries the compact line only; the full result object is the detail file beside it)
+  [ -f gpurun_out/${R}final/bench_${f}_detail.json ] && cp gpurun_out/${R}final/bench_${f}_detail.json profiles/${R}_bench_${f}_detail.json
 done
 cp gpurun_out/prof_${R}_headline/kernel_stats.csv profiles/${R}_headline_kernel_stats.csv
 cp gpurun_out/prof_${R}_headline/pmc_summary.txt profiles/${R}_headline_pmc_summary.txt
