@@ -117,6 +117,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if os.environ.get("SPKM_AB_LIB"):   # developer aid: another build of libspkm.so (A/B on one box; tools/ab_lib.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ab_lib  # noqa: F401
     from sparsifiedkmeans_amd import _lib, synth
     from sparsifiedkmeans_amd.engine import LloydEngine, Shard, mix_device, mix_sample_device, torch_context
 
@@ -603,7 +606,8 @@ def headline_line(result):
                                        "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["value_incl_run_tail"] = result.get("value_incl_run_tail")
     line["config"] = {k: cfg.get(k) for k in ("workload", "n_total", "n_per_gpu", "p2", "K", "nnz_per_point", "start", "order", "tol",
-                                              "maxiter", "parallelism", "hbm_resident_GB", "runs_completed_in_timed_region")
+                                              "maxiter", "parallelism", "allreduce", "final_obj", "hbm_resident_GB",
+                                              "runs_completed_in_timed_region")
                       if k in cfg}
     if cfg.get("exchange"):
         line["config"]["exchange"] = cfg["exchange"]

@@ -141,6 +141,22 @@ __global__ __launch_bounds__(256) void k_point_norms(const long long* __restrict
     }
 }
 
+// maximum over the 16 lanes of a DPP row, in every lane (v_max_i32_dpp: the compiler's update_dpp + max takes three
+// instructions per stage)
+__device__ __forceinline__ int row_max16_i32(int v)
+{
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
 // The screen's own copy of a fixed-stride shard, laid out the way the 4-lanes-per-point kernel consumes it.
 //  * values as f32;
 //  * per point, the entries ordered BY |x| DESCENDING in three segments -- the first 4 A1, the next 4 (A2 - A1), the rest;
@@ -171,97 +187,123 @@ __global__ __launch_bounds__(256) void k_screen_reorder(const IR* __restrict__ i
 {
     // rec != nullptr: the entries are read from the record layout (a shard that never had CSC arrays, or has let them go)
     // one step per workgroup pass: 16 lanes per point, up to 4 passes of 16 entries (fixed_s <= 64) held in
-    // registers; the ordered columns are staged in LDS, then written out in lane order
+    // registers; the ordered columns are staged in LDS, then written out in lane order.
+    // Round 6: straight-line code per step (the round-5 version ran ~1300 instructions per wave and step through 179 basic
+    // blocks -- 12 group maxima of 23 instructions, 24 ballot-ranked placements behind a branch each -- and was VALU bound
+    // at 2.7 TB/s).  Now: (1) each lane sorts its 4 keys, the e2 largest of the point come off the sorted heads (a 16-lane
+    // DPP maximum + 4 conditional moves per extraction) and leave two THRESHOLDS -- keys are unique, so "key >= T" is the
+    // segment test; (2) the six (segment, row-parity class) buckets are counted in one packed word per lane, ranked by ONE
+    // 16-lane DPP prefix scan, the bucket bases come from the group total (ds_swizzle broadcast of lane 15).  Order inside
+    // a bucket: by lane, then by pass (the round-5 order was by entry index; the order inside a class is free).
     __shared__ float s_x[16][64];
     __shared__ IR s_r[16][64];
     const int sub = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
-    const int lane = threadIdx.x & 63;
-    const int gsh = lane & 48; // first lane of this 16-lane group
     const int NR = (fixed_s + 3) >> 2;
     const int e1 = 4 * quad_split(NR), e2 = 4 * (quad_split_late(NR) > quad_split(NR) ? quad_split_late(NR) : quad_split(NR));
     const long long nsteps = (n + 15) >> 4;
-    const unsigned below = (1u << sub) - 1u;
     for (long long st = blockIdx.x; st < nsteps; st += gridDim.x) {
         const long long i = st * 16 + grp;
         const bool live = i < n;
         const long long src = live ? (map != nullptr ? (long long)map[i] : i) : 0;
         const long long j0 = src * fixed_s;
         const unsigned want = (unsigned)(i & 1);
-        double xv[4];
-        IR rv[4];
-        int key[4], seg[4];
+        float xf[4];
+        unsigned rv[4];
+        int key[4];
         double nb = 0.0;
+        // (unconditional loads: a slot past the column, or a point past the end, re-reads entry 0 of a valid point)
+        const char* rb = rec != nullptr ? rec + (size_t)src * (size_t)rec_R : nullptr;
+        const double* xp = rec != nullptr ? reinterpret_cast<const double*>(rb) : x + j0;
+        const IR* rp = rec != nullptr ? reinterpret_cast<const IR*>(rb + (size_t)fixed_s * 8) : ir + j0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = u * 16 + sub;
             const bool ok = live && e < fixed_s;
-            if (rec != nullptr) {
-                const char* rb = rec + (size_t)src * (size_t)rec_R;
-                xv[u] = ok ? reinterpret_cast<const double*>(rb)[e] : 0.0;
-                rv[u] = ok ? reinterpret_cast<const IR*>(rb + (size_t)fixed_s * 8)[e] : (IR)0;
-            } else {
-                xv[u] = ok ? x[j0 + e] : 0.0;
-                rv[u] = ok ? ir[j0 + e] : (IR)0;
-            }
-            nb += xv[u] * xv[u];
+            const int ec = e < fixed_s ? e : 0;
+            const double xl = xp[ec];
+            const unsigned rl = (unsigned)rp[ec];
+            const double xv = ok ? xl : 0.0;
+            rv[u] = ok ? rl : (unsigned)p;          // no entry: x = 0 on the all-zero row p
+            nb += xv * xv;
+            xf[u] = (float)xv;
             // |x| as f32 bits (monotone for non-negative floats, NaN above everything) with the low 6 bits replaced by the
             // entry's index: unique per entry, a total order whatever the data (the 2^-17 it moves a value by decides nothing
             // but the order of near-equal entries); -1: no entry
-            key[u] = ok ? (((__builtin_bit_cast(int, (float)xv[u]) & 0x7fffffff) & ~63) | (63 - e)) : -1;
-            seg[u] = 2;
+            key[u] = ok ? (((__builtin_bit_cast(int, xf[u]) & 0x7fffffff) & ~63) | (63 - e)) : -1;
         }
-        // the e2 largest |x| of the point, one per pass: the group's maximum (keys are unique), its owner takes rank t
-        // (e2 <= 16 passes of ~25 instructions; a full ranking -- 64 x 64 comparisons per point -- made this kernel 4x slower)
-        for (int t = 0; t < e2; t++) {
-            int m = max(max(key[0], key[1]), max(key[2], key[3]));
-            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xf, 0xf, false));  // quad_perm:[1,0,3,2]
-            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xf, 0xf, false));  // quad_perm:[2,3,0,1]
-            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x141, 0xf, 0xf, false)); // row_half_mirror
-            m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x140, 0xf, 0xf, false)); // row_mirror
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (key[u] == m && m >= 0) { seg[u] = t < e1 ? 0 : 1; key[u] = -1; }
-        }
-        // place: by segment, inside a segment by row parity class (first class = the point's own parity), inside a class in
-        // index order -- counted with ballots over the 16 lanes of the point
-        int base = 0;
-#pragma unroll
-        for (int sg = 0; sg < 3; sg++) {
-#pragma unroll
-            for (int cl = 0; cl < 2; cl++) {
-                int cnt = 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int e = u * 16 + sub;
-                    const bool ok = live && e < fixed_s;
-                    const bool in = ok && seg[u] == sg && ((((unsigned)rv[u] & 1u) == want) ? 0 : 1) == cl;
-                    const unsigned mk = (unsigned)((__ballot(in) >> gsh) & 0xffffull);
-                    if (in) {
-                        const int pos = base + cnt + __builtin_popcount(mk & below);
-                        s_x[grp][pos] = (float)xv[u];
-                        const unsigned row = (unsigned)rv[u];
-                        s_r[grp][pos] = (IR)((row << 3) ^ ((row >> 1) & 3u)); // LDS row offset / 16 with the tile swizzle folded in
-                    }
-                    cnt += __builtin_popcount(mk);
-                }
-                base += cnt;
-            }
-        }
-        // slots past the column / past the last point: x = 0 on the all-zero row p
+        // (1) thresholds: T1 = the e1-th largest key of the point, T2 = the e2-th largest (-1 when the point has fewer entries)
+        int a0 = max(key[0], key[1]), a1 = min(key[0], key[1]), a2 = max(key[2], key[3]), a3 = min(key[2], key[3]);
+        { const int h = max(a0, a2), l = min(a0, a2); a0 = h; a2 = l; }
+        { const int h = max(a1, a3), l = min(a1, a3); a1 = h; a3 = l; }
+        { const int h = max(a1, a2), l = min(a1, a2); a1 = h; a2 = l; }
+        int T1 = -1, T2 = -1;
+        auto extract = [&]() {               // the largest key still at a head of the point's 16 lanes; its lane moves up
+            const int m = row_max16_i32(a0);
+            const bool own = a0 == m;        // (m = -1: the point has run out of entries -- every head is -1 and stays so)
+            a0 = own ? a1 : a0;
+            a1 = own ? a2 : a1;
+            a2 = own ? a3 : a2;
+            a3 = own ? -1 : a3;
+            return m;
+        };
+        for (int t = 0; t < e1; t++) T1 = extract();
+        T2 = T1;
+        for (int t = e1; t < e2; t++) T2 = extract();
+        if (e1 == 0) T1 = 0x7fffffff;        // (no early split compiled for this round count: nothing is in segment 0)
+        if (e2 == 0) T2 = 0x7fffffff;
+        // (2) buckets b = 2 * segment + class (class 0 = the point's own row parity) for the entries, b = 6 for the empty
+        // slots (they follow the entries: x = 0 on row p), counted per lane in packed 8-bit fields: buckets 0..3 in word A,
+        // 4..6 in word B.  Every one of the point's 64 slots is written exactly once.
+        int shv[4];
+        unsigned cA = 0u, cB = 0u;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int e = u * 16 + sub;
-            if (e >= base) { s_x[grp][e] = 0.f; s_r[grp][e] = (IR)(((unsigned)p << 3) ^ (((unsigned)p >> 1) & 3u)); }
+            const int sg = (key[u] < T1 ? 1 : 0) + (key[u] < T2 ? 1 : 0);
+            const int b = key[u] >= 0 ? 2 * sg + (int)((rv[u] ^ want) & 1u) : 6;
+            shv[u] = 8 * b;
+            cA += b < 4 ? 1u << (shv[u] & 31) : 0u;
+            cB += b < 4 ? 0u : 1u << (shv[u] & 31);
+        }
+        unsigned iA = cA, iB = cB; // inclusive prefix over the point's 16 lanes (fields cannot overflow: 64 slots in all)
+        iA += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iA, 0x111, 0xf, 0xf, true); // row_shr:1
+        iB += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iB, 0x111, 0xf, 0xf, true);
+        iA += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iA, 0x112, 0xf, 0xf, true); // row_shr:2
+        iB += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iB, 0x112, 0xf, 0xf, true);
+        iA += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iA, 0x114, 0xf, 0xf, true); // row_shr:4
+        iB += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iB, 0x114, 0xf, 0xf, true);
+        iA += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iA, 0x118, 0xf, 0xf, true); // row_shr:8
+        iB += (unsigned)__builtin_amdgcn_update_dpp(0, (int)iB, 0x118, 0xf, 0xf, true);
+        const unsigned tA = (unsigned)__builtin_amdgcn_ds_swizzle((int)iA, 0x1F0); // lane 15 of the 16-lane row: the point's totals
+        const unsigned tB = (unsigned)__builtin_amdgcn_ds_swizzle((int)iB, 0x1F0);
+        // bucket bases (exclusive prefix over the buckets) packed the same way, + the lanes below = where this lane's first
+        // slot of each bucket goes
+        const unsigned n0 = tA & 0xffu, n1 = (tA >> 8) & 0xffu, n2 = (tA >> 16) & 0xffu, n3 = tA >> 24, n4 = tB & 0xffu, n5 = (tB >> 8) & 0xffu;
+        const unsigned s1 = n0, s2 = s1 + n1, s3 = s2 + n2, s4 = s3 + n3, s5 = s4 + n4, s6 = s5 + n5;
+        unsigned pA = (iA - cA) + ((s1 << 8) | (s2 << 16) | (s3 << 24));
+        unsigned pB = (iB - cB) + (s4 | (s5 << 8) | (s6 << 16));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool inA = shv[u] < 32;
+            const int sh = shv[u] & 31;
+            const int pos = (int)(((inA ? pA : pB) >> sh) & 63u);
+            pA += inA ? 1u << sh : 0u;
+            pB += inA ? 0u : 1u << sh;
+            s_x[grp][pos] = xf[u];
+            s_r[grp][pos] = (IR)((rv[u] << 3) ^ ((rv[u] >> 1) & 3u)); // LDS row offset / 16 with the tile swizzle folded in
         }
         __syncthreads();
         float* xo = xfs + (size_t)st * NR * 64;
         IR* ro = irs + (size_t)st * NR * 64;
-        for (int idx = threadIdx.x; idx < NR * 64; idx += 256) {
-            const int r = idx >> 6, L = idx & 63;
-            const int e = 4 * r + (L & 3);
-            xo[idx] = s_x[L >> 2][e];
-            ro[idx] = s_r[L >> 2][e];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { // NR <= 16: at most 1024 elements per step
+            const int idx = (int)threadIdx.x + 256 * k;
+            if (idx < NR * 64) {
+                const int r = idx >> 6, L = idx & 63;
+                const int e = 4 * r + (L & 3);
+                xo[idx] = s_x[L >> 2][e];
+                ro[idx] = s_r[L >> 2][e];
+            }
         }
         __syncthreads();
         // the certificate's per-point norm (root of sum x^2, rounded up; any order) rides on the same pass over x
