@@ -345,7 +345,8 @@ int spkm_mix_sample_rec_dev(spkm_ctx *ctx, uint64_t p, uint64_t p2, uint64_t n, 
  * an entry point that needs CSC arrays re-materialises library-owned ones from the records first.
  * The allocation behind d_rec must extend at least 256 BYTES past the last record (n * spkm_record_bytes(s, ir_bits) + 256):
  * the record kernels read whole 16-byte pieces and fetch a wave's batch ahead of its bounds check (the library gives its
- * own record buffers the same slack).  1 <= s <= 64. */
+ * own record buffers the same slack) -- checked against the allocation d_rec lies in (hipMemGetAddressRange):
+ * SPKM_ERR_BAD_VALUE when it ends earlier.  1 <= s <= 64. */
 int spkm_shard_create_rec_dev(spkm_ctx *ctx, uint64_t p, uint64_t n, uint64_t s, int ir_bits, const void *d_rec,
                               spkm_shard **out);
 

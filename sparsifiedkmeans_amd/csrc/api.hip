@@ -8,6 +8,8 @@
 
 #include "api_internal.h"
 #include <chrono>
+#include <sched.h>
+#include <time.h>
 
 static spkm_switches read_switches()
 {
@@ -32,6 +34,8 @@ static spkm_switches read_switches()
     w.force_pair_events = on("SPKM_FORCE_PAIR_EVENTS");
     w.check_assign = on("SPKM_CHECK_ASSIGN");
     w.no_regroup = on("SPKM_NO_REGROUP");
+    if (const char* v = getenv("SPKM_X_HINT_CHUNK")) w.x_hint_chunk = atoi(v);   // points per chunk in the two-phase screen launches (default 256)
+    if (const char* v = getenv("SPKM_X_PLAIN_CHUNK")) w.x_plain_chunk = atoi(v); // ... in the plain launch (default: n / (8 x teams), at most 4096)
     return w;
 }
 
@@ -606,21 +610,43 @@ extern "C" int spkm_lloyd_iter_host(spkm_ctx* ctx, const spkm_shard* s, uint64_t
     if ((rc = spkm_finalize_impl(ctx, s->p, K, d_reduce, gamma, d_centers, d_out, true))) return rc;
     const unsigned long long want = ctx->res_seq;
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(ctx->h_res);
+    auto by_copy = [&]() -> int { // the ordinary way: two small copies behind the stream
+        HIP_TRY(hipMemcpyAsync(host_out, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(host_out + 2, d_reduce + 2 * (size_t)s->p * K, (size_t)K * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return SPKM_OK;
+    };
+    if (ctx->res_map_failed) return by_copy(); // (a platform whose host mapping did not deliver once is not asked again)
     auto t0 = std::chrono::steady_clock::now();
+    const auto t_start = t0;
     bool drained = false;
     for (unsigned polls = 1;; polls++) {
         if (__atomic_load_n(q, __ATOMIC_ACQUIRE) == want) break;
-        __builtin_ia32_pause();
-        if ((polls & 0xfffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(250)) {
+        // spin for the first ~50 us (a settled iteration is 0.15 ms of kernels: the answer is usually this close), then let
+        // other threads have the core, then sleep in 20-us naps: a cold iteration of a large shard is tens of milliseconds
+        if (polls < 2048u) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#elif defined(__aarch64__)
+            asm volatile("yield");
+#endif
+            continue;
+        }
+        const auto waited = std::chrono::steady_clock::now() - t_start;
+        if (waited < std::chrono::microseconds(500)) sched_yield();
+        else {
+            const struct timespec nap = {0, 20000};
+            nanosleep(&nap, nullptr);
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(250)) {
             // a quarter of a second without the number: make sure the stream is still alive (a failed launch would never
-            // report), and if it has run dry with the number still missing take the results the ordinary way
+            // report), and if it has run dry with the number still missing take the results the ordinary way -- from now on
             const hipError_t e = hipStreamQuery(ctx->stream);
             if (e == hipSuccess) {
                 if (drained) {
                     if (__atomic_load_n(q, __ATOMIC_ACQUIRE) == want) break;
-                    HIP_TRY(hipMemcpy(host_out, d_out, 16, hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemcpy(host_out + 2, d_reduce + 2 * (size_t)s->p * K, (size_t)K * 8, hipMemcpyDeviceToHost));
-                    return SPKM_OK;
+                    ctx->res_map_failed = true;
+                    return by_copy();
                 }
                 drained = true;
             } else if (e != hipErrorNotReady) {

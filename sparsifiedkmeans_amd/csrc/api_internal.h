@@ -37,6 +37,8 @@ struct spkm_switches {
     bool no_rec = false;          // SPKM_NO_REC: no record layout (the exact pass reads the two separate arrays)
     bool no_point_list = false;   // SPKM_NO_POINT_LIST: the carried bounds always settle whole 16-point steps
     bool no_cluster_skip = false; // SPKM_NO_CLUSTER_SKIP: every cluster is planned, placed and streamed in every call
+    int x_hint_chunk = 0;         // SPKM_X_HINT_CHUNK: chunk size of the two-phase screen launches (0: the default, 256 points)
+    int x_plain_chunk = 0;        // SPKM_X_PLAIN_CHUNK: ... of the plain launch (0: the default)
     bool no_late_split = false;   // SPKM_NO_LATE_SPLIT: the hinted screen always asks after a quarter of the rounds
     bool no_incremental = false;  // SPKM_NO_INCREMENTAL: per-cluster sums are always re-accumulated over every member
     bool no_support_drift = false; // SPKM_NO_SUPPORT_DRIFT: centroid drift by its full 2-norm, not its s largest entries
@@ -66,6 +68,7 @@ struct spkm_ctx {
     double* h_res_dev = nullptr; // the same memory as the device addresses it
     size_t h_res_len = 0;        // doubles
     unsigned long long res_seq = 0ull;
+    bool res_map_failed = false;      // spkm_lloyd_iter_host: the mapped host memory did not deliver once -- results by copy from then on
     // cached launch geometry of the tiled kernel
     int bmap_G = -1, bmap_blocks = 0, bmap_streams = 0;
     int bmapq_key = -1, bmapq_blocks = 0;

@@ -31,6 +31,22 @@ extern "C" int spkm_shard_create_rec_dev(spkm_ctx* ctx, uint64_t p, uint64_t n, 
     if (ir_bits != 16 && ir_bits != 32) return SPKM_ERR_BAD_VALUE;
     if ((ir_bits == 16 && p > 65536) || s_entries == 0 || s_entries > 64 || s_entries > p) return SPKM_ERR_BAD_VALUE;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (n) {
+        // the 256 bytes of slack behind the last record (spkm.h) are checked against the allocation the pointer lies in: no
+        // size crosses this boundary, but the runtime knows it.  (A pointer it does not know -- another runtime's -- is let through.)
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)const_cast<void*>(d_rec)) == hipSuccess && base != nullptr) {
+            const size_t off = (size_t)((const char*)d_rec - (const char*)base);
+            const size_t need = (size_t)n * (size_t)spkm_record_bytes(s_entries, ir_bits) + 256;
+            if (off > size || size - off < need) {
+                snprintf(ctx->errmsg, sizeof(ctx->errmsg), "spkm_shard_create_rec_dev: the allocation ends %zu bytes after d_rec, n records + 256 bytes "
+                         "of slack need %zu (spkm.h)", off > size ? (size_t)0 : size - off, need);
+                return SPKM_ERR_BAD_VALUE;
+            }
+        } else
+            (void)hipGetLastError();
+    }
     spkm_shard* s = new spkm_shard();
     s->ctx = ctx; s->p = p; s->n = n; s->nnz = n * s_entries; s->ir_bits = ir_bits;
     s->fixed_s = (int)s_entries;
@@ -135,21 +151,33 @@ static int regroup_shard(spkm_ctx* ctx, spkm_shard* sm, int K)
 {
     const long long n = (long long)sm->n, npad = sm->hb_npad;
     const int K2 = 2 * K;
-    int *keys = nullptr, *perm = nullptr, *newmap = nullptr;
-    float* hb_new = nullptr;
-    auto fail = [&](hipError_t e) {
+    // (scratch and the new arrays belong to this guard until the very end: every early return -- ensure(), HIP_TRY -- frees them)
+    struct Owned {
+        int *keys = nullptr, *perm = nullptr, *newmap = nullptr;
+        float* hb_new = nullptr;
+        ~Owned()
+        {
+            if (keys) (void)hipFree(keys);
+            if (perm) (void)hipFree(perm);
+            if (newmap) (void)hipFree(newmap);
+            if (hb_new) (void)hipFree(hb_new);
+        }
+    } own;
+    int*& keys = own.keys;
+    int*& perm = own.perm;
+    int*& newmap = own.newmap;
+    float*& hb_new = own.hb_new;
+    auto fail = [&](hipError_t e, const char* what) {
         (void)hipGetLastError();
-        if (keys) (void)hipFree(keys);
-        if (perm) (void)hipFree(perm);
-        if (newmap) (void)hipFree(newmap);
-        if (hb_new) (void)hipFree(hb_new);
-        return e == hipErrorOutOfMemory ? SPKM_OK : (int)e; // (no room: the shard simply stays as it is)
+        if (e == hipErrorOutOfMemory) return (int)SPKM_OK; // (no room: the shard simply stays as it is)
+        snprintf(ctx->errmsg, sizeof(ctx->errmsg), "regroup_shard: %s: %s", what, hipGetErrorString(e));
+        return (int)e;                                     // (positive status = HIP error, as HIP_TRY returns it)
     };
     hipError_t e;
-    if ((e = hipMalloc((void**)&keys, (size_t)n * 4 + 64)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&perm, (size_t)n * 4 + 64)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&newmap, (size_t)n * 4 + 64)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&hb_new, ((size_t)3 * npad + HB_TAIL) * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&keys, (size_t)n * 4 + 64)) != hipSuccess) return fail(e, "hipMalloc(keys)");
+    if ((e = hipMalloc((void**)&perm, (size_t)n * 4 + 64)) != hipSuccess) return fail(e, "hipMalloc(perm)");
+    if ((e = hipMalloc((void**)&newmap, (size_t)n * 4 + 64)) != hipSuccess) return fail(e, "hipMalloc(map)");
+    if ((e = hipMalloc((void**)&hb_new, ((size_t)3 * npad + HB_TAIL) * 4)) != hipSuccess) return fail(e, "hipMalloc(bounds)");
     int rc;
     if ((rc = ensure(ctx, ctx->hist2, (size_t)K2 * 8))) return rc;
     if ((rc = ensure(ctx, ctx->offs2, (size_t)(K2 + 1) * 8))) return rc;
@@ -183,12 +211,12 @@ static int regroup_shard(spkm_ctx* ctx, spkm_shard* sm, int K)
                        (const char*)sm->rec, sm->rec_R, (const int*)newmap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // (once per shard and run: the old arrays go back now)
-    (void)hipFree(keys);
-    (void)hipFree(perm);
     (void)hipFree(sm->hb);
     if (sm->map) (void)hipFree(sm->map);
     sm->hb = hb_new;
     sm->map = newmap;
+    hb_new = nullptr; // (the shard's from here on; keys / perm go with the guard)
+    newmap = nullptr;
     sm->sp_clean = false;
     return SPKM_OK;
 }

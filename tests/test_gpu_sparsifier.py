@@ -126,3 +126,36 @@ def test_records_written_by_the_sparsifier_feed_the_engine_like_csc(gpu_ctx, ora
     assert shard.release_csc()                                             # ... and go again
     eng.iterate(c)
     assert np.array_equal(eng.assign.cpu().numpy(), ra)
+
+
+def test_record_shard_refuses_a_buffer_without_the_slack(gpu_ctx):
+    """spkm.h: the allocation behind d_rec must extend 256 bytes past the last record (the record kernels fetch ahead of their
+    bounds check).  No size crosses the C boundary, so the entry point asks the runtime for the allocation the pointer lies
+    in: a raw hipMalloc of exactly n * R bytes is refused with SPKM_ERR_BAD_VALUE, one with the slack is taken."""
+    import ctypes as C
+    import os
+
+    from sparsifiedkmeans_amd import _lib
+    from sparsifiedkmeans_amd.engine import record_bytes
+
+    L = _lib.lib()
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), mode=C.RTLD_GLOBAL)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    p, n, s = 1024, 8192, 51
+    R = record_bytes(s, 16)
+    for extra, ok in ((0, False), (255, False), (256, True)):
+        buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), n * R + extra) == 0
+        try:
+            h = C.c_void_p()
+            rc = L.spkm_shard_create_rec_dev(gpu_ctx.handle, p, n, s, 16, buf, C.byref(h))
+            if ok:
+                assert rc == 0 and h.value
+                L.spkm_shard_destroy(h)
+            else:
+                assert rc == _lib.ERR_BAD_VALUE, (extra, rc)
+                assert b"slack" in L.spkm_ctx_last_error(gpu_ctx.handle)
+        finally:
+            torch.cuda.synchronize()
+            hip.hipFree(buf)
