@@ -49,15 +49,19 @@ def evaluate(C):
     D2 = torch.empty((m, K), device="cuda")
     Pst = {A: torch.empty((m, K), device="cuda") for A in ROUNDS}
     Psr = {A: torch.empty((m, K), device="cuda") for A in ROUNDS}
+    P16 = {A: torch.empty((m, K), device="cuda") for A in ROUNDS}     # round 6: |x| order, x and c rounded to f16, f32 sums
+    X16 = X.half().float()
     for k0 in range(0, K, 10):
         G = Cm[k0:k0 + 10][:, R]                                      # [10, m, s]
         T = (X[None] - G) ** 2
         D2[:, k0:k0 + 10] = T.sum(-1).t()
         Ts = torch.gather(T, 2, ordr[None].expand(T.shape[0], -1, -1))
+        T16 = torch.gather((X16[None] - G.half().float()) ** 2, 2, ordr[None].expand(T.shape[0], -1, -1))
         for A in ROUNDS:
             Pst[A][:, k0:k0 + 10] = T[:, :, : 4 * A].sum(-1).t()
             Psr[A][:, k0:k0 + 10] = Ts[:, :, : 4 * A].sum(-1).t()
-    return D2, Pst, Psr
+            P16[A][:, k0:k0 + 10] = T16[:, :, : 4 * A].sum(-1).t()
+    return D2, Pst, Psr, P16
 
 TILES = [torch.arange(0, 32, device="cuda"), torch.arange(32, 64, device="cuda"), torch.arange(64, 100, device="cuda")]
 def groups_of(size, perm=None):
@@ -110,7 +114,7 @@ schemes = [Scheme("hamerly", K, "static"), Scheme("tile32", 32, "static"), Schem
 prev_c = None
 for it in range(1, iters + 1):
     cur = centers.clone()
-    D2, Pst, Psr = evaluate(cur)
+    D2, Pst, Psr, P16 = evaluate(cur)
     D = D2.sqrt()
     eng.iterate(centers)
     a_true = D.argmin(1)
@@ -131,6 +135,8 @@ for it in range(1, iters + 1):
         ub_prev = D_prev[ar, a_prev]
         hint_lib2 = ub_prev ** 2 + (2.0 * s / p2) * full2[a_prev]
         hint_best2 = D2[ar, a_prev]
+        xnorm = X.pow(2).sum(1).sqrt()
+        cmax = float((cur / gamma).abs().max().item())
         out = []
         for A in ROUNDS:
             row = [f"A={A}:"]
@@ -141,6 +147,17 @@ for it in range(1, iters + 1):
                         m2 = P[:, gi].topk(2, dim=1, largest=False).values[:, 1]
                         fin.append((m2 >= 1.5 * h2).view(-1, 16).all(1))
                     row.append(f"{nm}/{hn} {torch.stack(fin, 1).float().mean().item():.3f}")
+            # round 6: the same question asked of an f16 first phase -- x and c rounded to f16 (f32 sums), the
+            # input rounding folded into the bound: sqrt(P_true) >= sqrt(P16) - 2^-11 (|x|_A + |c|_A) with |x|_A <= the point's
+            # norm and |c|_A <= sqrt(4 A) max|c| (what the kernel would have at hand)
+            e16 = 2.0 ** -11 * (xnorm + float(np.sqrt(4.0 * A)) * cmax)
+            for hn, h2 in (("lib", hint_lib2), ("best", hint_best2)):
+                fin = []
+                for gi in TILES:
+                    m2 = P16[A][:, gi].topk(2, dim=1, largest=False).values[:, 1]
+                    lb = (m2.sqrt() - e16).clamp_min(0.0) ** 2
+                    fin.append((lb >= 1.5 * h2).view(-1, 16).all(1))
+                row.append(f"f16/{hn} {torch.stack(fin, 1).float().mean().item():.3f}")
             out.append(" ".join(row))
         print("      early-finished (step, tile) pairs  " + "  |  ".join(out), flush=True)
         # (3) what a partial sum is worth as a carried LOWER bound: sqrt(min over the other centroids) -- median / 1 % quantile over
